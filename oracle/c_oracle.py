@@ -1,0 +1,147 @@
+"""ctypes loader for oracle/libparl_oracle.so (the plain-C restatement) with numpy in/out.
+
+TEST INFRASTRUCTURE ONLY — see oracle/__init__.py."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, 'libparl_oracle.so')
+_lib = None
+
+
+def build():
+    subprocess.check_call(['make', '-C', _HERE, '-s'])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        _lib = ctypes.CDLL(_LIB)
+        _lib.oracle_philox_uniform53.restype = ctypes.c_double
+        _lib.oracle_philox_uniform53.argtypes = [ctypes.c_uint64] * 3
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+_NAN = float('nan')
+
+
+def _thr(x):
+    return _NAN if x is None else float(x)
+
+
+def vtrace(blp, tlp, discounts, rewards, values, bootstrap, clip_rho=1.0, clip_pg_rho=1.0):
+    blp, tlp, discounts, rewards, values = [_c(x, np.float32) for x in (blp, tlp, discounts, rewards, values)]
+    bootstrap = _c(bootstrap, np.float32)
+    T, B = blp.shape
+    vs = np.empty((T, B), np.float32)
+    pg = np.empty((T, B), np.float32)
+    rc = lib().oracle_vtrace_f32(_p(blp), _p(tlp), _p(discounts), _p(rewards), _p(values), _p(bootstrap),
+                                 _p(vs), _p(pg), T, B, ctypes.c_float(_thr(clip_rho)),
+                                 ctypes.c_float(_thr(clip_pg_rho)))
+    assert rc == 0
+    return vs, pg
+
+
+def vtrace_from_logits(blogits, tlogits, actions, rewards, dones, values, gamma, clip_rho=1.0,
+                       clip_pg_rho=1.0, time_major=True):
+    blogits, tlogits = _c(blogits, np.float32), _c(tlogits, np.float32)
+    actions = _c(actions, np.int64)
+    rewards, values = _c(rewards, np.float32), _c(values, np.float32)
+    dones = _c(dones, np.uint8)
+    if time_major:
+        T, B, A = tlogits.shape
+        osh = (T - 1, B)
+    else:
+        B, T, A = tlogits.shape
+        osh = (B, T - 1)
+    vs, pg, tlp, blp = [np.zeros(osh, np.float32) for _ in range(4)]
+    rc = lib().oracle_vtrace_from_logits_f32(_p(blogits), _p(tlogits), _p(actions), _p(rewards), _p(dones),
+                                             _p(values), _p(vs), _p(pg), _p(tlp), _p(blp), T, B, A,
+                                             1 if time_major else 0, ctypes.c_float(gamma),
+                                             ctypes.c_float(_thr(clip_rho)), ctypes.c_float(_thr(clip_pg_rho)))
+    assert rc == 0
+    return vs, pg, tlp, blp
+
+
+def gae(rewards, values, dones, next_value, gamma, lam, last_done=None, done_convention=0, accum_f64=False):
+    rewards, values = _c(rewards, np.float32), _c(values, np.float32)
+    next_value = _c(next_value, np.float32).reshape(-1)
+    dones = np.ascontiguousarray(dones)
+    is_f32 = dones.dtype == np.float32
+    if not is_f32:
+        dones = _c(dones, np.uint8)
+    if last_done is not None:
+        last_done = _c(last_done, dones.dtype).reshape(-1)
+    T, B = rewards.shape
+    adv = np.empty((T, B), np.float32)
+    ret = np.empty((T, B), np.float32)
+    rc = lib().oracle_gae_f32(_p(rewards), _p(values), _p(dones), _p(next_value), _p(last_done), _p(adv), _p(ret),
+                              T, B, ctypes.c_float(gamma), ctypes.c_float(lam), int(done_convention),
+                              1 if is_f32 else 0, 1 if accum_f64 else 0)
+    assert rc == 0
+    return adv, ret
+
+
+def discount_cumsum(x, gamma, dones=None, accum_f64=False):
+    x = _c(x, np.float32)
+    T, B = x.shape
+    if dones is not None:
+        dones = _c(dones, np.uint8)
+    out = np.empty((T, B), np.float32)
+    rc = lib().oracle_discount_cumsum_f32(_p(x), _p(dones), _p(out), T, B, ctypes.c_float(gamma),
+                                          1 if accum_f64 else 0)
+    assert rc == 0
+    return out
+
+
+def adv_normalize(adv, idx=None, eps=1e-8):
+    adv = _c(adv, np.float32).reshape(-1)
+    if idx is not None:
+        idx = _c(idx, np.int64).reshape(-1)
+        n = idx.size
+    else:
+        n = adv.size
+    out = np.empty(n, np.float32)
+    ms = np.empty(2, np.float32)
+    rc = lib().oracle_adv_normalize_f32(_p(adv), _p(idx), _p(out), ctypes.c_int64(n), ctypes.c_float(eps), _p(ms))
+    assert rc == 0
+    return out, ms
+
+
+def categorical_sample(probs, uniforms):
+    probs = _c(probs, np.float32)
+    uniforms = _c(uniforms, np.float64)
+    B, A = probs.shape
+    actions = np.empty(B, np.int64)
+    rc = lib().oracle_categorical_sample_f32(_p(probs), _p(uniforms), _p(actions), B, A)
+    assert rc == 0
+    return actions
+
+
+def philox_uniform53(seed, offset, row):
+    return lib().oracle_philox_uniform53(seed, offset, row)
+
+
+def policy_sample(x, seed, offset, row0=0, is_logits=True):
+    x = _c(x, np.float32)
+    B, A = x.shape
+    actions = np.empty(B, np.int64)
+    probs = np.empty((B, A), np.float32)
+    uni = np.empty(B, np.float64)
+    rc = lib().oracle_policy_sample_f32(_p(x), 1 if is_logits else 0, _p(actions), _p(probs), _p(uni), B, A,
+                                        ctypes.c_uint64(seed), ctypes.c_uint64(offset), ctypes.c_uint64(row0))
+    assert rc == 0
+    return actions, probs, uni

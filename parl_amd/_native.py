@@ -1,0 +1,100 @@
+"""ctypes binding of libparl_hip.so (the C ABI declared in include/parl_hip.h).
+
+The library is the product: if it is missing, or a call fails, this module raises — there is
+no CPU or eager-PyTorch fallback anywhere in parl_amd (oracle/ is test infrastructure and is
+never imported from here).
+
+torch must be imported before the library is loaded so that libparl_hip.so binds to the same
+libamdhip64.so.7 the torch allocator uses (device pointers are shared across the boundary).
+"""
+import ctypes
+import os
+import threading
+
+import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libparl_hip.so')
+
+c_f32p = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_p = ctypes.c_void_p
+_u64 = ctypes.c_uint64
+_i64 = ctypes.c_int64
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); kept in lock-step with include/parl_hip.h
+# (tests/test_capi_symbols.py parses the header and checks every declared symbol is here
+# and exported by the .so).
+SIGNATURES = {
+    'parlhip_version': (_i, []),
+    'parlhip_strerror': (ctypes.c_char_p, [_i]),
+    'parlhip_last_hip_error': (_i, []),
+    'parlhip_consume_device_errors': (_i, [_p]),
+    'parlhip_vtrace_f32': (_i, [_p] * 8 + [_i, _i, _f, _f, _p]),
+    'parlhip_vtrace_from_logits_f32':
+    (_i, [_p] * 10 + [_i, _i, _i, _i, _f, _f, _f, _p]),
+    'parlhip_gae_f32': (_i, [_p] * 7 + [_i, _i, _f, _f, _i, _i, _p]),
+    'parlhip_discount_cumsum_f32': (_i, [_p, _p, _p, _i, _i, _f, _p]),
+    'parlhip_adv_normalize_workspace_bytes': (_sz, [_i64]),
+    'parlhip_adv_normalize_f32': (_i, [_p, _p, _p, _i64, _f, _p, _sz, _p, _p]),
+    'parlhip_categorical_sample_f32': (_i, [_p, _p, _p, _i, _i, _p]),
+    'parlhip_policy_sample_f32':
+    (_i, [_p, _i, _p, _p, _p, _i, _i, _u64, _u64, _u64, _p]),
+}
+
+
+class ParlHipError(RuntimeError):
+    """A libparl_hip.so entry point returned a negative PARLHIP_E* code."""
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    'parl_amd: %s not found. Build it with `python -c "import '
+                    '__graft_entry__ as g; g.build()"` or `make -C parl_amd/csrc`. '
+                    'There is no fallback path.' % LIB_PATH)
+            handle = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(handle, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code < 0:
+        l = lib()
+        msg = l.parlhip_strerror(code).decode()
+        raise ParlHipError('%s failed: %s (code %d, hip error %d)' %
+                           (what, msg, code, l.parlhip_last_hip_error()))
+    return code
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ParlHipError('parl_amd ops need device (HIP) tensors; got a %s tensor. '
+                           'There is no CPU fallback.' % t.device)
+    if not t.is_contiguous():
+        raise ParlHipError('parl_amd ops need contiguous tensors')
+    return t.data_ptr()
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream as an integer handle."""
+    return torch.cuda.current_stream().cuda_stream

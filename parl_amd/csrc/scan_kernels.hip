@@ -1,0 +1,624 @@
+// scan_kernels.hip — V-trace / GAE / discounted-sum reverse scans for gfx950 (MI355X).
+//
+// Reference arithmetic (paths relative to the PARL tree):
+//   parl/algorithms/paddle/impala/vtrace.py:36-139   from_importance_weights
+//   parl/algorithms/paddle/impala/impala.py:59,119-132,167-194   discounts, _log_prob, slicing
+//   parl/utils/rl_utils.py:21-51 + examples/A2C/actor.py:73-85   calc_gae / segments
+//   examples/PPO/storage.py:45-64                                 RolloutStorage.compute_returns
+//
+// All of these are HBM-bound reverse linear recurrences over [T,B] float32 slabs.  Two
+// mappings are used:
+//   * lane-per-sequence (time-major input, B contiguous): every load of a wave is one
+//     coalesced 256 B (VEC=1) or 1 KiB (VEC=4, float4) segment; the carry lives in registers
+//     and the loads of U consecutive time steps are issued before the dependent FMA chain so
+//     U*5 wide loads per lane are in flight.
+//   * wave-per-sequence (env-major input, T contiguous — the reference's flat [B*T] batch):
+//     lane l owns time steps [l*K, l*K+K), loads are coalesced along T, and the affine
+//     recurrence acc_t = d_t + a_t*acc_{t+1} is solved with a 6-step wavefront-shuffle suffix
+//     scan over (a, d) pairs; neighbours' V_{t+1} / vs_{t+1} come from one more shuffle.
+#include "common.hpp"
+#include <math.h>
+
+namespace parlhip {
+
+// ----------------------------------------------------------------------------------------
+// small vector helpers (VEC = 1 or 4 sequences per lane)
+// ----------------------------------------------------------------------------------------
+template <int VEC> struct Vec;
+template <> struct Vec<1> {
+  float v[1];
+  __device__ static Vec load(const float* p) { Vec r; r.v[0] = *p; return r; }
+  __device__ void store(float* p) const { *p = v[0]; }
+};
+template <> struct Vec<4> {
+  float v[4];
+  __device__ static Vec load(const float* p) {
+    float4 q = *reinterpret_cast<const float4*>(p);
+    Vec r; r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w; return r;
+  }
+  __device__ void store(float* p) const {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+
+template <int VEC> struct U8Vec;
+template <> struct U8Vec<1> {
+  uint8_t v[1];
+  __device__ static U8Vec load(const uint8_t* p) { U8Vec r; r.v[0] = *p; return r; }
+};
+template <> struct U8Vec<4> {
+  uint8_t v[4];
+  __device__ static U8Vec load(const uint8_t* p) {
+    uint32_t q = *reinterpret_cast<const uint32_t*>(p);
+    U8Vec r; r.v[0] = q & 0xff; r.v[1] = (q >> 8) & 0xff; r.v[2] = (q >> 16) & 0xff;
+    r.v[3] = (q >> 24) & 0xff; return r;
+  }
+};
+
+__device__ __forceinline__ float clip_max(float x, float thr) {
+  // NaN threshold == the reference's `None`: no clipping (vtrace.py:102-105)
+  return (thr != thr) ? x : fminf(x, thr);
+}
+
+// ----------------------------------------------------------------------------------------
+// V-trace, lane-per-sequence, time-major, from log-probs.  28 B per (t,b) element.
+// ----------------------------------------------------------------------------------------
+template <int VEC, int U>
+__global__ __launch_bounds__(256) void vtrace_tm_kernel(
+    const float* __restrict__ blp, const float* __restrict__ tlp,
+    const float* __restrict__ disc, const float* __restrict__ rew,
+    const float* __restrict__ val, const float* __restrict__ boot,
+    float* __restrict__ vs, float* __restrict__ pg, int T, int B, float clip_rho,
+    float clip_pg) {
+  const int64_t b0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  if (b0 >= B) return;
+  float acc[VEC], vs_next[VEC], v_next[VEC];
+  {
+    Vec<VEC> bv = Vec<VEC>::load(boot + b0);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { acc[j] = 0.f; vs_next[j] = bv.v[j]; v_next[j] = bv.v[j]; }
+  }
+  int t = T - 1;
+  // main loop: U time steps per iteration, all loads issued before the dependent chain
+  for (; t - (U - 1) >= 0; t -= U) {
+    Vec<VEC> l_b[U], l_t[U], l_d[U], l_r[U], l_v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = (int64_t)(t - u) * B + b0;
+      l_b[u] = Vec<VEC>::load(blp + i);
+      l_t[u] = Vec<VEC>::load(tlp + i);
+      l_d[u] = Vec<VEC>::load(disc + i);
+      l_r[u] = Vec<VEC>::load(rew + i);
+      l_v[u] = Vec<VEC>::load(val + i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = (int64_t)(t - u) * B + b0;
+      Vec<VEC> o_vs, o_pg;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float rho = expf(l_t[u].v[j] - l_b[u].v[j]);
+        const float crho = clip_max(rho, clip_rho);
+        const float c = fminf(rho, 1.0f);
+        const float d = l_d[u].v[j], v = l_v[u].v[j], r = l_r[u].v[j];
+        const float delta = crho * (r + d * v_next[j] - v);
+        acc[j] = delta + d * c * acc[j];
+        const float vst = acc[j] + v;
+        o_pg.v[j] = clip_max(rho, clip_pg) * (r + d * vs_next[j] - v);
+        o_vs.v[j] = vst;
+        vs_next[j] = vst;
+        v_next[j] = v;
+      }
+      o_vs.store(vs + i);
+      o_pg.store(pg + i);
+    }
+  }
+  for (; t >= 0; --t) {
+    const int64_t i = (int64_t)t * B + b0;
+    Vec<VEC> xb = Vec<VEC>::load(blp + i), xt = Vec<VEC>::load(tlp + i),
+             xd = Vec<VEC>::load(disc + i), xr = Vec<VEC>::load(rew + i),
+             xv = Vec<VEC>::load(val + i), o_vs, o_pg;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float rho = expf(xt.v[j] - xb.v[j]);
+      const float crho = clip_max(rho, clip_rho);
+      const float c = fminf(rho, 1.0f);
+      const float d = xd.v[j], v = xv.v[j], r = xr.v[j];
+      const float delta = crho * (r + d * v_next[j] - v);
+      acc[j] = delta + d * c * acc[j];
+      const float vst = acc[j] + v;
+      o_pg.v[j] = clip_max(rho, clip_pg) * (r + d * vs_next[j] - v);
+      o_vs.v[j] = vst;
+      vs_next[j] = vst;
+      v_next[j] = v;
+    }
+    o_vs.store(vs + i);
+    o_pg.store(pg + i);
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// log-softmax gather (IMPALA._log_prob, impala.py:119-132)
+// ----------------------------------------------------------------------------------------
+template <int A_CT>
+__device__ __forceinline__ float log_prob_row(const float* __restrict__ row, int A, int a) {
+  const int n = A_CT > 0 ? A_CT : A;
+  if (A_CT > 0) {
+    float x[A_CT > 0 ? A_CT : 1];
+#pragma unroll
+    for (int k = 0; k < A_CT; ++k) x[k] = row[k];
+    float m = x[0];
+#pragma unroll
+    for (int k = 1; k < A_CT; ++k) m = fmaxf(m, x[k]);
+    float s = 0.f, xa = x[0];
+#pragma unroll
+    for (int k = 0; k < A_CT; ++k) {
+      s += expf(x[k] - m);
+      xa = (k == a) ? x[k] : xa;
+    }
+    return (xa - m) - logf(s);
+  } else {
+    float m = row[0];
+    for (int k = 1; k < n; ++k) m = fmaxf(m, row[k]);
+    float s = 0.f;
+    for (int k = 0; k < n; ++k) s += expf(row[k] - m);
+    return (row[a] - m) - logf(s);
+  }
+}
+
+// V-trace fused from logits, lane-per-sequence, time-major [T,B,A].
+template <int A_CT>
+__global__ __launch_bounds__(256) void vtrace_logits_tm_kernel(
+    const float* __restrict__ blog, const float* __restrict__ tlog,
+    const int64_t* __restrict__ actions, const float* __restrict__ rew,
+    const uint8_t* __restrict__ dones, const float* __restrict__ val,
+    float* __restrict__ vs, float* __restrict__ pg, float* __restrict__ tlp_out,
+    float* __restrict__ blp_out, int T, int B, int A, float gamma, float clip_rho,
+    float clip_pg, int* __restrict__ err) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float bootstrap = val[(int64_t)(T - 1) * B + b];
+  float acc = 0.f, vs_next = bootstrap, v_next = bootstrap;
+#pragma unroll 2
+  for (int t = T - 2; t >= 0; --t) {
+    const int64_t i = (int64_t)t * B + b;
+    int a = (int)actions[i];
+    if (a < 0 || a >= A) { *err = 1; a = 0; }
+    const float tl = log_prob_row<A_CT>(tlog + i * A, A, a);
+    const float bl = log_prob_row<A_CT>(blog + i * A, A, a);
+    const float d = dones[i] ? 0.f : gamma;
+    const float rho = expf(tl - bl);
+    const float crho = clip_max(rho, clip_rho);
+    const float c = fminf(rho, 1.0f);
+    const float v = val[i], r = rew[i];
+    const float delta = crho * (r + d * v_next - v);
+    acc = delta + d * c * acc;
+    const float vst = acc + v;
+    pg[i] = clip_max(rho, clip_pg) * (r + d * vs_next - v);
+    vs[i] = vst;
+    if (tlp_out) tlp_out[i] = tl;
+    if (blp_out) blp_out[i] = bl;
+    vs_next = vst;
+    v_next = v;
+  }
+}
+
+// V-trace fused from logits, wave-per-sequence, env-major [B,T,A] (reference flat batch).
+// Lane l owns time steps t = l*K + k, k < K; suffix scan over affine pairs with shuffles.
+template <int A_CT, int K>
+__global__ __launch_bounds__(256) void vtrace_logits_em_kernel(
+    const float* __restrict__ blog, const float* __restrict__ tlog,
+    const int64_t* __restrict__ actions, const float* __restrict__ rew,
+    const uint8_t* __restrict__ dones, const float* __restrict__ val,
+    float* __restrict__ vs, float* __restrict__ pg, float* __restrict__ tlp_out,
+    float* __restrict__ blp_out, int T, int B, int A, float gamma, float clip_rho,
+    float clip_pg, int* __restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (b >= B) return;  // whole wave exits together
+  const int Tm = T - 1;
+  const int64_t base = b * T;
+  const float bootstrap = val[base + Tm];
+
+  float rho[K], dsc[K], v[K], r[K], tl[K], bl[K];
+  bool valid[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int t = lane * K + k;
+    valid[k] = t < Tm;
+    rho[k] = 1.f; dsc[k] = 0.f; v[k] = 0.f; r[k] = 0.f; tl[k] = 0.f; bl[k] = 0.f;
+    if (valid[k]) {
+      const int64_t i = base + t;
+      int a = (int)actions[i];
+      if (a < 0 || a >= A) { *err = 1; a = 0; }
+      tl[k] = log_prob_row<A_CT>(tlog + i * A, A, a);
+      bl[k] = log_prob_row<A_CT>(blog + i * A, A, a);
+      dsc[k] = dones[i] ? 0.f : gamma;
+      rho[k] = expf(tl[k] - bl[k]);
+      v[k] = val[i];
+      r[k] = rew[i];
+    }
+  }
+  // V_{t+1}: next step in-lane, or the first value of the next lane, or the bootstrap.
+  const float v_first_next_lane = __shfl_down(v[0], 1, 64);
+  float v_next[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int t = lane * K + k;
+    float nv = (k + 1 < K) ? v[(k + 1 < K) ? k + 1 : k] : v_first_next_lane;
+    if (t + 1 >= Tm) nv = bootstrap;
+    v_next[k] = nv;
+  }
+  // per-step affine maps acc_t = d_t + a_t * acc_{t+1}; invalid steps are identity.
+  float a_[K], d_[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float crho = clip_max(rho[k], clip_rho);
+    const float c = fminf(rho[k], 1.0f);
+    d_[k] = valid[k] ? crho * (r[k] + dsc[k] * v_next[k] - v[k]) : 0.f;
+    a_[k] = valid[k] ? dsc[k] * c : 1.f;
+  }
+  // lane-local composition over [l*K, l*K+K): (LA, LD)
+  float LA = 1.f, LD = 0.f;
+#pragma unroll
+  for (int k = K - 1; k >= 0; --k) {
+    LD = d_[k] + a_[k] * LD;
+    LA = a_[k] * LA;
+  }
+  // inclusive suffix scan across lanes (Hillis–Steele, 6 shuffle steps)
+  float SA = LA, SD = LD;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float oa = __shfl_down(SA, off, 64);
+    const float od = __shfl_down(SD, off, 64);
+    if (lane + off < 64) {
+      SD = SD + SA * od;
+      SA = SA * oa;
+    }
+  }
+  // carry entering this lane's block = suffix result of lane+1 (0 for the last lane)
+  float carry = __shfl_down(SD, 1, 64);
+  if (lane == 63) carry = 0.f;
+  float vst[K];
+#pragma unroll
+  for (int k = K - 1; k >= 0; --k) {
+    carry = d_[k] + a_[k] * carry;
+    vst[k] = carry + v[k];
+  }
+  const float vs_first_next_lane = __shfl_down(vst[0], 1, 64);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int t = lane * K + k;
+    if (!valid[k]) continue;
+    float nvs = (k + 1 < K) ? vst[(k + 1 < K) ? k + 1 : k] : vs_first_next_lane;
+    if (t + 1 >= Tm) nvs = bootstrap;
+    const int64_t o = b * Tm + t;
+    pg[o] = clip_max(rho[k], clip_pg) * (r[k] + dsc[k] * nvs - v[k]);
+    vs[o] = vst[k];
+    if (tlp_out) tlp_out[o] = tl[k];
+    if (blp_out) blp_out[o] = bl[k];
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// GAE / n-step return, lane-per-sequence, time-major.
+// ----------------------------------------------------------------------------------------
+template <int VEC, int U, bool DONE_F32, int CONV>
+__global__ __launch_bounds__(256) void gae_tm_kernel(
+    const float* __restrict__ rew, const float* __restrict__ val,
+    const void* __restrict__ dones_v, const float* __restrict__ next_value,
+    const void* __restrict__ last_done_v, float* __restrict__ adv,
+    float* __restrict__ ret, int T, int B, float gamma, float gl) {
+  const int64_t b0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  if (b0 >= B) return;
+  const float* dones_f = (const float*)dones_v;
+  const uint8_t* dones_u = (const uint8_t*)dones_v;
+  float carry[VEC], v_next[VEC], nnt_next[VEC];
+  {
+    Vec<VEC> nv = Vec<VEC>::load(next_value + b0);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { carry[j] = 0.f; v_next[j] = nv.v[j]; nnt_next[j] = 1.f; }
+    if (CONV == PARLHIP_GAE_DONE_STARTS_STEP) {
+      if (DONE_F32) {
+        Vec<VEC> ld = Vec<VEC>::load((const float*)last_done_v + b0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) nnt_next[j] = 1.0f - ld.v[j];
+      } else {
+        U8Vec<VEC> ld = U8Vec<VEC>::load((const uint8_t*)last_done_v + b0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) nnt_next[j] = 1.0f - (float)ld.v[j];
+      }
+    }
+  }
+  auto step = [&](const Vec<VEC>& xr, const Vec<VEC>& xv, const float* dn, int64_t i) {
+    Vec<VEC> oa, orr;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float r = xr.v[j], v = xv.v[j];
+      if (CONV == PARLHIP_GAE_DONE_ENDS_STEP) {
+        const bool done = dn[j] != 0.f;
+        const float nv = done ? 0.f : v_next[j];
+        const float td = r + gamma * nv - v;
+        carry[j] = done ? td : td + gl * carry[j];
+      } else {
+        // storage.py:57-60, op order preserved (float32 numpy)
+        const float nnt = nnt_next[j];
+        const float delta = r + gamma * v_next[j] * nnt - v;
+        carry[j] = delta + gl * nnt * carry[j];
+        nnt_next[j] = 1.0f - dn[j];   // 1 - dones[t] feeds step t-1
+      }
+      oa.v[j] = carry[j];
+      orr.v[j] = carry[j] + v;
+      v_next[j] = v;
+    }
+    if (adv) oa.store(adv + i);
+    if (ret) orr.store(ret + i);
+  };
+  int t = T - 1;
+  for (; t - (U - 1) >= 0; t -= U) {
+    Vec<VEC> l_r[U], l_v[U];
+    float l_d[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = (int64_t)(t - u) * B + b0;
+      l_r[u] = Vec<VEC>::load(rew + i);
+      l_v[u] = Vec<VEC>::load(val + i);
+      if (DONE_F32) {
+        Vec<VEC> d = Vec<VEC>::load(dones_f + i);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) l_d[u][j] = d.v[j];
+      } else {
+        U8Vec<VEC> d = U8Vec<VEC>::load(dones_u + i);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) l_d[u][j] = (float)d.v[j];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(l_r[u], l_v[u], l_d[u], (int64_t)(t - u) * B + b0);
+  }
+  for (; t >= 0; --t) {
+    const int64_t i = (int64_t)t * B + b0;
+    Vec<VEC> xr = Vec<VEC>::load(rew + i), xv = Vec<VEC>::load(val + i);
+    float dn[VEC];
+    if (DONE_F32) {
+      Vec<VEC> d = Vec<VEC>::load(dones_f + i);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dn[j] = d.v[j];
+    } else {
+      U8Vec<VEC> d = U8Vec<VEC>::load(dones_u + i);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dn[j] = (float)d.v[j];
+    }
+    step(xr, xv, dn, i);
+  }
+}
+
+template <int VEC, int U>
+__global__ __launch_bounds__(256) void discount_cumsum_kernel(
+    const float* __restrict__ x, const uint8_t* __restrict__ dones,
+    float* __restrict__ out, int T, int B, float gamma) {
+  const int64_t b0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  if (b0 >= B) return;
+  float carry[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) carry[j] = 0.f;
+  int t = T - 1;
+  for (; t >= 0; t -= U) {
+    Vec<VEC> lx[U];
+    U8Vec<VEC> ld[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (t - u < 0) continue;
+      const int64_t i = (int64_t)(t - u) * B + b0;
+      lx[u] = Vec<VEC>::load(x + i);
+      if (dones) ld[u] = U8Vec<VEC>::load(dones + i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (t - u < 0) continue;
+      const int64_t i = (int64_t)(t - u) * B + b0;
+      Vec<VEC> o;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const bool done = dones && ld[u].v[j];
+        carry[j] = done ? lx[u].v[j] : lx[u].v[j] + gamma * carry[j];
+        o.v[j] = carry[j];
+      }
+      o.store(out + i);
+    }
+  }
+}
+
+// per-thread error flag used by the logits kernels (bad action index)
+__device__ int g_action_err;
+
+}  // namespace parlhip
+
+using namespace parlhip;
+
+// address of the device-side "bad action index" word (resolved once per process)
+static int* action_err_ptr() {
+  static int* p = nullptr;
+  if (!p) {
+    int* q = nullptr;
+    if (check(hipGetSymbolAddress((void**)&q, HIP_SYMBOL(g_action_err))) != PARLHIP_OK)
+      return nullptr;
+    p = q;
+  }
+  return p;
+}
+
+PARLHIP_EXPORT int parlhip_consume_device_errors(parlhip_stream_t stream) {
+  int* p = action_err_ptr();
+  if (!p) return PARLHIP_ELAUNCH;
+  int h = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (check(hipMemcpyAsync(&h, p, sizeof(int), hipMemcpyDeviceToHost, s))) return PARLHIP_ELAUNCH;
+  if (check(hipStreamSynchronize(s))) return PARLHIP_ELAUNCH;
+  if (h) {
+    if (check(hipMemsetAsync(p, 0, sizeof(int), s))) return PARLHIP_ELAUNCH;
+    if (check(hipStreamSynchronize(s))) return PARLHIP_ELAUNCH;
+  }
+  return h;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Choose VEC: float4 lanes need B % 4 == 0, 16-B aligned bases, and enough sequences that a
+// quarter as many lanes still fill the chip (>= 2 waves per SIMD over 256 CUs).
+static inline bool use_vec4(int B, std::initializer_list<const void*> ptrs) {
+  if (B % 4 != 0) return false;
+  if ((int64_t)B / 4 < (int64_t)kNumCU * 4 * kWave * 2) return false;
+  for (const void* p : ptrs)
+    if (p && !aligned16(p)) return false;
+  return true;
+}
+
+PARLHIP_EXPORT int parlhip_vtrace_f32(const float* blp, const float* tlp,
+                                  const float* discounts, const float* rewards,
+                                  const float* values, const float* bootstrap, float* vs,
+                                  float* pg, int T, int B, float clip_rho, float clip_pg,
+                                  parlhip_stream_t stream) {
+  if (T < 0 || B < 0) return PARLHIP_EINVAL;
+  if (T == 0 || B == 0) return PARLHIP_OK;
+  if (!blp || !tlp || !discounts || !rewards || !values || !bootstrap || !vs || !pg)
+    return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (use_vec4(B, {blp, tlp, discounts, rewards, values, bootstrap, vs, pg})) {
+    const int threads = B / 4;
+    vtrace_tm_kernel<4, 4><<<ceil_div(threads, 256), 256, 0, s>>>(
+        blp, tlp, discounts, rewards, values, bootstrap, vs, pg, T, B, clip_rho, clip_pg);
+  } else {
+    const int block = B >= 256 * 64 ? 256 : 64;
+    vtrace_tm_kernel<1, 8><<<ceil_div(B, block), block, 0, s>>>(
+        blp, tlp, discounts, rewards, values, bootstrap, vs, pg, T, B, clip_rho, clip_pg);
+  }
+  return check_launch();
+}
+
+template <int A_CT>
+static int launch_vtrace_logits(const float* blog, const float* tlog, const int64_t* actions,
+                                const float* rew, const uint8_t* dones, const float* val,
+                                float* vs, float* pg, float* tlp_out, float* blp_out, int T,
+                                int B, int A, int time_major, float gamma, float clip_rho,
+                                float clip_pg, hipStream_t s, int* err) {
+  if (time_major) {
+    const int block = B >= 256 * 64 ? 256 : 64;
+    vtrace_logits_tm_kernel<A_CT><<<ceil_div(B, block), block, 0, s>>>(
+        blog, tlog, actions, rew, dones, val, vs, pg, tlp_out, blp_out, T, B, A, gamma,
+        clip_rho, clip_pg, err);
+    return check_launch();
+  }
+  const int Tm = T - 1;
+  const int K = ceil_div(Tm, 64);
+  const int block = 256;  // 4 sequences per workgroup
+  const int grid = ceil_div((int64_t)B * 64, block);
+#define LAUNCH_EM(KK)                                                                    \
+  vtrace_logits_em_kernel<A_CT, KK><<<grid, block, 0, s>>>(                              \
+      blog, tlog, actions, rew, dones, val, vs, pg, tlp_out, blp_out, T, B, A, gamma,    \
+      clip_rho, clip_pg, err)
+  if (K <= 1) LAUNCH_EM(1);
+  else if (K <= 2) LAUNCH_EM(2);
+  else if (K <= 4) LAUNCH_EM(4);
+  else if (K <= 8) LAUNCH_EM(8);
+  else if (K <= 16) LAUNCH_EM(16);
+  else if (K <= 32) LAUNCH_EM(32);
+  else return PARLHIP_ENOSUP;  // T > 2049 env-major: transpose to time-major instead
+#undef LAUNCH_EM
+  return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_vtrace_from_logits_f32(
+    const float* blog, const float* tlog, const int64_t* actions, const float* rew,
+    const uint8_t* dones, const float* val, float* vs, float* pg, float* tlp_out,
+    float* blp_out, int T, int B, int A, int time_major, float gamma, float clip_rho,
+    float clip_pg, parlhip_stream_t stream) {
+  if (T < 1 || B < 0 || A < 1) return PARLHIP_EINVAL;
+  if (T == 1 || B == 0) return PARLHIP_OK;
+  if (!blog || !tlog || !actions || !rew || !dones || !val || !vs || !pg)
+    return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int* err = action_err_ptr();
+  if (!err) return PARLHIP_ELAUNCH;
+#define ARGS blog, tlog, actions, rew, dones, val, vs, pg, tlp_out, blp_out, T, B, A, \
+             time_major, gamma, clip_rho, clip_pg, s, err
+  switch (A) {
+    case 2: return launch_vtrace_logits<2>(ARGS);
+    case 3: return launch_vtrace_logits<3>(ARGS);
+    case 4: return launch_vtrace_logits<4>(ARGS);
+    case 6: return launch_vtrace_logits<6>(ARGS);
+    case 9: return launch_vtrace_logits<9>(ARGS);
+    case 18: return launch_vtrace_logits<18>(ARGS);
+    default: return launch_vtrace_logits<0>(ARGS);
+  }
+#undef ARGS
+}
+
+template <bool DONE_F32, int CONV>
+static int launch_gae(const float* rew, const float* val, const void* dones,
+                      const float* next_value, const void* last_done, float* adv, float* ret,
+                      int T, int B, float gamma, float gl, hipStream_t s) {
+  bool v4 = use_vec4(B, {rew, val, next_value, adv, ret});
+  if (v4) {
+    const uintptr_t dal = DONE_F32 ? 15 : 3;
+    if ((reinterpret_cast<uintptr_t>(dones) & dal) ||
+        (last_done && (reinterpret_cast<uintptr_t>(last_done) & dal)))
+      v4 = false;
+  }
+  if (v4) {
+    gae_tm_kernel<4, 4, DONE_F32, CONV><<<ceil_div(B / 4, 256), 256, 0, s>>>(
+        rew, val, dones, next_value, last_done, adv, ret, T, B, gamma, gl);
+  } else {
+    const int block = B >= 256 * 64 ? 256 : 64;
+    gae_tm_kernel<1, 8, DONE_F32, CONV><<<ceil_div(B, block), block, 0, s>>>(
+        rew, val, dones, next_value, last_done, adv, ret, T, B, gamma, gl);
+  }
+  return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_gae_f32(const float* rew, const float* val, const void* dones,
+                               const float* next_value, const void* last_done, float* adv,
+                               float* ret, int T, int B, float gamma, float lam,
+                               int done_convention, int dones_are_f32,
+                               parlhip_stream_t stream) {
+  if (T < 0 || B < 0) return PARLHIP_EINVAL;
+  if (T == 0 || B == 0) return PARLHIP_OK;
+  if (!rew || !val || !dones || !next_value || (!adv && !ret)) return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (done_convention == PARLHIP_GAE_DONE_ENDS_STEP) {
+    const float gl = gamma * lam;
+    return dones_are_f32
+               ? launch_gae<true, PARLHIP_GAE_DONE_ENDS_STEP>(rew, val, dones, next_value,
+                                                              nullptr, adv, ret, T, B, gamma, gl, s)
+               : launch_gae<false, PARLHIP_GAE_DONE_ENDS_STEP>(rew, val, dones, next_value,
+                                                               nullptr, adv, ret, T, B, gamma, gl, s);
+  }
+  if (done_convention == PARLHIP_GAE_DONE_STARTS_STEP) {
+    if (!last_done) return PARLHIP_EINVAL;
+    // Python: gamma * gae_lambda is a double product, rounded to f32 at the array op
+    const float gl = (float)((double)gamma * (double)lam);
+    return dones_are_f32
+               ? launch_gae<true, PARLHIP_GAE_DONE_STARTS_STEP>(rew, val, dones, next_value,
+                                                                last_done, adv, ret, T, B, gamma, gl, s)
+               : launch_gae<false, PARLHIP_GAE_DONE_STARTS_STEP>(rew, val, dones, next_value,
+                                                                 last_done, adv, ret, T, B, gamma, gl, s);
+  }
+  return PARLHIP_EINVAL;
+}
+
+PARLHIP_EXPORT int parlhip_discount_cumsum_f32(const float* x, const uint8_t* dones, float* out,
+                                           int T, int B, float gamma,
+                                           parlhip_stream_t stream) {
+  if (T < 0 || B < 0) return PARLHIP_EINVAL;
+  if (T == 0 || B == 0) return PARLHIP_OK;
+  if (!x || !out) return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  bool v4 = use_vec4(B, {x, out}) && !(reinterpret_cast<uintptr_t>(dones) & 3);
+  if (v4) {
+    discount_cumsum_kernel<4, 4><<<ceil_div(B / 4, 256), 256, 0, s>>>(x, dones, out, T, B, gamma);
+  } else {
+    const int block = B >= 256 * 64 ? 256 : 64;
+    discount_cumsum_kernel<1, 8><<<ceil_div(B, block), block, 0, s>>>(x, dones, out, T, B, gamma);
+  }
+  return check_launch();
+}

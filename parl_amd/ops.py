@@ -1,0 +1,211 @@
+"""Tensor-level wrappers over the C ABI (include/parl_hip.h).
+
+Every function takes HIP-resident torch tensors, enqueues the hand-written gfx950 kernel on
+torch's current stream and returns torch tensors.  Nothing here computes on the host and
+nothing falls back: a CPU tensor or a missing library raises ``ParlHipError``/``ImportError``.
+"""
+import math
+
+import torch
+
+from . import _native as N
+
+_NAN = float('nan')
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        raise N.ParlHipError('%s must be float32, got %s' % (name, t.dtype))
+    return t.contiguous()
+
+
+def _thr(x):
+    """Reference `None` threshold (vtrace.py:102-105) -> NaN sentinel of the C ABI."""
+    return _NAN if x is None else float(x)
+
+
+def vtrace(behaviour_actions_log_probs, target_actions_log_probs, discounts, rewards,
+           values, bootstrap_value, clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0):
+    """vtrace.from_importance_weights (parl/algorithms/paddle/impala/vtrace.py:36-139).
+
+    All [T,B] float32 time-major; returns (vs, pg_advantages)."""
+    blp = _f32(behaviour_actions_log_probs, 'behaviour_actions_log_probs')
+    tlp = _f32(target_actions_log_probs, 'target_actions_log_probs')
+    disc = _f32(discounts, 'discounts')
+    rew = _f32(rewards, 'rewards')
+    val = _f32(values, 'values')
+    boot = _f32(bootstrap_value, 'bootstrap_value')
+    T, B = blp.shape
+    vs = torch.empty_like(val)
+    pg = torch.empty_like(val)
+    N.check(
+        N.lib().parlhip_vtrace_f32(
+            N.ptr(blp), N.ptr(tlp), N.ptr(disc), N.ptr(rew), N.ptr(val), N.ptr(boot),
+            N.ptr(vs), N.ptr(pg), T, B, _thr(clip_rho_threshold),
+            _thr(clip_pg_rho_threshold), N.stream_ptr()), 'parlhip_vtrace_f32')
+    return vs, pg
+
+
+def vtrace_from_logits(behaviour_logits, target_logits, actions, rewards, dones, values,
+                       gamma, clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0,
+                       time_major=True, want_log_probs=False):
+    """Fused _log_prob ×2 + discounts + drop-last/bootstrap + V-trace
+    (impala.py:59,119-132,167-194 + vtrace.py:36-139).
+
+    Shapes: logits [T,B,A] (time_major) or [B,T,A]; actions int64, rewards f32, dones
+    bool/uint8, values f32 all [T,B] / [B,T].  Returns vs, pg_advantages (and the two
+    log-prob tensors if requested) with T-1 steps in the same major order."""
+    bl = _f32(behaviour_logits, 'behaviour_logits')
+    tl = _f32(target_logits, 'target_logits')
+    if time_major:
+        T, B, A = tl.shape
+        oshape = (T - 1, B)
+    else:
+        B, T, A = tl.shape
+        oshape = (B, T - 1)
+    if actions.dtype != torch.int64:
+        raise N.ParlHipError('actions must be int64')
+    actions = actions.contiguous()
+    rew = _f32(rewards, 'rewards')
+    val = _f32(values, 'values')
+    if dones.dtype == torch.bool:
+        dones = dones.contiguous().view(torch.uint8)
+    elif dones.dtype != torch.uint8:
+        raise N.ParlHipError('dones must be bool or uint8')
+    dones = dones.contiguous()
+    vs = torch.empty(oshape, dtype=torch.float32, device=val.device)
+    pg = torch.empty(oshape, dtype=torch.float32, device=val.device)
+    tlp = torch.empty(oshape, dtype=torch.float32, device=val.device) if want_log_probs else None
+    blp = torch.empty(oshape, dtype=torch.float32, device=val.device) if want_log_probs else None
+    N.check(
+        N.lib().parlhip_vtrace_from_logits_f32(
+            N.ptr(bl), N.ptr(tl), N.ptr(actions), N.ptr(rew), N.ptr(dones), N.ptr(val),
+            N.ptr(vs), N.ptr(pg), N.ptr(tlp), N.ptr(blp), T, B, A, 1 if time_major else 0,
+            float(gamma), _thr(clip_rho_threshold), _thr(clip_pg_rho_threshold),
+            N.stream_ptr()), 'parlhip_vtrace_from_logits_f32')
+    if want_log_probs:
+        return vs, pg, tlp, blp
+    return vs, pg
+
+
+GAE_DONE_ENDS_STEP = 0
+GAE_DONE_STARTS_STEP = 1
+
+
+def gae(rewards, values, dones, next_value, gamma, lam, last_done=None,
+        done_convention=GAE_DONE_ENDS_STEP):
+    """Batched calc_gae (rl_utils.py:34-51 with examples/A2C/actor.py:73-85 segments) or
+    RolloutStorage.compute_returns (examples/PPO/storage.py:45-64).
+
+    rewards/values [T,B] f32, dones [T,B] bool/uint8/float32, next_value [B].
+    Returns (advantages, returns) with returns = advantages + values."""
+    rew = _f32(rewards, 'rewards')
+    val = _f32(values, 'values')
+    nv = _f32(next_value, 'next_value').reshape(-1)
+    T, B = rew.shape
+    if dones.dtype == torch.bool:
+        dones = dones.contiguous().view(torch.uint8)
+    dones = dones.contiguous()
+    is_f32 = dones.dtype == torch.float32
+    if not is_f32 and dones.dtype != torch.uint8:
+        raise N.ParlHipError('dones must be bool, uint8 or float32')
+    if last_done is not None:
+        if last_done.dtype == torch.bool:
+            last_done = last_done.contiguous().view(torch.uint8)
+        last_done = last_done.contiguous().reshape(-1)
+        if last_done.dtype != dones.dtype:
+            raise N.ParlHipError('last_done must have the dtype of dones')
+    adv = torch.empty_like(val)
+    ret = torch.empty_like(val)
+    N.check(
+        N.lib().parlhip_gae_f32(
+            N.ptr(rew), N.ptr(val), N.ptr(dones), N.ptr(nv), N.ptr(last_done),
+            N.ptr(adv), N.ptr(ret), T, B, float(gamma), float(lam), int(done_convention),
+            1 if is_f32 else 0, N.stream_ptr()), 'parlhip_gae_f32')
+    return adv, ret
+
+
+def discount_cumsum(x, gamma, dones=None):
+    """Batched calc_discount_sum_rewards (rl_utils.py:21-31) over [T,B]."""
+    x = _f32(x, 'x')
+    T, B = x.shape
+    if dones is not None:
+        if dones.dtype == torch.bool:
+            dones = dones.contiguous().view(torch.uint8)
+        dones = dones.contiguous()
+    out = torch.empty_like(x)
+    N.check(
+        N.lib().parlhip_discount_cumsum_f32(
+            N.ptr(x), N.ptr(dones), N.ptr(out), T, B, float(gamma), N.stream_ptr()),
+        'parlhip_discount_cumsum_f32')
+    return out
+
+
+def adv_normalize(adv, idx=None, eps=1e-8, return_stats=False):
+    """(adv - mean) / (std + eps) with the unbiased std (ppo.py:124-127), optionally on the
+    gathered minibatch adv[idx]."""
+    adv = _f32(adv, 'adv').reshape(-1)
+    if idx is not None:
+        if idx.dtype != torch.int64:
+            raise N.ParlHipError('idx must be int64')
+        idx = idx.contiguous().reshape(-1)
+        n = idx.numel()
+    else:
+        n = adv.numel()
+    out = torch.empty(n, dtype=torch.float32, device=adv.device)
+    wsb = N.lib().parlhip_adv_normalize_workspace_bytes(n)
+    ws = torch.empty(max(wsb // 8, 1), dtype=torch.float64, device=adv.device)
+    stats = torch.empty(2, dtype=torch.float32, device=adv.device) if return_stats else None
+    N.check(
+        N.lib().parlhip_adv_normalize_f32(
+            N.ptr(adv), N.ptr(idx), N.ptr(out), n, float(eps), N.ptr(ws), wsb,
+            N.ptr(stats), N.stream_ptr()), 'parlhip_adv_normalize_f32')
+    if return_stats:
+        return out, stats
+    return out
+
+
+def categorical_sample(probs, uniforms):
+    """np.random.choice(A, 1, p=prob) per row given explicit float64 uniforms
+    (examples/IMPALA/atari_agent.py:38-40).  Returns int64 [B]."""
+    probs = _f32(probs, 'probs')
+    B, A = probs.shape
+    if uniforms.dtype != torch.float64:
+        raise N.ParlHipError('uniforms must be float64')
+    uniforms = uniforms.contiguous()
+    actions = torch.empty(B, dtype=torch.int64, device=probs.device)
+    N.check(
+        N.lib().parlhip_categorical_sample_f32(
+            N.ptr(probs), N.ptr(uniforms), N.ptr(actions), B, A, N.stream_ptr()),
+        'parlhip_categorical_sample_f32')
+    return actions
+
+
+def policy_sample(logits_or_probs, seed, offset, row0=0, is_logits=True, want_probs=False,
+                  want_uniforms=False):
+    """IMPALA.sample's softmax + per-row np.random.choice with on-device Philox uniforms.
+
+    u[b] = philox4x32-10(seed; offset, row0+b) -> 53-bit double.  Returns actions (and the
+    probabilities / uniforms when requested, for parity checks)."""
+    x = _f32(logits_or_probs, 'logits_or_probs')
+    B, A = x.shape
+    actions = torch.empty(B, dtype=torch.int64, device=x.device)
+    probs = torch.empty_like(x) if want_probs else None
+    uni = torch.empty(B, dtype=torch.float64, device=x.device) if want_uniforms else None
+    N.check(
+        N.lib().parlhip_policy_sample_f32(
+            N.ptr(x), 1 if is_logits else 0, N.ptr(actions), N.ptr(probs), N.ptr(uni), B, A,
+            int(seed) & (2**64 - 1), int(offset) & (2**64 - 1), int(row0) & (2**64 - 1),
+            N.stream_ptr()), 'parlhip_policy_sample_f32')
+    out = (actions, )
+    if want_probs:
+        out += (probs, )
+    if want_uniforms:
+        out += (uni, )
+    return out if len(out) > 1 else actions
+
+
+def consume_device_errors():
+    """Synchronise and return/clear the device-side data-error flag (bad action index)."""
+    return N.check(N.lib().parlhip_consume_device_errors(N.stream_ptr()),
+                   'parlhip_consume_device_errors')

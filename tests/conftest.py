@@ -1,0 +1,46 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    return {k: z[k] for k in z.files}
+
+
+def golden_cases(d):
+    """group 'case/key' entries of a golden npz into {case: {key: array}}"""
+    out = {}
+    for k, v in d.items():
+        if '/' in k:
+            c, kk = k.split('/', 1)
+            out.setdefault(c, {})[kk] = v
+    return out
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    """the plain-C CPU oracle (test infrastructure)"""
+    from oracle import c_oracle
+    c_oracle.lib()
+    return c_oracle
+
+
+@pytest.fixture(scope='session')
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return torch.device('cuda:0')

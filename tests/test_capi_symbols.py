@@ -1,0 +1,78 @@
+"""The C-ABI library must export every symbol include/parl_hip.h declares, and the ctypes
+binding table must cover exactly that set.  CPU-only: loads the .so, calls nothing that needs
+a GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    out = set()
+    inc = os.path.join(ROOT, 'include')
+    for fn in os.listdir(inc):
+        if fn.endswith('.h'):
+            src = open(os.path.join(inc, fn)).read()
+            src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+            out |= set(re.findall(r'\b(parlhip_\w+)\s*\(', src))
+    return out
+
+
+@pytest.fixture(scope='module')
+def built_lib():
+    from parl_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _native.LIB_PATH
+
+
+def test_header_symbols_exported(built_lib):
+    syms = declared_symbols()
+    assert len(syms) >= 10
+    nm = subprocess.check_output(['nm', '-D', '--defined-only', built_lib]).decode()
+    exported = set(re.findall(r' T (parlhip_\w+)', nm))
+    assert syms <= exported, 'declared but not exported: %s' % sorted(syms - exported)
+    assert exported <= syms, 'exported but not declared in include/: %s' % sorted(exported - syms)
+
+
+def test_ctypes_table_matches_header(built_lib):
+    from parl_amd import _native
+    assert set(_native.SIGNATURES) == declared_symbols()
+    lib = _native.lib()  # resolves every symbol, sets argtypes
+    assert lib.parlhip_version() >= 100
+    assert lib.parlhip_strerror(-1) == b'invalid argument'
+    assert lib.parlhip_adv_normalize_workspace_bytes(1 << 20) >= 16
+
+
+def test_argument_validation_without_gpu(built_lib):
+    """EINVAL paths return before touching the device"""
+    from parl_amd import _native
+    lib = _native.lib()
+    assert lib.parlhip_vtrace_f32(None, None, None, None, None, None, None, None, 5, 4, 1.0, 1.0, None) == -1
+    assert lib.parlhip_vtrace_f32(None, None, None, None, None, None, None, None, 0, 4, 1.0, 1.0, None) == 0
+    assert lib.parlhip_gae_f32(None, None, None, None, None, None, None, -1, 4, 0.99, 1.0, 0, 0, None) == -1
+    assert lib.parlhip_categorical_sample_f32(None, None, None, 4, 0, None) == -1
+
+
+def test_product_fails_loudly_on_cpu_tensors(built_lib):
+    import torch
+    from parl_amd import ops, _native
+    x = torch.zeros(4, 3)
+    with pytest.raises(_native.ParlHipError):
+        ops.vtrace(x, x, x, x, x, torch.zeros(3))
+
+
+def test_no_oracle_in_product():
+    """parl_amd/ must never import, load or link anything under oracle/"""
+    pkg = os.path.join(ROOT, 'parl_amd')
+    bad = re.compile(r'(import\s+oracle|from\s+oracle|c_oracle|libparl_oracle|oracle/_ref|emu_oracle)')
+    for d, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.hpp', '.cpp', '.h', 'Makefile')):
+                s = open(os.path.join(d, fn)).read()
+                assert not bad.search(s), '%s references the oracle' % os.path.join(d, fn)

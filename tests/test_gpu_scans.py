@@ -1,0 +1,263 @@
+"""Parity of the HIP scan / sampling kernels (through the C ABI) against the CPU oracle and
+the reference's golden vectors.  All tests need a real MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cases, load_golden
+
+pytestmark = pytest.mark.gpu
+
+# tolerance stated by BASELINE.json north_star: returns / V-trace targets to 1e-5 fp32
+RTOL = 1e-5
+ATOL = 1e-5
+
+
+def T_(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def nan_to_none(x):
+    x = float(x)
+    return None if np.isnan(x) else x
+
+
+def vtrace_inputs(rng, T, B):
+    blp = -np.abs(rng.standard_normal((T, B))).astype(np.float32)
+    tlp = -np.abs(rng.standard_normal((T, B))).astype(np.float32)
+    dones = rng.random((T, B)) < 1 / 50
+    disc = (~dones).astype(np.float32) * np.float32(0.99)
+    rew = rng.choice([-1.0, 0.0, 1.0], size=(T, B), p=[.01, .98, .01]).astype(np.float32)
+    val = rng.standard_normal((T, B)).astype(np.float32)
+    boot = rng.standard_normal(B).astype(np.float32)
+    return blp, tlp, disc, rew, val, boot
+
+
+@pytest.mark.parametrize('case', ['ref_B1', 'ref_B4', 'B7_T13', 'B3_T50', 'B2_T9_noclip'])
+def test_vtrace_golden(dev, case):
+    from parl_amd import ops
+    g = golden_cases(load_golden('vtrace_known_answer.npz'))[case]
+    vs, pg = ops.vtrace(T_(g['behaviour_actions_log_probs'], dev), T_(g['target_actions_log_probs'], dev),
+                        T_(g['discounts'], dev), T_(g['rewards'], dev), T_(g['values'], dev),
+                        T_(g['bootstrap_value'], dev), nan_to_none(g['clip_rho_threshold']),
+                        nan_to_none(g['clip_pg_rho_threshold']))
+    np.testing.assert_allclose(vs.cpu().numpy(), g['vs'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(pg.cpu().numpy(), g['pg_advantages'], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize('T,B', [(49, 1024), (49, 20), (1, 1), (5, 3), (127, 4099), (19, 131072 + 4), (7, 262144)])
+@pytest.mark.parametrize('clips', [(1.0, 1.0), (3.7, 2.2), (None, None)])
+def test_vtrace_vs_oracle(dev, oracle, T, B, clips):
+    from parl_amd import ops
+    rng = np.random.default_rng(T * 1000 + B)
+    inp = vtrace_inputs(rng, T, B)
+    vs, pg = ops.vtrace(*[T_(x, dev) for x in inp], clips[0], clips[1])
+    ovs, opg = oracle.vtrace(*inp, clips[0], clips[1])
+    np.testing.assert_allclose(vs.cpu().numpy(), ovs, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(pg.cpu().numpy(), opg, rtol=RTOL, atol=ATOL)
+
+
+def test_vtrace_empty(dev):
+    from parl_amd import ops
+    z = torch.zeros((0, 4), device=dev)
+    vs, pg = ops.vtrace(z, z, z, z, z, torch.zeros(4, device=dev))
+    assert vs.shape == (0, 4)
+
+
+def test_vtrace_full_size_properties(dev):
+    """saturating shape (T'=127, B=262,144): on-policy (rho=1), no clipping effect,
+    V-trace reduces to the n-step TD(1) return — checked against a float64 torch scan on device,
+    plus linearity in (rewards, values, bootstrap)."""
+    from parl_amd import ops
+    T, B = 127, 262144
+    g = torch.Generator(device=dev).manual_seed(0)
+    lp = -torch.rand((T, B), device=dev, generator=g)
+    disc = (torch.rand((T, B), device=dev, generator=g) > 1 / 800).float() * 0.99
+    rew = torch.randn((T, B), device=dev, generator=g)
+    val = torch.randn((T, B), device=dev, generator=g)
+    boot = torch.randn(B, device=dev, generator=g)
+    vs, pg = ops.vtrace(lp, lp, disc, rew, val, boot, 1.0, 1.0)
+    # reference: vs_t = r_t + disc_t * vs_{t+1}, vs_T = bootstrap (float64)
+    ref = torch.empty((T, B), device=dev, dtype=torch.float64)
+    nxt = boot.double()
+    for t in range(T - 1, -1, -1):
+        nxt = rew[t].double() + disc[t].double() * nxt
+        ref[t] = nxt
+    torch.testing.assert_close(vs.double(), ref, rtol=1e-5, atol=1e-4)
+    nvs = torch.cat([vs[1:], boot[None]], 0)
+    torch.testing.assert_close(pg, rew + disc * nvs - val, rtol=1e-5, atol=1e-5)
+    # linearity: doubling rewards, values, bootstrap doubles vs and pg
+    vs2, pg2 = ops.vtrace(lp, lp, disc, rew * 2, val * 2, boot * 2, 1.0, 1.0)
+    torch.testing.assert_close(vs2, vs * 2, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(pg2, pg * 2, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('time_major', [True, False])
+@pytest.mark.parametrize('T,B,A', [(50, 1024, 6), (50, 20, 6), (2, 1, 4), (20, 257, 4), (9, 70, 18), (65, 33, 6),
+                                   (66, 5, 3), (130, 7, 2), (300, 3, 7), (50, 16384, 6)])
+def test_vtrace_from_logits_vs_oracle(dev, oracle, time_major, T, B, A):
+    from parl_amd import ops
+    rng = np.random.default_rng(T + B + A)
+    shp = (T, B) if time_major else (B, T)
+    bl = rng.standard_normal(shp + (A, )).astype(np.float32)
+    tl = (bl + 0.3 * rng.standard_normal(shp + (A, ))).astype(np.float32)
+    act = rng.integers(0, A, shp).astype(np.int64)
+    rew = rng.choice([-1.0, 0.0, 1.0], size=shp, p=[.05, .9, .05]).astype(np.float32)
+    dones = rng.random(shp) < 0.03
+    val = rng.standard_normal(shp).astype(np.float32)
+    vs, pg, tlp, blp = ops.vtrace_from_logits(T_(bl, dev), T_(tl, dev), T_(act, dev), T_(rew, dev), T_(dones, dev),
+                                              T_(val, dev), 0.99, 1.0, 1.0, time_major=time_major,
+                                              want_log_probs=True)
+    ovs, opg, otlp, oblp = oracle.vtrace_from_logits(bl, tl, act, rew, dones, val, 0.99, 1.0, 1.0, time_major)
+    np.testing.assert_allclose(tlp.cpu().numpy(), otlp, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(blp.cpu().numpy(), oblp, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(vs.cpu().numpy(), ovs, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(pg.cpu().numpy(), opg, rtol=RTOL, atol=ATOL)
+    assert ops.consume_device_errors() == 0
+
+
+def test_vtrace_from_logits_bad_action_flag(dev):
+    from parl_amd import ops
+    T, B, A = 5, 4, 6
+    z = torch.zeros((T, B, A), device=dev)
+    act = torch.full((T, B), 9, dtype=torch.int64, device=dev)
+    s = torch.zeros((T, B), device=dev)
+    ops.vtrace_from_logits(z, z, act, s, s.bool(), s, 0.99)
+    assert ops.consume_device_errors() == 1
+    assert ops.consume_device_errors() == 0
+
+
+@pytest.mark.parametrize('case', ['a2c_T20_B6_lam1', 'a2c_T20_B6_lam95', 'a2c_T5_B3_lam1', 'a2c_T128_B4_lam9'])
+def test_gae_a2c_golden(dev, case):
+    """HIP float32 scan vs the reference calc_gae (float64 lfilter) per (env, segment)"""
+    from parl_amd import ops
+    g = golden_cases(load_golden('calc_gae.npz'))[case]
+    adv, ret = ops.gae(T_(g['rewards'], dev), T_(g['values'], dev), T_(g['dones'], dev), T_(g['next_value'], dev),
+                       0.99, float(g['lam']))
+    np.testing.assert_allclose(adv.cpu().numpy(), g['advantages'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(ret.cpu().numpy(), g['target_values'], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize('case', ['T16_E8', 'T64_E5', 'T7_E3_g9_l1'])
+def test_gae_ppo_golden_bit_exact(dev, case):
+    """RolloutStorage.compute_returns is float32 numpy: the kernel keeps its op order -> bit-exact"""
+    from parl_amd import ops
+    g = golden_cases(load_golden('ppo_compute_returns.npz'))[case]
+    gamma, lam = [float(x) for x in g['gamma_lam']]
+    adv, ret = ops.gae(T_(g['rewards'], dev), T_(g['values'], dev), T_(g['dones'], dev), T_(g['value'], dev), gamma,
+                       lam, last_done=T_(g['done'], dev), done_convention=ops.GAE_DONE_STARTS_STEP)
+    np.testing.assert_array_equal(adv.cpu().numpy(), g['advantages'])
+    np.testing.assert_array_equal(ret.cpu().numpy(), g['returns'])
+
+
+@pytest.mark.parametrize('T,B', [(20, 256), (20, 5), (1, 1), (128, 1031), (33, 131072), (2048, 4096)])
+@pytest.mark.parametrize('conv,f32', [(0, False), (1, True), (1, False), (0, True)])
+def test_gae_vs_oracle(dev, oracle, T, B, conv, f32):
+    from parl_amd import ops
+    rng = np.random.default_rng(T * 7 + B)
+    rew = np.clip(rng.standard_normal((T, B)), -10, 10).astype(np.float32)
+    val = rng.standard_normal((T, B)).astype(np.float32)
+    dones = (rng.random((T, B)) < 0.02)
+    last = (rng.random(B) < 0.3)
+    dt = np.float32 if f32 else np.uint8
+    dones, last = dones.astype(dt), last.astype(dt)
+    nv = rng.standard_normal(B).astype(np.float32)
+    adv, ret = ops.gae(T_(rew, dev), T_(val, dev), T_(dones, dev), T_(nv, dev), 0.99, 0.95,
+                       last_done=T_(last, dev) if conv else None, done_convention=conv)
+    oadv, oret = oracle.gae(rew, val, dones, nv, 0.99, 0.95, last_done=last if conv else None, done_convention=conv)
+    if conv == 1:  # same float32 op order on both sides
+        np.testing.assert_array_equal(adv.cpu().numpy(), oadv)
+        np.testing.assert_array_equal(ret.cpu().numpy(), oret)
+    else:
+        np.testing.assert_allclose(adv.cpu().numpy(), oadv, rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(ret.cpu().numpy(), oret, rtol=RTOL, atol=ATOL)
+
+
+def test_gae_fp32_vs_reference_f64_T2048(dev, oracle):
+    """SURVEY hard part: fp32 scan vs the reference's float64 lfilter at gamma=.99, lam=1, T=2048"""
+    from parl_amd import ops
+    rng = np.random.default_rng(5)
+    T, B = 2048, 64
+    rew = rng.choice([-1.0, 0.0, 1.0], size=(T, B), p=[.01, .98, .01]).astype(np.float32)
+    val = rng.standard_normal((T, B)).astype(np.float32)
+    dones = np.zeros((T, B), np.uint8)
+    nv = rng.standard_normal(B).astype(np.float32)
+    adv, _ = ops.gae(T_(rew, dev), T_(val, dev), T_(dones, dev), T_(nv, dev), 0.99, 1.0)
+    oadv, _ = oracle.gae(rew, val, dones, nv, 0.99, 1.0, accum_f64=True)
+    np.testing.assert_allclose(adv.cpu().numpy(), oadv, rtol=1e-5, atol=2e-5)
+
+
+def test_discount_cumsum(dev, oracle):
+    from parl_amd import ops
+    g = golden_cases(load_golden('calc_gae.npz'))['dsum']
+    out = ops.discount_cumsum(T_(g['x'], dev), 0.97)
+    np.testing.assert_allclose(out.cpu().numpy(), g['out'], rtol=RTOL, atol=ATOL)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((40, 70000)).astype(np.float32)
+    d = rng.random((40, 70000)) < 0.05
+    out = ops.discount_cumsum(T_(x, dev), 0.9, T_(d, dev))
+    np.testing.assert_allclose(out.cpu().numpy(), oracle.discount_cumsum(x, 0.9, d), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize('n', [1000, 262144, 4096 * 2048 // 32, 3])
+def test_adv_normalize(dev, oracle, n):
+    from parl_amd import ops
+    rng = np.random.default_rng(n)
+    adv = (rng.standard_normal(n * 2) * 2 + 0.7).astype(np.float32)
+    out, st = ops.adv_normalize(T_(adv, dev), return_stats=True)
+    oout, oms = oracle.adv_normalize(adv)
+    np.testing.assert_allclose(st.cpu().numpy(), oms, rtol=1e-6)
+    np.testing.assert_allclose(out.cpu().numpy(), oout, rtol=RTOL, atol=ATOL)
+    idx = rng.permutation(n * 2)[:n].astype(np.int64)
+    out = ops.adv_normalize(T_(adv, dev), T_(idx, dev))
+    oout, _ = oracle.adv_normalize(adv, idx)
+    np.testing.assert_allclose(out.cpu().numpy(), oout, rtol=RTOL, atol=ATOL)
+    # property at any size: zero mean, unit (unbiased) std
+    if n > 100:
+        assert abs(float(out.mean())) < 1e-4 and abs(float(out.std()) - 1) < 1e-4
+
+
+@pytest.mark.parametrize('A', [2, 4, 6, 18, 40])
+def test_categorical_sample_bit_exact(dev, oracle, A):
+    from parl_amd import ops
+    rng = np.random.default_rng(A)
+    B = 5000
+    logits = rng.standard_normal((B, A)).astype(np.float32) * 2
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    probs = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    u = rng.random(B)
+    u[:4] = [0.0, np.nextafter(1.0, 0.0), 0.5, 0.25]
+    got = ops.categorical_sample(T_(probs, dev), T_(u, dev)).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.categorical_sample(probs, u))
+    # and against numpy's own choice on the same uniform stream
+    np.random.seed(11)
+    ref = np.array([np.random.choice(A, 1, p=p)[0] for p in probs[:300]])
+    np.random.seed(11)
+    uu = np.array([np.random.random_sample() for _ in range(300)])
+    got = ops.categorical_sample(T_(probs[:300], dev), T_(uu, dev)).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize('A', [4, 6, 18])
+def test_policy_sample(dev, oracle, A):
+    from parl_amd import ops
+    rng = np.random.default_rng(A + 100)
+    B = 4096
+    logits = (rng.standard_normal((B, A)) * 3).astype(np.float32)
+    seed, offset, row0 = 0x1234567890abcdef, 77, 1 << 33
+    act, probs, uni = ops.policy_sample(T_(logits, dev), seed, offset, row0, want_probs=True, want_uniforms=True)
+    oact, oprobs, ouni = oracle.policy_sample(logits, seed, offset, row0)
+    # uniforms: integer Philox -> bit-exact
+    np.testing.assert_array_equal(uni.cpu().numpy(), ouni)
+    # probabilities: float32 softmax, expf may differ in the last ulp between libm and ocml
+    np.testing.assert_allclose(probs.cpu().numpy(), oprobs, rtol=2e-6, atol=1e-9)
+    # action indices: bit-exact given the probabilities the device itself used
+    np.testing.assert_array_equal(act.cpu().numpy(), oracle.categorical_sample(probs.cpu().numpy(), ouni))
+    # sharding invariance: rows [k:] sampled alone with row0+k give the same actions
+    act2 = ops.policy_sample(T_(logits[1000:], dev), seed, offset, row0 + 1000)
+    np.testing.assert_array_equal(act2.cpu().numpy(), act.cpu().numpy()[1000:])
+    # distribution sanity (chi-square-ish): empirical frequencies of a fixed row
+    row = np.tile(logits[:1], (200000, 1))
+    a = ops.policy_sample(T_(row, dev), 5, 0, 0).cpu().numpy()
+    freq = np.bincount(a, minlength=A) / len(a)
+    np.testing.assert_allclose(freq, oprobs[0], atol=5e-3)

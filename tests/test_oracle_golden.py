@@ -1,0 +1,127 @@
+"""Pin the CPU oracle (oracle/scan_oracle.c) against the reference's own golden vectors
+(tests/golden/*.npz, generated from /root/reference by tests/golden/make_golden.py) and against
+numpy's np.random.choice.  CPU-only."""
+import numpy as np
+import pytest
+
+from conftest import golden_cases, load_golden
+
+
+def nan_to_none(x):
+    x = float(x)
+    return None if np.isnan(x) else x
+
+
+@pytest.mark.parametrize('case', ['ref_B1', 'ref_B4', 'B7_T13', 'B3_T50', 'B2_T9_noclip'])
+def test_vtrace_known_answer(oracle, case):
+    g = golden_cases(load_golden('vtrace_known_answer.npz'))[case]
+    vs, pg = oracle.vtrace(g['behaviour_actions_log_probs'], g['target_actions_log_probs'], g['discounts'],
+                           g['rewards'], g['values'], g['bootstrap_value'],
+                           nan_to_none(g['clip_rho_threshold']), nan_to_none(g['clip_pg_rho_threshold']))
+    # the reference's own tolerance is 5 decimals (vtrace_test_paddle.py:142-144); values reach
+    # ~1e2 here, so also demand 1e-5 relative
+    np.testing.assert_allclose(vs, g['vs'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(pg, g['pg_advantages'], rtol=1e-5, atol=1e-5)
+
+
+def test_vtrace_survey_values(oracle):
+    """the numbers recorded in SURVEY.md §8c for the reference recipe"""
+    g = golden_cases(load_golden('vtrace_known_answer.npz'))
+    b1, b4 = g['ref_B1'], g['ref_B4']
+    np.testing.assert_allclose(b1['vs'][:, 0], [0.2001819, 2.7096822, 8.513628, 11.932398, 7.3300004], rtol=1e-6)
+    np.testing.assert_allclose(b4['pg_advantages'][:, 3], [0.6683227, 5.3430295, 27.742376, 54.848476, 33.329998],
+                               rtol=1e-6)
+
+
+def test_calc_gae_samples(oracle):
+    g = load_golden('calc_gae.npz')
+    r = np.array([[1], [0], [-1], [1]], np.float32)
+    v = np.array([[.5], [.25], [-.5], [.75]], np.float32)
+    d = np.zeros((4, 1), np.uint8)
+    adv, _ = oracle.gae(r, v, d, np.array([0.3], np.float32), 0.99, 1.0, accum_f64=True)
+    np.testing.assert_allclose(adv[:, 0], g['sample1'], rtol=1e-6)
+    d[3] = 1  # next_value = 0 <=> terminal last step
+    adv, _ = oracle.gae(r, v, d, np.array([123.0], np.float32), 0.99, 0.95, accum_f64=True)
+    np.testing.assert_allclose(adv[:, 0], g['sample2'], rtol=1e-6)
+
+
+@pytest.mark.parametrize('case', ['a2c_T20_B6_lam1', 'a2c_T20_B6_lam95', 'a2c_T5_B3_lam1', 'a2c_T128_B4_lam9'])
+@pytest.mark.parametrize('f64', [True, False])
+def test_calc_gae_a2c_segments(oracle, case, f64):
+    g = golden_cases(load_golden('calc_gae.npz'))[case]
+    adv, ret = oracle.gae(g['rewards'], g['values'], g['dones'], g['next_value'], 0.99, float(g['lam']),
+                          accum_f64=f64)
+    tol = 2e-6 if f64 else 1e-5
+    np.testing.assert_allclose(adv, g['advantages'], rtol=tol, atol=tol)
+    np.testing.assert_allclose(ret, g['target_values'], rtol=tol, atol=tol)
+
+
+def test_discount_sum(oracle):
+    g = golden_cases(load_golden('calc_gae.npz'))['dsum']
+    out = oracle.discount_cumsum(g['x'], 0.97, accum_f64=True)
+    np.testing.assert_allclose(out, g['out'], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('case', ['T16_E8', 'T64_E5', 'T7_E3_g9_l1'])
+def test_ppo_compute_returns_bit_exact(oracle, case):
+    """examples/PPO/storage.py:45-64 is float32 numpy; the oracle keeps its op order -> bit-exact"""
+    g = golden_cases(load_golden('ppo_compute_returns.npz'))[case]
+    gamma, lam = [float(x) for x in g['gamma_lam']]
+    adv, ret = oracle.gae(g['rewards'], g['values'], g['dones'], g['value'], gamma, lam, last_done=g['done'],
+                          done_convention=1)
+    assert adv.dtype == np.float32 and g['advantages'].dtype == np.float32
+    np.testing.assert_array_equal(adv, g['advantages'])
+    np.testing.assert_array_equal(ret, g['returns'])
+
+
+def test_categorical_matches_np_random_choice(oracle):
+    """np.random.choice(len(prob), 1, p=prob) (examples/IMPALA/atari_agent.py:38-40) consumes one
+    random_sample() per call; feeding the oracle the same uniforms must give the same indices."""
+    rng = np.random.default_rng(7)
+    for A in (2, 4, 6, 18):
+        logits = rng.standard_normal((500, A)).astype(np.float32) * 2
+        e = np.exp(logits - logits.max(1, keepdims=True))
+        probs = (e / e.sum(1, keepdims=True)).astype(np.float32)
+        np.random.seed(123)
+        ref = np.array([np.random.choice(len(p), 1, p=p)[0] for p in probs])
+        np.random.seed(123)
+        u = np.array([np.random.random_sample() for _ in range(len(probs))])
+        got = oracle.categorical_sample(probs, u)
+        np.testing.assert_array_equal(got, ref)
+
+
+def test_categorical_edge_uniforms(oracle):
+    probs = np.array([[0.25, 0.25, 0.5], [0.0, 1.0, 0.0], [1.0, 0.0, 0.0]], np.float32)
+    for u in (0.0, 0.25, 0.4999999, 0.5, np.nextafter(1.0, 0.0)):
+        got = oracle.categorical_sample(probs, np.full(3, u))
+        cdf = np.cumsum(probs.astype(np.float64), 1)
+        cdf /= cdf[:, -1:]
+        ref = np.array([np.searchsorted(c, u, side='right') for c in cdf])
+        np.testing.assert_array_equal(got, ref)
+
+
+def test_philox_known_answer(oracle):
+    """Philox4x32-10 known-answer vectors from the Random123 distribution (kat_vectors):
+    counter=0,key=0 -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8; all-ones -> 408f276d 41c83b0e a20bc7c6 6d5451fd"""
+    import ctypes
+    out = (ctypes.c_uint32 * 4)()
+    oracle.lib().oracle_philox4x32_10(ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0), out)
+    assert [hex(x) for x in out] == ['0x6627e8d5', '0xe169c58d', '0xbc57ac4c', '0x9b00dbd8']
+    m = 2**64 - 1
+    oracle.lib().oracle_philox4x32_10(ctypes.c_uint64(m), ctypes.c_uint64(m), ctypes.c_uint64(m), out)
+    assert [hex(x) for x in out] == ['0x408f276d', '0x41c83b0e', '0xa20bc7c6', '0x6d5451fd']
+
+
+def test_adv_normalize_matches_torch(oracle):
+    import torch
+    rng = np.random.default_rng(3)
+    adv = (rng.standard_normal(4097) * 3 + 1.5).astype(np.float32)
+    t = torch.from_numpy(adv)
+    ref = ((t - t.mean()) / (t.std() + 1e-8)).numpy()  # torch ppo.py:115-117
+    out, ms = oracle.adv_normalize(adv)
+    np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-6)
+    idx = rng.permutation(4097)[:1000]
+    ti = t[torch.from_numpy(idx)]
+    ref = ((ti - ti.mean()) / (ti.std() + 1e-8)).numpy()
+    out, _ = oracle.adv_normalize(adv, idx)
+    np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-6)
