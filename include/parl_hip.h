@@ -152,6 +152,75 @@ int parlhip_policy_sample_f32(const float* logits_or_probs, int is_logits,
                               double* uniforms_out, int B, int A, uint64_t seed,
                               uint64_t offset, uint64_t row0, parlhip_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Frame pipeline: MaxAndSkipEnv max + WarpFrame
+ * parl/env/atari_wrappers.py:239 (obs_buffer.max(axis=0)), :263-267 (cv2 RGB2GRAY +
+ * cv2.resize INTER_AREA), restated from OpenCV's published algorithm (oracle/frame_oracle.c).
+ * ------------------------------------------------------------------------------------ */
+/* Resampling tables + NTSC palette: built on the HOST into a caller buffer of
+ * parlhip_frame_post_tables_bytes(dim) bytes, then copied to the device by the caller. */
+size_t parlhip_frame_post_tables_bytes(int dim);
+int parlhip_frame_post_tables_init(void* host_blob, int dim);
+/* frames0/frames1: E frames, in_stride bytes apart.  fmt 0: RGB u8 [210,160,3] (the WarpFrame
+ * boundary); fmt 1: TIA colour bytes [210,160] as the device emulator emits them (16-byte
+ * aligned).  frames1 NULL = no max.  flags (optional, [E]): bit0 set = ignore frames1 for that
+ * env.  out: E frames of dim*dim bytes, out_stride bytes apart (e.g. a rollout-ring slot).   */
+int parlhip_frame_post_u8(const uint8_t* frames0, const uint8_t* frames1, int64_t in_stride,
+                          int fmt, const uint8_t* flags, uint8_t* out, int64_t out_stride,
+                          int E, int dim, const void* tables_dev, parlhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Vectorised Atari env: VectorEnv([wrap_deepmind(gym.make(id), dim, obs_format='NCHW')]*E)
+ * parl/env/vector_env.py:34-63 + parl/env/atari_wrappers.py:356-385 + the ALE emulator
+ * behind gym.make (third party; restated, see oracle/atari_oracle.h).  One env per wavefront.
+ * ------------------------------------------------------------------------------------ */
+#define PARLHIP_GAME_PONG 1
+#define PARLHIP_GAME_BREAKOUT 2
+size_t parlhip_atari_state_bytes(void);       /* per-env state blob (device), E of them      */
+size_t parlhip_atari_frame_bytes(void);       /* per-env raw frame pair (device): 2*210*160  */
+size_t parlhip_atari_rom_table_bytes(uint32_t rom_size);
+size_t parlhip_atari_reset_cache_bytes(void); /* 30 reset snapshots (device)                 */
+int parlhip_atari_num_actions(int game);      /* ALE minimal action set size                 */
+/* HOST: pre-decode an unbanked 2K/4K cartridge into one 32-bit word per address.             */
+int parlhip_atari_rom_table_build(const uint8_t* rom_host, uint32_t rom_size,
+                                  uint32_t* table_host);
+/* Build the 30 real-reset snapshots (noop count 1..30) on the device.  jam_flag_dev: int32
+ * word OR-ed with emulator fault bits (undocumented opcode etc.); 0 = clean.                 */
+int parlhip_atari_reset_cache_build(const uint32_t* rom_table_dev, uint32_t rom_size, int game,
+                                    int64_t max_episode_steps, void* cache_dev,
+                                    int32_t* jam_flag_dev, parlhip_stream_t stream);
+/* VectorEnv.reset: initialises states; leaves each env's reset frames in `frames` and
+ * obs_flags[e] = 2 | single (bit1: the frame stack must be refilled, FrameStack.reset).      */
+int parlhip_atari_vec_reset(void* states, const uint32_t* rom_table_dev, uint32_t rom_size,
+                            int game, uint8_t* frames, uint8_t* obs_flags, int E, uint64_t seed,
+                            uint64_t env_id0, int64_t max_episode_steps, int32_t* jam_flag_dev,
+                            parlhip_stream_t stream);
+/* VectorEnv.step with auto-reset.  actions int64 [E] index the minimal action set.  Outputs:
+ * rewards f32 [E] (ClipRewardEnv sign), dones u8 [E], obs_flags u8 [E], the episode that
+ * MonitorEnv closed this step if any (ep_lengths[e] > 0; lengths in emulated frames, returns
+ * unclipped), and the raw frame pair of the returned observation in `frames` (feed to
+ * parlhip_frame_post_u8 with fmt 1 and flags = obs_flags).  reset_cache_dev may be NULL
+ * (general reset path only).  env ids env_id0+e select the per-env noop RNG stream.          */
+int parlhip_atari_vec_step(void* states, const uint32_t* rom_table_dev, uint32_t rom_size,
+                           int game, const int64_t* actions, uint8_t* frames, float* rewards,
+                           uint8_t* dones, uint8_t* obs_flags, float* ep_returns,
+                           int32_t* ep_lengths, int E, uint64_t seed, uint64_t env_id0,
+                           int64_t max_episode_steps, const void* reset_cache_dev,
+                           int32_t* jam_flag_dev, parlhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * FrameStack (atari_wrappers.py:270-306) over a rollout ring of SINGLE frames
+ * ------------------------------------------------------------------------------------ */
+/* since_next[e] = (obs_flags[e] & 2) ? 0 : min(since_prev[e] + 1, 3); since_prev NULL = 0.   */
+int parlhip_stack_since_update_u8(const uint8_t* obs_flags, const uint8_t* since_prev,
+                                  uint8_t* since_next, int E, parlhip_stream_t stream);
+/* ring u8 [S,E,frame_bytes], since u8 [S,E]; for sample i: slot = slots[i], env = envs[i];
+ * out[i][j] = ring[slot - min(3-j, since[slot][env])][env], j = 0 (oldest) .. 3 (newest).
+ * out u8 [n,4,frame_bytes] — the NCHW stack FrameStack._get_ob returns.                      */
+int parlhip_stack_gather_u8(const uint8_t* ring, const uint8_t* since, int E, int frame_bytes,
+                            const int32_t* slots, const int32_t* envs, int64_t n, uint8_t* out,
+                            parlhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

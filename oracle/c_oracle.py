@@ -145,3 +145,82 @@ def policy_sample(x, seed, offset, row0=0, is_logits=True):
                                         ctypes.c_uint64(seed), ctypes.c_uint64(offset), ctypes.c_uint64(row0))
     assert rc == 0
     return actions, probs, uni
+
+
+# ---------------------------------------------------------------------------------------
+# Atari: emulator + wrapper chain + VectorEnv (atari_oracle.c, atari_env_oracle.c)
+# ---------------------------------------------------------------------------------------
+GAME_IDS = {'pong': 1, 'breakout': 2}
+
+
+def frame_tables(dim):
+    L = lib()
+    L.oracle_frame_tables_bytes.restype = ctypes.c_size_t
+    n = L.oracle_frame_tables_bytes(int(dim))
+    blob = np.zeros(n, np.uint8)
+    L.oracle_frame_tables_init(_p(blob), int(dim))
+    return blob
+
+
+def frame_post(frames0, frames1, dim, fmt):
+    """max (optional) + RGB2GRAY + INTER_AREA resize; frames [E,210,160(,3)] u8 -> [E,dim,dim]"""
+    f0 = _c(frames0, np.uint8)
+    f1 = None if frames1 is None else _c(frames1, np.uint8)
+    E = f0.shape[0]
+    out = np.zeros((E, dim, dim), np.uint8)
+    blob = frame_tables(dim)
+    rc = lib().oracle_frame_post_u8(_p(f0), _p(f1), int(fmt), _p(out), ctypes.c_int64(dim * dim), E, int(dim),
+                                    _p(blob))
+    assert rc == 0
+    return out
+
+
+class VecEnv:
+    """VectorEnv([wrap_deepmind(gym.make(...), dim, obs_format='NCHW')] * E) restated on CPU."""
+
+    def __init__(self, rom_bytes, game, E, dim=84, seed=0, env_id0=0, max_episode_steps=400000):
+        L = lib()
+        L.oracle_vec_new.restype = ctypes.c_void_p
+        self.L, self.E, self.dim = L, E, dim
+        self.h = ctypes.c_void_p(
+            L.oracle_vec_new(rom_bytes, len(rom_bytes), GAME_IDS[game], E, dim, ctypes.c_uint64(seed),
+                             ctypes.c_uint64(env_id0), ctypes.c_int64(max_episode_steps)))
+        self.num_actions = L.oracle_vec_num_actions(self.h)
+
+    def reset(self):
+        obs = np.zeros((self.E, 4, self.dim, self.dim), np.uint8)
+        self.L.oracle_vec_reset(self.h, _p(obs))
+        return obs
+
+    def step(self, actions):
+        actions = _c(actions, np.int64)
+        obs = np.zeros((self.E, 4, self.dim, self.dim), np.uint8)
+        rew = np.zeros(self.E, np.float32)
+        done = np.zeros(self.E, np.uint8)
+        self.L.oracle_vec_step(self.h, _p(actions), _p(obs), _p(rew), _p(done))
+        return obs, rew, done
+
+    def pop_episodes(self, env):
+        r = np.zeros(64, np.float64)
+        n_ = np.zeros(64, np.int64)
+        n = self.L.oracle_vec_pop_episodes(self.h, env, _p(r), _p(n_), 64)
+        return list(zip(r[:n].tolist(), n_[:n].tolist()))
+
+    def ram(self, env):
+        out = np.zeros(128, np.uint8)
+        self.L.oracle_vec_ram(self.h, env, _p(out))
+        return out
+
+    def raw_frames(self, env):
+        out = np.zeros((2, 210, 160), np.uint8)
+        self.L.oracle_vec_raw_frames(self.h, env, _p(out))
+        return out
+
+    def lives(self, env):
+        return self.L.oracle_vec_lives(self.h, env)
+
+    def __del__(self):
+        try:
+            self.L.oracle_vec_free(self.h)
+        except Exception:
+            pass

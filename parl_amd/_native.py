@@ -42,6 +42,22 @@ SIGNATURES = {
     'parlhip_categorical_sample_f32': (_i, [_p, _p, _p, _i, _i, _p]),
     'parlhip_policy_sample_f32':
     (_i, [_p, _i, _p, _p, _p, _i, _i, _u64, _u64, _u64, _p]),
+    'parlhip_frame_post_tables_bytes': (_sz, [_i]),
+    'parlhip_frame_post_tables_init': (_i, [_p, _i]),
+    'parlhip_frame_post_u8': (_i, [_p, _p, _i64, _i, _p, _p, _i64, _i, _i, _p, _p]),
+    'parlhip_atari_state_bytes': (_sz, []),
+    'parlhip_atari_frame_bytes': (_sz, []),
+    'parlhip_atari_rom_table_bytes': (_sz, [ctypes.c_uint32]),
+    'parlhip_atari_reset_cache_bytes': (_sz, []),
+    'parlhip_atari_num_actions': (_i, [_i]),
+    'parlhip_atari_rom_table_build': (_i, [_p, ctypes.c_uint32, _p]),
+    'parlhip_atari_reset_cache_build': (_i, [_p, ctypes.c_uint32, _i, _i64, _p, _p, _p]),
+    'parlhip_atari_vec_reset':
+    (_i, [_p, _p, ctypes.c_uint32, _i, _p, _p, _i, _u64, _u64, _i64, _p, _p]),
+    'parlhip_atari_vec_step':
+    (_i, [_p, _p, ctypes.c_uint32, _i, _p, _p, _p, _p, _p, _p, _p, _i, _u64, _u64, _i64, _p, _p, _p]),
+    'parlhip_stack_since_update_u8': (_i, [_p, _p, _p, _i, _p]),
+    'parlhip_stack_gather_u8': (_i, [_p, _p, _i, _i, _p, _p, _i64, _p, _p]),
 }
 
 

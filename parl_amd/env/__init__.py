@@ -1,0 +1,2 @@
+"""parl_amd.env — on-device counterparts of parl.env (vector_env.py, atari_wrappers.py)."""
+from .device_vector_env import DeviceVectorEnv, find_rom, GAMES  # noqa: F401

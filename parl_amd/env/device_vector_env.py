@@ -1,0 +1,202 @@
+"""DeviceVectorEnv — VectorEnv([wrap_deepmind(gym.make(id), dim, obs_format='NCHW')] * E) with
+every env resident on one MI355X (one env per wavefront).
+
+Mirrors the contract of parl/env/vector_env.py:26-63 (``reset() -> obs batch``,
+``step(actions) -> (obs, rewards, dones, infos)`` with auto-reset: the obs returned for a done
+env is its reset obs while reward/done describe the terminal transition) and of
+parl/env/atari_wrappers.py:356-385 (wrapper order).  Differences are the container types:
+tensors on the GPU instead of Python lists of numpy arrays; `VectorEnvAdapter` below gives the
+list-of-numpy view the reference's actor.py expects.
+
+All compute goes through the C ABI (include/parl_hip.h); there is no CPU fallback.
+"""
+import ctypes
+import hashlib
+import os
+
+import numpy as np
+import torch
+
+from .. import _native as N
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(os.path.dirname(_HERE))
+
+# gym id -> (rom name, C-ABI game id, md5 of the cartridge ALE ships for that id)
+GAMES = {
+    'PongNoFrameskip-v4': ('pong', 1, '60e0ea3cbe0913d39803477945e9e5ec'),
+    'BreakoutNoFrameskip-v4': ('breakout', 2, 'f34f08e5eb96e500e851a80be3277a56'),
+}
+
+
+def find_rom(name, rom_dir=None):
+    """Cartridge bytes for `name` ('pong', 'breakout').  ROMs are user-supplied data (as with
+    ALE): looked up in rom_dir, $PARL_AMD_ROM_DIR, <repo>/roms."""
+    dirs = [rom_dir, os.environ.get('PARL_AMD_ROM_DIR'), os.path.join(_REPO, 'roms')]
+    for d in dirs:
+        if d and os.path.exists(os.path.join(d, name + '.bin')):
+            return open(os.path.join(d, name + '.bin'), 'rb').read()
+    raise FileNotFoundError(
+        'cartridge %s.bin not found (looked in %s). Put the ROM there or set PARL_AMD_ROM_DIR.' %
+        (name, [d for d in dirs if d]))
+
+
+class DeviceVectorEnv(object):
+    def __init__(self, env_name, num_envs, dim=84, horizon=1, seed=0, env_id0=0, device=None,
+                 rom_dir=None, max_episode_steps=400000, use_reset_cache=True, rom_bytes=None):
+        if env_name not in GAMES:
+            raise ValueError('unsupported env %r (have %s)' % (env_name, sorted(GAMES)))
+        name, self.game, md5 = GAMES[env_name]
+        rom = rom_bytes if rom_bytes is not None else find_rom(name, rom_dir)
+        if hashlib.md5(rom).hexdigest() != md5:
+            raise ValueError('%s.bin md5 mismatch: not the cartridge ALE uses for %s' % (name, env_name))
+        self.env_name, self.envs_num, self.dim = env_name, int(num_envs), int(dim)
+        self.horizon = int(horizon)
+        self.seed, self.env_id0 = int(seed), int(env_id0)
+        self.max_episode_steps = int(max_episode_steps)
+        self.device = torch.device(device if device is not None else 'cuda')
+        L = N.lib()
+        self.act_dim = L.parlhip_atari_num_actions(self.game)
+        self.obs_shape = (4, self.dim, self.dim)
+        E, dev = self.envs_num, self.device
+        u8 = dict(dtype=torch.uint8, device=dev)
+        # --- cartridge: pre-decoded on the host, resident on the device
+        self.rom_size = len(rom)
+        table = np.zeros(self.rom_size, np.uint32)
+        rom_np = np.frombuffer(rom, np.uint8)
+        N.check(L.parlhip_atari_rom_table_build(rom_np.ctypes.data, self.rom_size, table.ctypes.data),
+                'parlhip_atari_rom_table_build')
+        self.rom_table = torch.from_numpy(table.view(np.int32)).to(dev)
+        # --- per-env state, raw frame pairs, per-step outputs
+        self.states = torch.zeros(E * L.parlhip_atari_state_bytes(), **u8)
+        self.raw_frames = torch.zeros((E, 2, 210, 160), **u8)
+        self.rewards = torch.zeros(E, dtype=torch.float32, device=dev)
+        self.dones = torch.zeros(E, **u8)
+        self.obs_flags = torch.zeros(E, **u8)
+        self.ep_returns = torch.zeros(E, dtype=torch.float32, device=dev)
+        self.ep_lengths = torch.zeros(E, dtype=torch.int32, device=dev)
+        self.jam = torch.zeros(1, dtype=torch.int32, device=dev)
+        # --- frame_post tables
+        nb = L.parlhip_frame_post_tables_bytes(self.dim)
+        blob = np.zeros(nb, np.uint8)
+        N.check(L.parlhip_frame_post_tables_init(blob.ctypes.data, self.dim), 'frame_post_tables_init')
+        self.fp_tables = torch.from_numpy(blob).to(dev)
+        # --- rollout ring of SINGLE frames: slot t+3 holds the newest frame of obs time t
+        self.fsz = self.dim * self.dim
+        self.slots = self.horizon + 4
+        self.ring = torch.zeros((self.slots, E, self.fsz), **u8)
+        self.since = torch.zeros((self.slots, E), **u8)
+        self.t = 0
+        self._env_idx = torch.arange(E, dtype=torch.int32, device=dev)
+        # --- O(1) real resets
+        self.reset_cache = None
+        if use_reset_cache:
+            self.reset_cache = torch.zeros(L.parlhip_atari_reset_cache_bytes(), **u8)
+            N.check(
+                L.parlhip_atari_reset_cache_build(
+                    N.ptr(self.rom_table), self.rom_size, self.game, self.max_episode_steps,
+                    N.ptr(self.reset_cache), N.ptr(self.jam), N.stream_ptr()), 'reset_cache_build')
+
+    # ---------------------------------------------------------------- internals
+    def _frame_post(self, slot):
+        L = N.lib()
+        out = self.ring[slot]
+        N.check(
+            L.parlhip_frame_post_u8(
+                N.ptr(self.raw_frames), self.raw_frames.data_ptr() + 210 * 160, 2 * 210 * 160, 1,
+                N.ptr(self.obs_flags), N.ptr(out), self.fsz, self.envs_num, self.dim,
+                N.ptr(self.fp_tables), N.stream_ptr()), 'parlhip_frame_post_u8')
+        prev = self.since[slot - 1] if slot > 0 else None
+        N.check(
+            L.parlhip_stack_since_update_u8(
+                N.ptr(self.obs_flags), N.ptr(prev) if prev is not None else None,
+                N.ptr(self.since[slot]), self.envs_num, N.stream_ptr()), 'stack_since_update')
+
+    def gather(self, slots, envs, out=None):
+        """Stacked obs u8 [n,4,dim,dim] for (ring slot, env) pairs (int32 tensors)."""
+        n = slots.numel()
+        if out is None:
+            out = torch.empty((n, 4, self.dim, self.dim), dtype=torch.uint8, device=self.device)
+        N.check(
+            N.lib().parlhip_stack_gather_u8(
+                N.ptr(self.ring), N.ptr(self.since), self.envs_num, self.fsz, N.ptr(slots.contiguous()),
+                N.ptr(envs.contiguous()), n, N.ptr(out), N.stream_ptr()), 'parlhip_stack_gather_u8')
+        return out
+
+    def current_obs(self, out=None):
+        slots = torch.full((self.envs_num, ), self.t + 3, dtype=torch.int32, device=self.device)
+        return self.gather(slots, self._env_idx, out)
+
+    # ---------------------------------------------------------------- VectorEnv contract
+    def reset(self):
+        """VectorEnv.reset (vector_env.py:34-39) -> obs u8 [E,4,dim,dim] on the device."""
+        L = N.lib()
+        N.check(
+            L.parlhip_atari_vec_reset(
+                N.ptr(self.states), N.ptr(self.rom_table), self.rom_size, self.game, N.ptr(self.raw_frames),
+                N.ptr(self.obs_flags), self.envs_num, self.seed, self.env_id0, self.max_episode_steps,
+                N.ptr(self.jam), N.stream_ptr()), 'parlhip_atari_vec_reset')
+        self.t = 0
+        self._frame_post(3)
+        return self.current_obs()
+
+    def step_async(self, actions):
+        """Enqueue one VectorEnv.step; results land in self.rewards/dones/... and ring slot t+4."""
+        if actions.dtype != torch.int64:
+            raise N.ParlHipError('actions must be int64')
+        if self.t >= self.horizon:
+            raise N.ParlHipError('rollout ring full: call roll() every `horizon` steps')
+        L = N.lib()
+        N.check(
+            L.parlhip_atari_vec_step(
+                N.ptr(self.states), N.ptr(self.rom_table), self.rom_size, self.game, N.ptr(actions.contiguous()),
+                N.ptr(self.raw_frames), N.ptr(self.rewards), N.ptr(self.dones), N.ptr(self.obs_flags),
+                N.ptr(self.ep_returns), N.ptr(self.ep_lengths), self.envs_num, self.seed, self.env_id0,
+                self.max_episode_steps, N.ptr(self.reset_cache), N.ptr(self.jam), N.stream_ptr()),
+            'parlhip_atari_vec_step')
+        self.t += 1
+        self._frame_post(self.t + 3)
+
+    def roll(self):
+        """Start the next rollout: the last 4 frame slots become the history of obs time 0."""
+        T = self.t
+        if T > 0:
+            self.ring[0:4].copy_(self.ring[T:T + 4].clone())
+            self.since[0:4].copy_(self.since[T:T + 4].clone())
+        self.t = 0
+
+    def step(self, actions):
+        """VectorEnv.step (vector_env.py:41-63) with tensors: (obs, rewards, dones, info)."""
+        if self.t >= self.horizon:
+            self.roll()
+        self.step_async(actions)
+        info = {'episode_returns': self.ep_returns, 'episode_lengths': self.ep_lengths}
+        return self.current_obs(), self.rewards, self.dones.bool(), info
+
+    def check_faults(self):
+        """Raise if any env hit an emulator fault (undocumented opcode, ...). Synchronises."""
+        j = int(self.jam.item())
+        if j:
+            raise N.ParlHipError('atari emulator fault bits 0x%x' % j)
+
+
+class VectorEnvAdapter(object):
+    """List-of-numpy view with the exact VectorEnv return types (vector_env.py:41-63), for code
+    written against the reference (e.g. examples/IMPALA/actor.py:54-91).  Costs a D2H copy per
+    step — the device-native loop in parl_amd.rollout does not use it."""
+
+    def __init__(self, env):
+        self.env = env
+        self.envs_num = env.envs_num
+
+    def reset(self):
+        return list(self.env.reset().cpu().numpy())
+
+    def step(self, actions):
+        a = torch.as_tensor(np.asarray(actions), dtype=torch.int64, device=self.env.device)
+        obs, rew, done, info = self.env.step(a)
+        ret = info['episode_returns'].cpu().numpy()
+        ln = info['episode_lengths'].cpu().numpy()
+        infos = [{'episode': {'r': float(ret[i]), 'l': int(ln[i])}} if ln[i] > 0 else {} for i in range(self.envs_num)]
+        return (list(obs.cpu().numpy()), [float(x) for x in rew.cpu().numpy()], [bool(x) for x in done.cpu().numpy()],
+                infos)
