@@ -1,0 +1,149 @@
+"""IMPALA for the torch host framework with the API of the reference's Paddle implementation
+(parl/algorithms/paddle/impala/impala.py:25-227) — the reference ships no torch IMPALA
+(parl/algorithms/torch/__init__.py:15-29), so this is the torch twin.
+
+What runs where:
+  * model forward/backward, log-softmax gather, entropy, KL, Adam, global-norm clip: PyTorch-ROCm;
+  * _log_prob of the behaviour policy, discounts, the [B*T]->[T-1,B] slicing and V-trace:
+    ONE fused HIP kernel (ops.vtrace_from_logits), no Python loop over time.
+The value and policy heads share one trunk pass when the model offers `policy_and_value`
+(mathematically identical to the reference's two passes, impala.py:148-149).
+"""
+import torch
+import torch.nn.functional as F
+
+from ... import ops
+from ...core import Algorithm
+from . import vtrace
+
+__all__ = ['IMPALA', 'VTraceLoss']
+
+
+class VTraceLoss(object):
+    """Same constructor arguments and attributes as impala.py:25-79; all tensors [T,B]."""
+
+    def __init__(self,
+                 behaviour_actions_log_probs,
+                 target_actions_log_probs,
+                 policy_entropy,
+                 dones,
+                 discount,
+                 rewards,
+                 values,
+                 bootstrap_value,
+                 entropy_coeff=-0.01,
+                 vf_loss_coeff=0.5,
+                 clip_rho_threshold=1.0,
+                 clip_pg_rho_threshold=1.0):
+        self.vtrace_returns = vtrace.from_importance_weights(
+            behaviour_actions_log_probs=behaviour_actions_log_probs.detach(),
+            target_actions_log_probs=target_actions_log_probs.detach(),
+            discounts=(~dones).float() * discount,
+            rewards=rewards,
+            values=values.detach(),
+            bootstrap_value=bootstrap_value.detach(),
+            clip_rho_threshold=clip_rho_threshold,
+            clip_pg_rho_threshold=clip_pg_rho_threshold)
+        _finish_loss(self, target_actions_log_probs, values, policy_entropy, entropy_coeff, vf_loss_coeff)
+
+
+def _finish_loss(self, target_actions_log_probs, values, policy_entropy, entropy_coeff, vf_loss_coeff):
+    # sums, not means (impala.py:67-79)
+    self.pi_loss = -1.0 * torch.sum(target_actions_log_probs * self.vtrace_returns.pg_advantages)
+    delta = values - self.vtrace_returns.vs
+    self.vf_loss = 0.5 * torch.sum(torch.square(delta))
+    self.entropy = torch.sum(policy_entropy)
+    self.total_loss = self.pi_loss + self.vf_loss * vf_loss_coeff + self.entropy * entropy_coeff
+
+
+class _FusedVTraceLoss(object):
+    """VTraceLoss whose V-trace targets came from the fused from-logits kernel."""
+
+    def __init__(self, vs, pg_adv, target_actions_log_probs, values, policy_entropy, entropy_coeff,
+                 vf_loss_coeff):
+        self.vtrace_returns = vtrace.VTraceReturns(vs=vs, pg_advantages=pg_adv)
+        _finish_loss(self, target_actions_log_probs, values, policy_entropy, entropy_coeff, vf_loss_coeff)
+
+
+class IMPALA(Algorithm):
+    def __init__(self,
+                 model,
+                 sample_batch_steps=None,
+                 gamma=None,
+                 vf_loss_coeff=None,
+                 clip_rho_threshold=None,
+                 clip_pg_rho_threshold=None):
+        # same argument checks as impala.py:100-104
+        assert isinstance(sample_batch_steps, int)
+        assert isinstance(gamma, float)
+        assert isinstance(vf_loss_coeff, float)
+        assert isinstance(clip_rho_threshold, float)
+        assert isinstance(clip_pg_rho_threshold, float)
+        super(IMPALA, self).__init__(model)
+        self.sample_batch_steps = sample_batch_steps
+        self.gamma = gamma
+        self.vf_loss_coeff = vf_loss_coeff
+        self.clip_rho_threshold = clip_rho_threshold
+        self.clip_pg_rho_threshold = clip_pg_rho_threshold
+        # paddle Adam(lr=0.001, ClipGradByGlobalNorm(40)) (impala.py:113-117); eps defaults agree
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=0.001)
+        self.grad_clip_norm = 40.0
+        self.grad_hook = None  # set by parl_amd.dist for data-parallel learners
+
+    def _heads(self, obs):
+        if hasattr(self.model, 'policy_and_value'):
+            return self.model.policy_and_value(obs)
+        return self.model.policy(obs), self.model.value(obs)
+
+    def learn(self, obs, actions, behaviour_logits, rewards, dones, learning_rate, entropy_coeff,
+              time_major=False):
+        """Reference contract (impala.py:134-215): flat batches of N = B*T rows, ENV-major
+        ([env0 t0..tT-1, env1 ...], examples/IMPALA/actor.py:78-89).  time_major=True takes the
+        device rollout layout instead (rows ordered [t0 all envs, t1 all envs, ...]).
+
+        obs [N,C,H,W] (uint8 or float32), actions int64 [N], behaviour_logits f32 [N,A],
+        rewards f32 [N], dones bool [N].  Returns (vtrace_loss, kl)."""
+        T = self.sample_batch_steps
+        N = obs.shape[0]
+        B = N // T
+        target_logits, values = self._heads(obs)
+        A = target_logits.shape[-1]
+        logp_all = F.log_softmax(target_logits, dim=-1)
+        p_all = logp_all.exp()
+        policy_entropy = -(p_all * logp_all).sum(-1)  # Categorical.entropy (impala.py:156)
+        target_actions_log_probs = logp_all.gather(-1, actions.unsqueeze(-1)).squeeze(-1)  # :119-132
+        with torch.no_grad():  # kl for debug (impala.py:161-165)
+            blogp = F.log_softmax(behaviour_logits, dim=-1)
+            kl = (p_all * (logp_all - blogp)).sum(-1).mean()
+        if time_major:
+            shp, cut = (T, B), (lambda t: t.reshape(T, B)[:-1])
+        else:
+            shp, cut = (B, T), (lambda t: t.reshape(B, T)[:, :-1])
+        with torch.no_grad():
+            vs, pg_adv = ops.vtrace_from_logits(
+                behaviour_logits.reshape(shp + (A, )), target_logits.detach().reshape(shp + (A, )),
+                actions.reshape(shp), rewards.reshape(shp), dones.reshape(shp), values.detach().reshape(shp),
+                self.gamma, self.clip_rho_threshold, self.clip_pg_rho_threshold, time_major=time_major)
+        # drop the last step of every sequence: it only supplies the bootstrap (impala.py:186-194)
+        vtrace_loss = _FusedVTraceLoss(vs, pg_adv, cut(target_actions_log_probs), cut(values), cut(policy_entropy),
+                                       entropy_coeff, self.vf_loss_coeff)
+        for g in self.optimizer.param_groups:
+            g['lr'] = learning_rate
+        self.optimizer.zero_grad(set_to_none=True)
+        vtrace_loss.total_loss.backward()
+        if self.grad_hook is not None:
+            self.grad_hook(self.model)  # e.g. RCCL all-reduce (sum) of the flattened gradient
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.grad_clip_norm)
+        self.optimizer.step()
+        return vtrace_loss, kl
+
+    @torch.no_grad()
+    def sample(self, obs):
+        """(probs, logits) — impala.py:217-227"""
+        logits = self.model.policy(obs)
+        return F.softmax(logits, dim=-1), logits
+
+    @torch.no_grad()
+    def predict(self, obs):
+        """greedy action (the fluid IMPALA exposes predict, fluid impala.py:214-225)"""
+        return self.model.policy(obs).argmax(-1)

@@ -445,6 +445,10 @@ struct Emu {
         PC = (PC + 2) & 0xffff;
         break;
       }
+      case M_PUSH: cyc++; ea = 0x100 | S; PC = (PC + 1) & 0xffff; break;
+      case M_PULL: cyc += 2; S = (S + 1) & 0xff; ea = 0x100 | S; noise = 0; PC = (PC + 1) & 0xffff;
+                   if (S < 0x80) jam |= JAM_STACK;  // pulling from TIA space is not modelled
+                   break;
       default: break;  // M_IMP / M_REL handled by the operation
     }
     const bool has_ea = kind != K_NONE && mode != M_IMM;
@@ -516,10 +520,10 @@ struct Emu {
       case O_SED: cyc++; P |= FD; PC = (PC + 1) & 0xffff; break;
       case O_NOP: cyc++; PC = (PC + 1) & 0xffff; break;
       case O_JAM: cyc++; jam |= JAM_OPCODE; PC = (PC + 1) & 0xffff; break;
-      case O_PHA: cyc++; push(A); PC = (PC + 1) & 0xffff; break;
-      case O_PHP: cyc++; push(P | FB | FU); PC = (PC + 1) & 0xffff; break;
-      case O_PLA: cyc += 2; A = pull(); set_nz(A); PC = (PC + 1) & 0xffff; break;
-      case O_PLP: cyc += 2; P = (pull() & ~FB) | FU; PC = (PC + 1) & 0xffff; break;
+      case O_PHA: wv = A; S = (S - 1) & 0xff; break;
+      case O_PHP: wv = P | FB | FU; S = (S - 1) & 0xff; break;
+      case O_PLA: A = m; set_nz(A); break;
+      case O_PLP: P = (m & ~FB) | FU; break;
       case O_BPL: case O_BMI: case O_BVC: case O_BVS: case O_BCC: case O_BCS: case O_BNE: case O_BEQ: {
         const int flag = (op == O_BPL || op == O_BMI) ? FN : ((op == O_BVC || op == O_BVS) ? FV :
                          ((op == O_BCC || op == O_BCS) ? FC : FZ));

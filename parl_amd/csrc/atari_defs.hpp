@@ -11,7 +11,9 @@ constexpr int kHBlank = 68, kClocksPerLine = 228, kCyclesPerLine = 76;
 constexpr int kMaxInstrPerFrame = 25000;  // Stella: m6502().execute(25000)
 
 // ---- addressing modes / access kinds / operations of the pre-decoded instruction word ----
-enum Mode : int { M_IMP = 0, M_IMM, M_ZP, M_ZPX, M_ZPY, M_ABS, M_ABX, M_ABY, M_IZX, M_IZY, M_REL };
+enum Mode : int { M_IMP = 0, M_IMM, M_ZP, M_ZPX, M_ZPY, M_ABS, M_ABX, M_ABY, M_IZX, M_IZY, M_REL,
+                  M_PUSH, M_PULL };  // PHA/PHP and PLA/PLP go through the generic bus path (the
+                                     // stack may point into TIA space: the PHP-to-ENABL trick)
 enum Kind : int { K_NONE = 0, K_READ = 1, K_WRITE = 2, K_RMW = 3 };
 enum Op : int {
   O_JAM = 0, O_NOP, O_ORA, O_AND, O_EOR, O_ADC, O_SBC, O_CMP, O_CPX, O_CPY, O_LDA, O_LDX, O_LDY,
@@ -41,10 +43,10 @@ inline uint16_t decode_opcode(uint8_t op) {
     case 0x60: return enc(M_IMP, K_NONE, O_RTS);
     case 0x4c: return enc(M_IMP, K_NONE, O_JMP);
     case 0x6c: return enc(M_IMP, K_NONE, O_JMPI);
-    case 0x08: return enc(M_IMP, K_NONE, O_PHP);
-    case 0x28: return enc(M_IMP, K_NONE, O_PLP);
-    case 0x48: return enc(M_IMP, K_NONE, O_PHA);
-    case 0x68: return enc(M_IMP, K_NONE, O_PLA);
+    case 0x08: return enc(M_PUSH, K_WRITE, O_PHP);
+    case 0x28: return enc(M_PULL, K_READ, O_PLP);
+    case 0x48: return enc(M_PUSH, K_WRITE, O_PHA);
+    case 0x68: return enc(M_PULL, K_READ, O_PLA);
     case 0x88: return enc(M_IMP, K_NONE, O_DEY);
     case 0xa8: return enc(M_IMP, K_NONE, O_TAY);
     case 0xc8: return enc(M_IMP, K_NONE, O_INY);

@@ -1,0 +1,97 @@
+"""One process per GPU over RCCL (torch.distributed backend "nccl" on ROCm) — SURVEY.md §8(e).
+
+The reference has no collective code at all (actors are xparl RPC processes, one learner GPU).
+Here envs shard by rank (env ids rank*E .. rank*E+E-1 keep their RNG streams), every rank runs
+emulator + policy + V-trace + fwd/bwd on its own shard, and ONE exchange happens per update:
+an all-reduce (SUM — the losses are sums, impala.py:67-79, so the data-parallel gradient of the
+union batch is the sum) of the flattened gradient, followed by global-norm clipping on the
+REDUCED gradient and an identical Adam step on every rank.  Small per-step tensors (actions,
+behaviour logits, rewards, dones: 41 B/step at A=6) can be all-gathered for global statistics;
+observations are never gathered (1.45 GB per rank at 84x84 would buy nothing under DP)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """Initialise from the torchrun env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def broadcast_model(model, src=0):
+    """init-time weight broadcast so every rank starts from rank 0's parameters"""
+    if world_size() == 1:
+        return
+    for p in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(p.data, src=src)
+
+
+class FlatGradAllReduce(object):
+    """grad_hook for IMPALA/A2C: one bucket = the whole model (4.0 MB / 10.9 MB fp32), one
+    all-reduce per update.  The flat buffer is allocated once; grads are views into it after the
+    first call, so no pack/unpack copies in steady state."""
+
+    def __init__(self, model):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.params[0].device)
+        off = 0
+        self.views = []
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def __call__(self, model=None):
+        if world_size() == 1:
+            return
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+                p.grad = v
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+
+
+def all_gather_small(tensors):
+    """All-gather a dict of small per-step tensors along a new leading rank dim."""
+    w = world_size()
+    if w == 1:
+        return {k: v.unsqueeze(0) for k, v in tensors.items()}
+    out = {}
+    for k, v in tensors.items():
+        v = v.contiguous()
+        buf = torch.empty((w, ) + tuple(v.shape), dtype=v.dtype, device=v.device)
+        dist.all_gather_into_tensor(buf, v) if v.is_cuda else dist.all_gather(list(buf.unbind(0)), v)
+        out[k] = buf
+    return out
+
+
+def all_reduce_max_scalar(x):
+    """max over ranks of a python float (bench timing)"""
+    if world_size() == 1:
+        return x
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()

@@ -140,8 +140,9 @@ class DeviceVectorEnv(object):
         self._frame_post(3)
         return self.current_obs()
 
-    def step_async(self, actions):
-        """Enqueue one VectorEnv.step; results land in self.rewards/dones/... and ring slot t+4."""
+    def step_async(self, actions, rewards_out=None, dones_out=None):
+        """Enqueue one VectorEnv.step; results land in self.rewards/dones (or the given [E] slabs
+        of a rollout buffer) and the new frame in ring slot t+4."""
         if actions.dtype != torch.int64:
             raise N.ParlHipError('actions must be int64')
         if self.t >= self.horizon:
@@ -150,7 +151,8 @@ class DeviceVectorEnv(object):
         N.check(
             L.parlhip_atari_vec_step(
                 N.ptr(self.states), N.ptr(self.rom_table), self.rom_size, self.game, N.ptr(actions.contiguous()),
-                N.ptr(self.raw_frames), N.ptr(self.rewards), N.ptr(self.dones), N.ptr(self.obs_flags),
+                N.ptr(self.raw_frames), N.ptr(self.rewards if rewards_out is None else rewards_out),
+                N.ptr(self.dones if dones_out is None else dones_out), N.ptr(self.obs_flags),
                 N.ptr(self.ep_returns), N.ptr(self.ep_lengths), self.envs_num, self.seed, self.env_id0,
                 self.max_episode_steps, N.ptr(self.reset_cache), N.ptr(self.jam), N.stream_ptr()),
             'parlhip_atari_vec_step')

@@ -1,0 +1,75 @@
+"""The two Atari networks of the reference examples, as torch parl.Models.
+
+AtariModel42 — examples/IMPALA/atari_model.py:21-90 (42x42 input, 1.00 M params):
+    conv 4->16 k4 s2 p1 (42->21), 16->32 k4 s2 p2 (->11), 32->256 k11 (->1), fc 256->A / 256->1
+    with Normal(0,1) initialised heads (atari_model.py:44-57), obs / 255 (:66).
+AtariModel84 — examples/A2C/atari_model.py:21-104 (84x84 input, 2.74 M params):
+    conv 4->32 k8 s4 p1 (84->20), 32->64 k4 s2 p2 (->11), 64->64 k3 (->9), fc 5184->512,
+    512->A, 512->1.
+obs may arrive as uint8 straight from the rollout ring: the /255 happens after the cast on the
+GPU, so the batch crosses HBM as bytes (4x less than the reference's float32 obs)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..core import Model
+
+__all__ = ['AtariModel42', 'AtariModel84']
+
+
+class AtariModel42(Model):
+    def __init__(self, act_dim):
+        super(AtariModel42, self).__init__()
+        self.conv1 = nn.Conv2d(4, 16, kernel_size=4, stride=2, padding=1)
+        self.conv2 = nn.Conv2d(16, 32, kernel_size=4, stride=2, padding=2)
+        self.conv3 = nn.Conv2d(32, 256, kernel_size=11, stride=1, padding=0)
+        self.policy_fc = nn.Linear(256, act_dim)
+        self.value_fc = nn.Linear(256, 1)
+        for fc in (self.policy_fc, self.value_fc):  # paddle Normal() initializer: N(0, 1)
+            nn.init.normal_(fc.weight, 0.0, 1.0)
+            nn.init.normal_(fc.bias, 0.0, 1.0)
+
+    def _trunk(self, obs):
+        x = obs.float() / 255.0
+        x = F.relu(self.conv1(x))
+        x = F.relu(self.conv2(x))
+        x = F.relu(self.conv3(x))
+        return x.flatten(1)
+
+    def policy(self, obs):
+        return self.policy_fc(self._trunk(obs))
+
+    def value(self, obs):
+        return self.value_fc(self._trunk(obs)).squeeze(1)
+
+    def policy_and_value(self, obs):
+        h = self._trunk(obs)
+        return self.policy_fc(h), self.value_fc(h).squeeze(1)
+
+
+class AtariModel84(Model):
+    def __init__(self, act_dim):
+        super(AtariModel84, self).__init__()
+        self.conv1 = nn.Conv2d(4, 32, kernel_size=8, stride=4, padding=1)
+        self.conv2 = nn.Conv2d(32, 64, kernel_size=4, stride=2, padding=2)
+        self.conv3 = nn.Conv2d(64, 64, kernel_size=3, stride=1, padding=0)
+        self.fc = nn.Linear(5184, 512)
+        self.policy_fc = nn.Linear(512, act_dim)
+        self.value_fc = nn.Linear(512, 1)
+
+    def _trunk(self, obs):
+        x = obs.float() / 255.0
+        x = F.relu(self.conv1(x))
+        x = F.relu(self.conv2(x))
+        x = F.relu(self.conv3(x))
+        return F.relu(self.fc(x.flatten(1)))
+
+    def policy(self, obs):
+        return self.policy_fc(self._trunk(obs))
+
+    def value(self, obs):
+        return self.value_fc(self._trunk(obs)).squeeze(1)
+
+    def policy_and_value(self, obs):
+        h = self._trunk(obs)
+        return self.policy_fc(h), self.value_fc(h).squeeze(1)

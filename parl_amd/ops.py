@@ -205,6 +205,17 @@ def policy_sample(logits_or_probs, seed, offset, row0=0, is_logits=True, want_pr
     return out if len(out) > 1 else actions
 
 
+def policy_sample_into(logits, actions_out, seed, offset, row0=0):
+    """policy_sample writing into a preallocated int64 [B] slab (rollout buffers)."""
+    x = _f32(logits, 'logits')
+    B, A = x.shape
+    N.check(
+        N.lib().parlhip_policy_sample_f32(
+            N.ptr(x), 1, N.ptr(actions_out), None, None, B, A, int(seed) & (2**64 - 1),
+            int(offset) & (2**64 - 1), int(row0) & (2**64 - 1), N.stream_ptr()), 'parlhip_policy_sample_f32')
+    return actions_out
+
+
 def consume_device_errors():
     """Synchronise and return/clear the device-side data-error flag (bad action index)."""
     return N.check(N.lib().parlhip_consume_device_errors(N.stream_ptr()),

@@ -1,0 +1,76 @@
+"""On-device IMPALA actor: the work of examples/IMPALA/actor.py:54-91 (Actor.sample) for E
+envs at once, with no host round trip per step.
+
+Reference flow per step (actor.py:58-76): agent.sample(obs) -> softmax probs to the host ->
+np.random.choice per env (atari_agent.py:38-40) -> vector_env.step -> Python lists; after T steps
+the lists are merged env-major and pickled to the learner (actor.py:78-89).
+Here per step: policy forward (PyTorch-ROCm) -> ops.policy_sample (softmax + inverse-CDF draw,
+Philox uniforms) -> DeviceVectorEnv.step_async (emulator + frame_post kernels) writing rewards /
+dones straight into the [T,E] slabs of this buffer.  The batch handed to the learner is
+TIME-major ([t0 all envs, t1 all envs, ...]); IMPALA.learn(time_major=True) consumes it without
+a transpose (sum-reduced losses are order independent, impala.py:67-79)."""
+import torch
+
+from . import ops
+
+
+class DeviceRollout(object):
+    def __init__(self, env, sample_batch_steps, seed=0):
+        assert env.horizon >= sample_batch_steps, 'env ring too short for the rollout'
+        self.env, self.T, self.seed = env, int(sample_batch_steps), int(seed)
+        E, A, dev = env.envs_num, env.act_dim, env.device
+        T = self.T
+        self.actions = torch.zeros((T, E), dtype=torch.int64, device=dev)
+        self.behaviour_logits = torch.zeros((T, E, A), dtype=torch.float32, device=dev)
+        self.rewards = torch.zeros((T, E), dtype=torch.float32, device=dev)
+        self.dones = torch.zeros((T, E), dtype=torch.uint8, device=dev)
+        self.obs = torch.zeros((T * E, 4, env.dim, env.dim), dtype=torch.uint8, device=dev)
+        self._obs_step = torch.zeros((E, 4, env.dim, env.dim), dtype=torch.uint8, device=dev)
+        self._slots = (torch.arange(T, dtype=torch.int32, device=dev) + 3).repeat_interleave(E)
+        self._envs = torch.arange(E, dtype=torch.int32, device=dev).repeat(T)
+        self.step_count = 0  # Philox offset: one uniform per (global step, env)
+        # MonitorEnv statistics (atari_wrappers.py:44-100), reduced on the device
+        self.ep_count = torch.zeros((), dtype=torch.float64, device=dev)
+        self.ep_return_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.ep_length_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.started = False
+
+    @torch.no_grad()
+    def collect(self, model):
+        """Run T env steps with `model` as behaviour policy; returns the time-major batch."""
+        env = self.env
+        if not self.started:
+            env.reset()
+            self.started = True
+        else:
+            env.roll()
+        for t in range(self.T):
+            obs = env.current_obs(self._obs_step)
+            logits = model.policy(obs)
+            self.behaviour_logits[t].copy_(logits)
+            ops.policy_sample_into(logits, self.actions[t], self.seed, self.step_count, env.env_id0)
+            env.step_async(self.actions[t], self.rewards[t], self.dones[t])
+            closed = env.ep_lengths > 0
+            self.ep_count += closed.sum()
+            self.ep_return_sum += (env.ep_returns * closed).sum()
+            self.ep_length_sum += (env.ep_lengths * closed).sum()
+            self.step_count += 1
+        env.gather(self._slots, self._envs, self.obs)
+        E = env.envs_num
+        return {
+            'obs': self.obs,
+            'actions': self.actions.reshape(self.T * E),
+            'behaviour_logits': self.behaviour_logits.reshape(self.T * E, -1),
+            'rewards': self.rewards.reshape(self.T * E),
+            'dones': self.dones.reshape(self.T * E).bool(),
+        }
+
+    def pop_episode_stats(self):
+        """(episodes closed, mean unclipped return, mean length in emulated frames); syncs."""
+        n = float(self.ep_count.item())
+        r = float(self.ep_return_sum.item())
+        l = float(self.ep_length_sum.item())
+        self.ep_count.zero_()
+        self.ep_return_sum.zero_()
+        self.ep_length_sum.zero_()
+        return n, (r / n if n else None), (l / n if n else None)
