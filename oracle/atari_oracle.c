@@ -566,8 +566,11 @@ static void cpu_step(Atari* a) {
     /* stack */
     case 0x48: a->cyc++; push(a, a->A); break;
     case 0x08: a->cyc++; push(a, a->P | FB | FU); break;
-    case 0x68: a->cyc += 2; a->A = pull(a); set_nz(a, a->A); break;
-    case 0x28: a->cyc += 2; a->P = (uint8_t)((pull(a) & ~FB) | FU); break;
+    /* PLA/PLP: the two dummy reads (next opcode byte, then the old stack top) are real bus
+     * cycles — they decide the data-bus 'noise' bits when the stack sits in TIA space
+     * (Breakout: PHP/PLA at S=$1F strobes ENABL) */
+    case 0x68: rd(a, a->PC); rd(a, 0x100 | a->S); a->A = pull(a); set_nz(a, a->A); break;
+    case 0x28: rd(a, a->PC); rd(a, 0x100 | a->S); a->P = (uint8_t)((pull(a) & ~FB) | FU); break;
     /* branches */
     case 0x10: branch(a, !(a->P & FN)); break; case 0x30: branch(a, a->P & FN); break;
     case 0x50: branch(a, !(a->P & FV)); break; case 0x70: branch(a, a->P & FV); break;

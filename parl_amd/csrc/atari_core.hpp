@@ -446,9 +446,13 @@ struct Emu {
         break;
       }
       case M_PUSH: cyc++; ea = 0x100 | S; PC = (PC + 1) & 0xffff; break;
-      case M_PULL: cyc += 2; S = (S + 1) & 0xff; ea = 0x100 | S; noise = 0; PC = (PC + 1) & 0xffff;
-                   if (S < 0x80) jam |= JAM_STACK;  // pulling from TIA space is not modelled
-                   break;
+      case M_PULL:
+        // two dummy reads (next opcode byte = b1, then the old stack top) precede the pull; when
+        // the stack sits in TIA space (Breakout: PHP/PLA at S=$1F) the old-top read returns
+        // (latches & 0xc0) | (b1 & 0x3f), so the bus noise seen by the pull is b1 & 0x3f
+        cyc += 2; S = (S + 1) & 0xff; ea = 0x100 | S; noise = b1; PC = (PC + 1) & 0xffff;
+        if (S == 0) jam |= JAM_STACK;  // old top in RAM, new top in TIA: noise would be the RAM byte
+        break;
       default: break;  // M_IMP / M_REL handled by the operation
     }
     const bool has_ea = kind != K_NONE && mode != M_IMM;

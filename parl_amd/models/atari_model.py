@@ -7,22 +7,47 @@ AtariModel84 — examples/A2C/atari_model.py:21-104 (84x84 input, 2.74 M params)
     conv 4->32 k8 s4 p1 (84->20), 32->64 k4 s2 p2 (->11), 64->64 k3 (->9), fc 5184->512,
     512->A, 512->1.
 obs may arrive as uint8 straight from the rollout ring: the /255 happens after the cast on the
-GPU, so the batch crosses HBM as bytes (4x less than the reference's float32 obs)."""
+GPU, so the batch crosses HBM as bytes (4x less than the reference's float32 obs).
+
+Convolutions run as im2col + one rocBLAS GEMM (`GemmConv2d`), not through MIOpen: this image
+ships no precompiled MIOpen kernel database for gfx950, so every new (shape, direction) pair
+would JIT-compile for minutes on a fresh box (measured: the 1024-env bench did not finish its
+first learner update in 300 s).  Parameters keep nn.Conv2d's names/shapes, so state_dicts are
+interchangeable with a stock torch model (and with the reference's checkpoints)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ..core import Model
 
-__all__ = ['AtariModel42', 'AtariModel84']
+__all__ = ['AtariModel42', 'AtariModel84', 'GemmConv2d']
+
+
+class GemmConv2d(nn.Conv2d):
+    """nn.Conv2d whose forward is unfold (im2col) + a batched GEMM; fp32, same arithmetic order up
+    to the GEMM's reduction tree.  A kernel that covers the whole input is a plain linear layer."""
+
+    def forward(self, x):
+        kh, kw = self.kernel_size
+        n, c, h, w = x.shape
+        wmat = self.weight.flatten(1)  # [O, C*kh*kw]
+        if (h, w) == (kh, kw) and self.padding == (0, 0):
+            return F.linear(x.flatten(1), wmat, self.bias).view(n, -1, 1, 1)
+        ho = (h + 2 * self.padding[0] - kh) // self.stride[0] + 1
+        wo = (w + 2 * self.padding[1] - kw) // self.stride[1] + 1
+        col = F.unfold(x, self.kernel_size, padding=self.padding, stride=self.stride)  # [N, C*kh*kw, L]
+        out = torch.matmul(wmat, col)  # [N, O, L]
+        if self.bias is not None:
+            out = out + self.bias.view(1, -1, 1)
+        return out.view(n, -1, ho, wo)
 
 
 class AtariModel42(Model):
     def __init__(self, act_dim):
         super(AtariModel42, self).__init__()
-        self.conv1 = nn.Conv2d(4, 16, kernel_size=4, stride=2, padding=1)
-        self.conv2 = nn.Conv2d(16, 32, kernel_size=4, stride=2, padding=2)
-        self.conv3 = nn.Conv2d(32, 256, kernel_size=11, stride=1, padding=0)
+        self.conv1 = GemmConv2d(4, 16, kernel_size=4, stride=2, padding=1)
+        self.conv2 = GemmConv2d(16, 32, kernel_size=4, stride=2, padding=2)
+        self.conv3 = GemmConv2d(32, 256, kernel_size=11, stride=1, padding=0)
         self.policy_fc = nn.Linear(256, act_dim)
         self.value_fc = nn.Linear(256, 1)
         for fc in (self.policy_fc, self.value_fc):  # paddle Normal() initializer: N(0, 1)
@@ -50,9 +75,9 @@ class AtariModel42(Model):
 class AtariModel84(Model):
     def __init__(self, act_dim):
         super(AtariModel84, self).__init__()
-        self.conv1 = nn.Conv2d(4, 32, kernel_size=8, stride=4, padding=1)
-        self.conv2 = nn.Conv2d(32, 64, kernel_size=4, stride=2, padding=2)
-        self.conv3 = nn.Conv2d(64, 64, kernel_size=3, stride=1, padding=0)
+        self.conv1 = GemmConv2d(4, 32, kernel_size=8, stride=4, padding=1)
+        self.conv2 = GemmConv2d(32, 64, kernel_size=4, stride=2, padding=2)
+        self.conv3 = GemmConv2d(64, 64, kernel_size=3, stride=1, padding=0)
         self.fc = nn.Linear(5184, 512)
         self.policy_fc = nn.Linear(512, act_dim)
         self.value_fc = nn.Linear(512, 1)
