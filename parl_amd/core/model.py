@@ -23,7 +23,9 @@ class Model(nn.Module):
 
     def get_weights(self):
         """{name: host numpy copy} (core/torch/model.py:115-123)"""
-        return {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
+        # always a COPY: on a CPU-resident model `.numpy()` would alias the live parameters
+        return {k: (v.detach().cpu().numpy() if v.is_cuda else v.detach().numpy().copy())
+                for k, v in self.state_dict().items()}
 
     def set_weights(self, weights):
         """load host numpy weights (core/torch/model.py:125-134)"""

@@ -24,8 +24,11 @@ __all__ = ['AtariModel42', 'AtariModel84', 'GemmConv2d']
 
 
 class GemmConv2d(nn.Conv2d):
-    """nn.Conv2d whose forward is unfold (im2col) + a batched GEMM; fp32, same arithmetic order up
-    to the GEMM's reduction tree.  A kernel that covers the whole input is a plain linear layer."""
+    """nn.Conv2d whose forward is ONE strided-gather copy (im2col through a 6-D unfold view) + ONE
+    rocBLAS GEMM [N*Ho*Wo, C*kh*kw] x [C*kh*kw, O]; fp32, same arithmetic up to the GEMM's
+    reduction tree.  (torch's F.unfold launches one im2col kernel PER SAMPLE — 614,400 launches
+    per learner update at N=51,200 — so it is not used.)  A kernel that covers the whole input is
+    a plain linear layer.  The output is an NCHW-shaped view of the [N, Ho, Wo, O] GEMM result."""
 
     def forward(self, x):
         kh, kw = self.kernel_size
@@ -33,13 +36,14 @@ class GemmConv2d(nn.Conv2d):
         wmat = self.weight.flatten(1)  # [O, C*kh*kw]
         if (h, w) == (kh, kw) and self.padding == (0, 0):
             return F.linear(x.flatten(1), wmat, self.bias).view(n, -1, 1, 1)
-        ho = (h + 2 * self.padding[0] - kh) // self.stride[0] + 1
-        wo = (w + 2 * self.padding[1] - kw) // self.stride[1] + 1
-        col = F.unfold(x, self.kernel_size, padding=self.padding, stride=self.stride)  # [N, C*kh*kw, L]
-        out = torch.matmul(wmat, col)  # [N, O, L]
-        if self.bias is not None:
-            out = out + self.bias.view(1, -1, 1)
-        return out.view(n, -1, ho, wo)
+        ph, pw = self.padding
+        if ph or pw:
+            x = F.pad(x, (pw, pw, ph, ph))
+        patches = x.unfold(2, kh, self.stride[0]).unfold(3, kw, self.stride[1])  # [N,C,Ho,Wo,kh,kw] view
+        ho, wo = patches.shape[2], patches.shape[3]
+        col = patches.permute(0, 2, 3, 1, 4, 5).reshape(n * ho * wo, c * kh * kw)
+        out = col @ wmat.t() if self.bias is None else torch.addmm(self.bias, col, wmat.t())
+        return out.view(n, ho, wo, -1).permute(0, 3, 1, 2)
 
 
 class AtariModel42(Model):

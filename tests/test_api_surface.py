@@ -1,0 +1,212 @@
+"""Host-side mirror of the reference interface: parl.Model / Algorithm / Agent
+(parl/core/torch/*), IMPALA / A2C constructors, @parl.remote_class calling convention, utils.
+CPU-only; modelled on parl/core/torch/tests/*_test_torch.py and parl/remote/tests/*."""
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import parl_amd as parl
+from parl_amd.remote import FutureGetRepeatedlyError, RemoteError
+
+
+class TinyModel(parl.Model):
+    def __init__(self, act_dim=3):
+        super(TinyModel, self).__init__()
+        self.fc = nn.Linear(4, 8)
+        self.pi = nn.Linear(8, act_dim)
+        self.v = nn.Linear(8, 1)
+
+    def policy(self, obs):
+        return self.pi(torch.relu(self.fc(obs)))
+
+    def value(self, obs):
+        return self.v(torch.relu(self.fc(obs))).squeeze(1)
+
+    def policy_and_value(self, obs):
+        h = torch.relu(self.fc(obs))
+        return self.pi(h), self.v(h).squeeze(1)
+
+
+def test_model_get_set_weights_roundtrip():
+    a, b = TinyModel(), TinyModel()
+    w = a.get_weights()
+    assert all(isinstance(v, np.ndarray) for v in w.values())  # host numpy copies (model.py:115-123)
+    b.set_weights(w)
+    x = torch.randn(5, 4)
+    assert torch.equal(a.policy(x), b.policy(x))
+
+
+def test_model_sync_weights_to_decay():
+    a, b = TinyModel(), TinyModel()
+    wa, wb = a.get_weights(), b.get_weights()
+    a.sync_weights_to(b, decay=0.25)
+    for k, v in b.get_weights().items():
+        if 'weight' in k or 'bias' in k:
+            np.testing.assert_allclose(v, 0.25 * wb[k] + 0.75 * wa[k], rtol=1e-6, atol=1e-7)
+    with pytest.raises(AssertionError):
+        a.sync_weights_to(a)
+
+
+def test_algorithm_weights_walk():
+    class TwoModels(parl.Algorithm):
+        def __init__(self, m):
+            super(TwoModels, self).__init__(m)
+            self.target = TinyModel()
+            self.extras = [TinyModel(), 3]
+
+    alg = TwoModels(TinyModel())
+    w = alg.get_weights()
+    assert set(w) == {'model', 'target', 'extras'} and len(w['extras']) == 1
+    alg2 = TwoModels(TinyModel())
+    alg2.set_weights(w)
+    x = torch.randn(2, 4)
+    assert torch.equal(alg.target.policy(x), alg2.target.policy(x))
+    with pytest.raises(AssertionError):
+        parl.Algorithm(model=nn.Linear(2, 2))  # not a parl.Model
+
+
+def test_agent_save_restore(tmp_path):
+    class A(parl.Agent):
+        pass
+
+    alg = parl.algorithms.A2C(TinyModel(), vf_loss_coeff=0.5)
+    ag = A(alg)
+    p = str(tmp_path / 'sub' / 'model.ckpt')
+    ag.save(p)
+    alg2 = parl.algorithms.A2C(TinyModel(), vf_loss_coeff=0.5)
+    ag2 = A(alg2)
+    ag2.restore(p)
+    x = torch.randn(3, 4)
+    assert torch.equal(alg.model.policy(x), alg2.model.policy(x))
+    ag.eval()
+    assert not alg.model.training
+    ag.train()
+    assert alg.model.training
+
+
+def test_a2c_ctor_both_reference_signatures():
+    m = TinyModel()
+    a = parl.algorithms.A2C(m, vf_loss_coeff=0.5)  # paddle signature (paddle/a2c.py:26)
+    b = parl.algorithms.A2C(m, {'vf_loss_coeff': 0.25, 'learning_rate': 3e-4})  # torch (torch/a2c.py:27)
+    c = parl.algorithms.A2C(m, 0.5)
+    assert (a.vf_loss_coeff, b.vf_loss_coeff, c.vf_loss_coeff) == (0.5, 0.25, 0.5)
+    with pytest.raises(AssertionError):
+        parl.algorithms.A2C(nn.Linear(2, 2), vf_loss_coeff=0.5)
+
+
+def test_a2c_learn_matches_manual_loss_cpu():
+    """A2C.learn's loss arithmetic (torch/a2c.py:40-81) is plain torch and runs on CPU."""
+    torch.manual_seed(0)
+    m = TinyModel()
+    alg = parl.algorithms.A2C(m, vf_loss_coeff=0.5)
+    obs, act = torch.randn(6, 4), torch.randint(0, 3, (6, ))
+    adv, tgt = torch.randn(6), torch.randn(6)
+    logits, values = m.policy_and_value(obs)
+    logp = torch.log_softmax(logits, 1)
+    pi = -(logp.gather(1, act[:, None]).squeeze(1) * adv).sum()
+    vf = 0.5 * ((values - tgt)**2).sum()
+    ent = -(logp.exp() * logp).sum()
+    total, pi_l, vf_l, ent_l = alg.learn(obs, act, adv, tgt, 1e-3, -0.01)
+    np.testing.assert_allclose(float(pi_l), float(pi), rtol=1e-6)
+    np.testing.assert_allclose(float(vf_l), float(vf), rtol=1e-6)
+    np.testing.assert_allclose(float(ent_l), float(ent), rtol=1e-6)
+    np.testing.assert_allclose(float(total), float(pi + 0.5 * vf - 0.01 * ent), rtol=1e-6)
+
+
+def test_impala_ctor_asserts():
+    m = TinyModel()
+    parl.algorithms.IMPALA(m, sample_batch_steps=5, gamma=0.99, vf_loss_coeff=0.5, clip_rho_threshold=1.0,
+                           clip_pg_rho_threshold=1.0)
+    with pytest.raises(AssertionError):  # impala.py:100-104: gamma must be a float
+        parl.algorithms.IMPALA(m, sample_batch_steps=5, gamma=1, vf_loss_coeff=0.5, clip_rho_threshold=1.0,
+                               clip_pg_rho_threshold=1.0)
+
+
+def test_ops_refuse_cpu_tensors_no_fallback():
+    from parl_amd import ops
+    from parl_amd._native import ParlHipError
+    z = torch.zeros((3, 2))
+    with pytest.raises(ParlHipError):
+        ops.vtrace(z, z, z, z, z, torch.zeros(2))
+    with pytest.raises(ParlHipError):
+        ops.gae(z, z, torch.zeros((3, 2), dtype=torch.uint8), torch.zeros(2), 0.99, 0.95)
+
+
+# ---------------------------------------------------------------- @parl.remote_class
+@parl.remote_class
+class Counter(object):
+    def __init__(self, start=0):
+        self.n = start
+
+    def add(self, k):
+        self.n += k
+        return self.n
+
+    def boom(self):
+        raise ValueError('boom')
+
+
+@parl.remote_class(wait=False, max_memory=300, n_gpu=0)
+class SlowCounter(object):
+    def __init__(self):
+        self.n = 0
+        self.thread = None
+
+    def add(self, k):
+        time.sleep(0.02)
+        self.thread = threading.current_thread().name
+        self.n += k
+        return self.n
+
+    def boom(self):
+        raise ValueError('boom')
+
+
+def test_remote_class_wait_mode():
+    parl.connect('localhost:8010')
+    c = Counter(5)
+    assert c.add(2) == 7
+    assert c.n == 7  # attribute get is proxied (proxy_wrapper.py:69-76)
+    c.n = 10
+    assert c.add(1) == 11
+    with pytest.raises(RemoteError):
+        c.boom()
+
+
+def test_remote_class_nowait_futures():
+    c = SlowCounter()
+    futs = [c.add(1) for _ in range(5)]
+    assert [f.get() for f in futs] == [1, 2, 3, 4, 5]  # one worker thread, call order kept
+    assert c.thread != threading.current_thread().name
+    with pytest.raises(FutureGetRepeatedlyError):
+        futs[0].get()
+    with pytest.raises(RemoteError):
+        c.boom().get()
+
+
+def test_remote_class_xparl_env_returns_raw_class(monkeypatch):
+    monkeypatch.setenv('XPARL', 'True')  # remote_decorator.py:75-77
+
+    @parl.remote_class(wait=False)
+    class Raw(object):
+        def f(self):
+            return 1
+
+    assert Raw().f() == 1
+
+
+# ---------------------------------------------------------------- utils
+def test_window_and_time_stat():
+    w = parl.utils.WindowStat(3)
+    for v in (1.0, 2.0, 3.0, 4.0):
+        w.add(v)
+    assert w.count == 4 and w.mean == 3.0 and w.min == 2.0 and w.max == 4.0
+    t = parl.utils.TimeStat(window_size=2)
+    with t:
+        time.sleep(0.001)
+    assert t.mean > 0

@@ -1,0 +1,153 @@
+"""N>1 path on CPU: world_size-2 gloo processes.  Covers the host-side exchange
+logic (flat gradient all-reduce with SUM semantics, clip on the REDUCED gradient, identical Adam
+step on every rank, small-tensor all-gather, max-over-ranks timing) and the env sharding contract
+(env ids rank*E .. rank*E+E-1 keep their RNG streams, checked on the CPU oracle env)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import torch.nn as nn
+    import parl_amd as parl
+    from parl_amd import dist as pdist
+
+    r, l, w = pdist.init(backend='gloo')
+    assert (r, w) == (rank, world)
+
+    class M(parl.Model):
+        def __init__(self):
+            super(M, self).__init__()
+            self.fc = nn.Linear(4, 8)
+            self.pi = nn.Linear(8, 3)
+            self.v = nn.Linear(8, 1)
+
+        def policy(self, o):
+            return self.pi(torch.tanh(self.fc(o)))
+
+        def value(self, o):
+            return self.v(torch.tanh(self.fc(o))).squeeze(1)
+
+        def policy_and_value(self, o):
+            h = torch.tanh(self.fc(o))
+            return self.pi(h), self.v(h).squeeze(1)
+
+    torch.manual_seed(100 + rank)  # different init per rank: broadcast must fix it
+    m = M()
+    pdist.broadcast_model(m)
+    alg = parl.algorithms.A2C(m, vf_loss_coeff=0.5)
+    alg.grad_hook = pdist.FlatGradAllReduce(m)
+    g = torch.Generator().manual_seed(7)
+    obs = torch.randn(2 * 6, 4, generator=g)
+    act = torch.randint(0, 3, (2 * 6, ), generator=g)
+    adv, tgt = torch.randn(2 * 6, generator=g), torch.randn(2 * 6, generator=g)
+    sl = slice(rank * 6, rank * 6 + 6)  # this rank's shard of the union batch
+    for _ in range(3):
+        alg.learn(obs[sl], act[sl], adv[sl] * 30, tgt[sl], 1e-2, -0.01)  # *30: make the clip bite
+    gathered = pdist.all_gather_small({'x': torch.full((2, 3), float(rank))})
+    tmax = pdist.all_reduce_max_scalar(1.0 + rank)
+    pdist.barrier()
+    q.put((rank, {k: v.numpy().copy() for k, v in m.state_dict().items()}, gathered['x'].numpy().copy(), tmax))
+
+
+def test_data_parallel_matches_single_learner_on_union_batch(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sd0, sd1 = res[0][1], res[1][1]
+    for k in sd0:  # identical parameters on every rank after DP updates
+        assert np.array_equal(sd0[k], sd1[k]), k
+    assert np.array_equal(res[0][2], np.array([[[0.] * 3] * 2, [[1.] * 3] * 2], np.float32))
+    assert res[0][3] == 2.0 and res[1][3] == 2.0
+
+    # single learner on the union batch, starting from rank 0's init: sums of losses => the DP
+    # gradient is the SUM over ranks (impala.py:67-79 / a2c.py:67-79), clip applies after the sum
+    import torch.nn as nn
+    import parl_amd as parl
+
+    class M(parl.Model):
+        def __init__(self):
+            super(M, self).__init__()
+            self.fc = nn.Linear(4, 8)
+            self.pi = nn.Linear(8, 3)
+            self.v = nn.Linear(8, 1)
+
+        def policy_and_value(self, o):
+            h = torch.tanh(self.fc(o))
+            return self.pi(h), self.v(h).squeeze(1)
+
+        def policy(self, o):
+            return self.policy_and_value(o)[0]
+
+        def value(self, o):
+            return self.policy_and_value(o)[1]
+
+    torch.manual_seed(100)
+    m = M()
+    alg = parl.algorithms.A2C(m, vf_loss_coeff=0.5)
+    g = torch.Generator().manual_seed(7)
+    obs = torch.randn(12, 4, generator=g)
+    act = torch.randint(0, 3, (12, ), generator=g)
+    adv, tgt = torch.randn(12, generator=g), torch.randn(12, generator=g)
+    for _ in range(3):
+        alg.learn(obs, act, adv * 30, tgt, 1e-2, -0.01)
+    for k, v in m.state_dict().items():
+        np.testing.assert_allclose(sd0[k], v.numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_env_sharding_keeps_rng_streams(oracle):
+    """rank r owns env ids r*E..r*E+E-1: a shard started at env_id0 reproduces the corresponding
+    envs of the unsharded vector env (same noop streams, same trajectories)."""
+    from parl_amd.env import find_rom
+    try:
+        rom = find_rom('breakout')
+    except FileNotFoundError:
+        pytest.skip('cartridge not present')
+    full = oracle.VecEnv(rom, 'breakout', 4, 42, seed=9)
+    shard = oracle.VecEnv(rom, 'breakout', 2, 42, seed=9, env_id0=2)
+    assert np.array_equal(full.reset()[2:], shard.reset())
+    rng = np.random.default_rng(0)
+    for _ in range(60):
+        a = rng.integers(0, 4, 4)
+        o, r, d = full.step(a)
+        o2, r2, d2 = shard.step(a[2:])
+        assert np.array_equal(o[2:], o2) and np.array_equal(r[2:], r2) and np.array_equal(d[2:], d2)
+
+
+@pytest.mark.gpu
+def test_device_env_sharding_keeps_rng_streams(dev):
+    from parl_amd.env import DeviceVectorEnv
+    full = DeviceVectorEnv('BreakoutNoFrameskip-v4', 4, dim=42, horizon=8, seed=9, device=dev)
+    shard = DeviceVectorEnv('BreakoutNoFrameskip-v4', 2, dim=42, horizon=8, seed=9, env_id0=2, device=dev)
+    assert torch.equal(full.reset()[2:], shard.reset())
+    g = torch.Generator().manual_seed(0)
+    for _ in range(120):
+        a = torch.randint(0, 4, (4, ), generator=g).to(dev)
+        o, r, d, _ = full.step(a)
+        o2, r2, d2, _ = shard.step(a[2:].contiguous())
+        assert torch.equal(o[2:], o2) and torch.equal(r[2:], r2) and torch.equal(d[2:], d2)
