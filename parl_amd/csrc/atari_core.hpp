@@ -121,15 +121,18 @@ struct Emu {
                         ((c2 >= 0) && (o2 >= 0) && (o2 < w));
         return in && (enam & 0x02) && !(resmp & 0x02);
       };
-      const bool p0 = act && g0 && player(t(T_POSP0), nus0, t(T_REFP0), g0, t(T_SUP0));
-      const bool p1 = act && g1 && player(t(T_POSP1), nus1, t(T_REFP1), g1, t(T_SUP1));
-      const bool m0 = act && missile(t(T_POSM0), nus0, t(T_ENAM0), t(T_RESMP0));
-      const bool m1 = act && missile(t(T_POSM1), nus1, t(T_ENAM1), t(T_RESMP1));
-      bool bl;
-      {
+      // wave-uniform enables first: a disabled object costs one scalar branch, not its pixel math
+      // (most Pong / Breakout scanlines have no player, missile or ball at all)
+      bool p0 = false, p1 = false, m0 = false, m1 = false, bl = false;
+      if (g0) p0 = act && player(t(T_POSP0), nus0, t(T_REFP0), g0, t(T_SUP0));
+      if (g1) p1 = act && player(t(T_POSP1), nus1, t(T_REFP1), g1, t(T_SUP1));
+      const int enam0 = t(T_ENAM0), enam1 = t(T_ENAM1), resmp0 = t(T_RESMP0), resmp1 = t(T_RESMP1);
+      if ((enam0 & 0x02) && !(resmp0 & 0x02)) m0 = act && missile(t(T_POSM0), nus0, enam0, resmp0);
+      if ((enam1 & 0x02) && !(resmp1 & 0x02)) m1 = act && missile(t(T_POSM1), nus1, enam1, resmp1);
+      if (ebl) {
         int d = x - t(T_POSBL);
         d += d < 0 ? 160 : 0;
-        bl = act && ebl && (d < (1 << ((ctrlpf >> 4) & 3)));
+        bl = act && (d < (1 << ((ctrlpf >> 4) & 3)));
       }
       bool pf;
       {
@@ -174,12 +177,57 @@ struct Emu {
     if (fb && act) fb[row * kW + x] = (uint8_t)color;
   }
 
+  // wave-uniform: can any pixel of the current register state set a collision latch?
+  DEVI bool can_collide() const {
+    if (t(T_VBLANK) & 0x02) return false;
+    const int g0 = (t(T_VDELP0) & 1) ? t(T_DGRP0) : t(T_GRP0);
+    const int g1 = (t(T_VDELP1) & 1) ? t(T_DGRP1) : t(T_GRP1);
+    const int ebl = ((t(T_VDELBL) & 1) ? t(T_DENABL) : t(T_ENABL)) & 0x02;
+    const int m0 = (t(T_ENAM0) & 0x02) && !(t(T_RESMP0) & 0x02);
+    const int m1 = (t(T_ENAM1) & 0x02) && !(t(T_RESMP1) & 0x02);
+    return (g0 | g1 | ebl | m0 | m1) != 0;
+  }
+
+  // Does writing `v` to TIA register `reg` change anything the picture or the collision latches
+  // depend on?  If not, the catch-up render before the write can be skipped: the pending pixels
+  // are drawn later with identical register state.  (Pong rewrites PF1/PF2/GRP1/ENAM0/ENABL with
+  // unchanged values on almost every scanline and strobes WSYNC mid-line.)
+  DEVI bool write_needs_catch_up(int reg, int v) const {
+    switch (reg) {
+      case 0x00: case 0x02: case 0x03:                           // VSYNC, WSYNC, RSYNC
+      case 0x15: case 0x16: case 0x17: case 0x18: case 0x19: case 0x1a:  // audio
+      case 0x20: case 0x21: case 0x22: case 0x23: case 0x24: case 0x2b:  // HMxx, HMCLR: used at HMOVE
+        return false;
+      case 0x01: case 0x04: case 0x05: case 0x0a: case 0x0b: case 0x0c: case 0x0d: case 0x0e:
+      case 0x0f: case 0x1d: case 0x1e: case 0x1f: case 0x25: case 0x26: case 0x27:
+        return t(reg) != v;
+      case 0x06: case 0x07: case 0x08: case 0x09:
+        return t(reg) != (v & 0xfe);
+      case 0x1b: return t(T_GRP0) != v || t(T_DGRP1) != t(T_GRP1);
+      case 0x1c: return t(T_GRP1) != v || t(T_DGRP0) != t(T_GRP0) || t(T_DENABL) != t(T_ENABL);
+      default:
+        return reg <= 0x2c;  // position strobes, RESMPx, HMOVE, CXCLR: always; unmapped: never
+    }
+  }
+
   DEVI void tia_update(int clock) {
     const int c0 = cyc0 * 3;
     const int start = c0 + kClocksPerLine * kYStart;
     const int stop_clock = start + kClocksPerLine * kH;
     clock = clock > stop_clock ? stop_clock : clock;
     last_clock = last_clock < start ? start : last_clock;
+    if (last_clock >= clock) return;
+    if (!fb && !can_collide()) {
+      // collisions-only frame and nothing to latch in this span (VBLANK on, or no player /
+      // missile / ball enabled): skip the pixels, keep the end-of-scanline side effects
+      if ((clock - c0) / kClocksPerLine > (last_clock - c0) / kClocksPerLine) {
+        tset(T_SUP0, 0);
+        tset(T_SUP1, 0);
+        tset(T_HMBLANK, 0);
+      }
+      last_clock = clock;
+      return;
+    }
     while (last_clock < clock) {
       const int rel = last_clock - c0;
       const int line = rel / kClocksPerLine;
@@ -460,11 +508,16 @@ struct Emu {
     // ---- stage R: catch the picture up before a TIA access (single render site) ----
     if (is_tia) {
       if (kind == K_READ) {
-        tia_update((cyc + 1) * 3);
+        // only the collision latches (CXxx, 0x0-0x7) depend on the picture; INPTx do not
+        if ((ea & 0x0f) < 8) tia_update((cyc + 1) * 3);
       } else if (kind == K_WRITE) {
-        const int clock = (cyc + 1) * 3;
-        const int hpos = (clock - cyc0 * 3) % kClocksPerLine;
-        tia_update(clock + poke_delay(ea & 0x3f, hpos));
+        const int reg = ea & 0x3f;
+        const int wvp = op == O_STA ? A : (op == O_STX ? X : (op == O_STY ? Y : (op == O_PHA ? A : (P | FB | FU))));
+        if (write_needs_catch_up(reg, wvp)) {
+          const int clock = (cyc + 1) * 3;
+          const int hpos = (clock - cyc0 * 3) % kClocksPerLine;
+          tia_update(clock + poke_delay(reg, hpos));
+        }
       } else {
         jam |= JAM_RMW_TIA;
       }

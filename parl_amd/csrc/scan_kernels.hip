@@ -203,42 +203,20 @@ __global__ __launch_bounds__(256) void vtrace_logits_tm_kernel(
   }
 }
 
-// V-trace fused from logits, wave-per-sequence, env-major [B,T,A] (reference flat batch).
-// Lane l owns time steps t = l*K + k, k < K; suffix scan over affine pairs with shuffles.
-template <int A_CT, int K>
-__global__ __launch_bounds__(256) void vtrace_logits_em_kernel(
-    const float* __restrict__ blog, const float* __restrict__ tlog,
-    const int64_t* __restrict__ actions, const float* __restrict__ rew,
-    const uint8_t* __restrict__ dones, const float* __restrict__ val,
-    float* __restrict__ vs, float* __restrict__ pg, float* __restrict__ tlp_out,
-    float* __restrict__ blp_out, int T, int B, int A, float gamma, float clip_rho,
-    float clip_pg, int* __restrict__ err) {
-  const int lane = threadIdx.x & 63;
-  const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (b >= B) return;  // whole wave exits together
-  const int Tm = T - 1;
-  const int64_t base = b * T;
-  const float bootstrap = val[base + Tm];
-
-  float rho[K], dsc[K], v[K], r[K], tl[K], bl[K];
-  bool valid[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int t = lane * K + k;
-    valid[k] = t < Tm;
-    rho[k] = 1.f; dsc[k] = 0.f; v[k] = 0.f; r[k] = 0.f; tl[k] = 0.f; bl[k] = 0.f;
-    if (valid[k]) {
-      const int64_t i = base + t;
-      int a = (int)actions[i];
-      if (a < 0 || a >= A) { *err = 1; a = 0; }
-      tl[k] = log_prob_row<A_CT>(tlog + i * A, A, a);
-      bl[k] = log_prob_row<A_CT>(blog + i * A, A, a);
-      dsc[k] = dones[i] ? 0.f : gamma;
-      rho[k] = expf(tl[k] - bl[k]);
-      v[k] = val[i];
-      r[k] = rew[i];
-    }
-  }
+// ----------------------------------------------------------------------------------------
+// Wave-per-sequence V-trace core.  Lane l owns time steps t = l*K + k, k < K (T' <= 64*K); the
+// affine recurrence acc_t = delta_t + (disc_t * c_t) * acc_{t+1} is solved with a 6-step
+// wavefront-shuffle suffix scan over (a, d) pairs, so one sequence costs ONE round of loads
+// plus O(K + log 64) dependent steps instead of T' dependent steps.  Used (a) for the
+// reference's env-major flat batch, where T is the contiguous axis, and (b) for time-major
+// input when B is too small for lane-per-sequence to fill the chip (B=1024: 16 waves).
+// ----------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void vtrace_wave_core(const float (&rho)[K], const float (&dsc)[K],
+                                                 const float (&v)[K], const float (&r)[K],
+                                                 const bool (&valid)[K], int lane, int Tm,
+                                                 float bootstrap, float clip_rho, float clip_pg,
+                                                 float (&vst)[K], float (&pgv)[K]) {
   // V_{t+1}: next step in-lane, or the first value of the next lane, or the bootstrap.
   const float v_first_next_lane = __shfl_down(v[0], 1, 64);
   float v_next[K];
@@ -279,7 +257,6 @@ __global__ __launch_bounds__(256) void vtrace_logits_em_kernel(
   // carry entering this lane's block = suffix result of lane+1 (0 for the last lane)
   float carry = __shfl_down(SD, 1, 64);
   if (lane == 63) carry = 0.f;
-  float vst[K];
 #pragma unroll
   for (int k = K - 1; k >= 0; --k) {
     carry = d_[k] + a_[k] * carry;
@@ -289,14 +266,98 @@ __global__ __launch_bounds__(256) void vtrace_logits_em_kernel(
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int t = lane * K + k;
-    if (!valid[k]) continue;
     float nvs = (k + 1 < K) ? vst[(k + 1 < K) ? k + 1 : k] : vs_first_next_lane;
     if (t + 1 >= Tm) nvs = bootstrap;
-    const int64_t o = b * Tm + t;
-    pg[o] = clip_max(rho[k], clip_pg) * (r[k] + dsc[k] * nvs - v[k]);
+    pgv[k] = clip_max(rho[k], clip_pg) * (r[k] + dsc[k] * nvs - v[k]);
+  }
+}
+
+// V-trace fused from logits, wave-per-sequence.  TM = false: env-major [B,T,A] (the reference's
+// flat batch, impala.py:167-175); TM = true: time-major [T,B,A] with small B.
+template <int A_CT, int K, bool TM>
+__global__ __launch_bounds__(256) void vtrace_logits_wave_kernel(
+    const float* __restrict__ blog, const float* __restrict__ tlog,
+    const int64_t* __restrict__ actions, const float* __restrict__ rew,
+    const uint8_t* __restrict__ dones, const float* __restrict__ val,
+    float* __restrict__ vs, float* __restrict__ pg, float* __restrict__ tlp_out,
+    float* __restrict__ blp_out, int T, int B, int A, float gamma, float clip_rho,
+    float clip_pg, int* __restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (b >= B) return;  // whole wave exits together
+  const int Tm = T - 1;
+  // element (t, b): inputs hold T steps, outputs T-1 steps, same major order
+  const int64_t in_t = TM ? B : 1, in_b = TM ? 1 : T, out_b = TM ? 1 : Tm;
+  const float bootstrap = val[(int64_t)Tm * in_t + b * in_b];
+
+  float rho[K], dsc[K], v[K], r[K], tl[K], bl[K], vst[K], pgv[K];
+  bool valid[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int t = lane * K + k;
+    valid[k] = t < Tm;
+    rho[k] = 1.f; dsc[k] = 0.f; v[k] = 0.f; r[k] = 0.f; tl[k] = 0.f; bl[k] = 0.f;
+    if (valid[k]) {
+      const int64_t i = (int64_t)t * in_t + b * in_b;
+      int a = (int)actions[i];
+      if (a < 0 || a >= A) { *err = 1; a = 0; }
+      tl[k] = log_prob_row<A_CT>(tlog + i * A, A, a);
+      bl[k] = log_prob_row<A_CT>(blog + i * A, A, a);
+      dsc[k] = dones[i] ? 0.f : gamma;
+      rho[k] = expf(tl[k] - bl[k]);
+      v[k] = val[i];
+      r[k] = rew[i];
+    }
+  }
+  vtrace_wave_core<K>(rho, dsc, v, r, valid, lane, Tm, bootstrap, clip_rho, clip_pg, vst, pgv);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int t = lane * K + k;
+    if (!valid[k]) continue;
+    const int64_t o = (int64_t)t * in_t + b * out_b;
+    pg[o] = pgv[k];
     vs[o] = vst[k];
     if (tlp_out) tlp_out[o] = tl[k];
     if (blp_out) blp_out[o] = bl[k];
+  }
+}
+
+// V-trace from log-probs (the reference function boundary), time-major, wave-per-sequence:
+// the small-B path of parlhip_vtrace_f32 (reference shape T'=49, B=1024 is 1.4 MB).
+template <int K>
+__global__ __launch_bounds__(256) void vtrace_wave_kernel(
+    const float* __restrict__ blp, const float* __restrict__ tlp,
+    const float* __restrict__ disc, const float* __restrict__ rew,
+    const float* __restrict__ val, const float* __restrict__ boot,
+    float* __restrict__ vs, float* __restrict__ pg, int T, int B, float clip_rho,
+    float clip_pg) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (b >= B) return;
+  const float bootstrap = boot[b];
+  float rho[K], dsc[K], v[K], r[K], vst[K], pgv[K];
+  bool valid[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int t = lane * K + k;
+    valid[k] = t < T;
+    rho[k] = 1.f; dsc[k] = 0.f; v[k] = 0.f; r[k] = 0.f;
+    if (valid[k]) {
+      const int64_t i = (int64_t)t * B + b;
+      rho[k] = expf(tlp[i] - blp[i]);
+      dsc[k] = disc[i];
+      v[k] = val[i];
+      r[k] = rew[i];
+    }
+  }
+  vtrace_wave_core<K>(rho, dsc, v, r, valid, lane, T, bootstrap, clip_rho, clip_pg, vst, pgv);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int t = lane * K + k;
+    if (!valid[k]) continue;
+    const int64_t o = (int64_t)t * B + b;
+    pg[o] = pgv[k];
+    vs[o] = vst[k];
   }
 }
 
@@ -462,6 +523,10 @@ PARLHIP_EXPORT int parlhip_consume_device_errors(parlhip_stream_t stream) {
   return h;
 }
 
+// Largest B for which time-major input takes the wave-per-sequence kernels (B waves): above it
+// lane-per-sequence (B/64 waves of fully coalesced loads) has enough waves to hide latency.
+static constexpr int kWaveSeqMaxB = 8192;
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Choose VEC: float4 lanes need B % 4 == 0, 16-B aligned bases, and enough sequences that a
@@ -484,6 +549,22 @@ PARLHIP_EXPORT int parlhip_vtrace_f32(const float* blp, const float* tlp,
   if (!blp || !tlp || !discounts || !rewards || !values || !bootstrap || !vs || !pg)
     return PARLHIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (B <= kWaveSeqMaxB && T <= 64 * 32) {
+    // too few sequences for lane-per-sequence to fill 256 CUs: one wavefront per sequence
+    const int K = ceil_div(T, 64);
+    const int grid = ceil_div((int64_t)B * 64, 256);
+#define LAUNCH_W(KK)                                                                      \
+  vtrace_wave_kernel<KK><<<grid, 256, 0, s>>>(blp, tlp, discounts, rewards, values,      \
+                                              bootstrap, vs, pg, T, B, clip_rho, clip_pg)
+    if (K <= 1) LAUNCH_W(1);
+    else if (K <= 2) LAUNCH_W(2);
+    else if (K <= 4) LAUNCH_W(4);
+    else if (K <= 8) LAUNCH_W(8);
+    else if (K <= 16) LAUNCH_W(16);
+    else LAUNCH_W(32);
+#undef LAUNCH_W
+    return check_launch();
+  }
   if (use_vec4(B, {blp, tlp, discounts, rewards, values, bootstrap, vs, pg})) {
     const int threads = B / 4;
     vtrace_tm_kernel<4, 4><<<ceil_div(threads, 256), 256, 0, s>>>(
@@ -502,21 +583,28 @@ static int launch_vtrace_logits(const float* blog, const float* tlog, const int6
                                 float* vs, float* pg, float* tlp_out, float* blp_out, int T,
                                 int B, int A, int time_major, float gamma, float clip_rho,
                                 float clip_pg, hipStream_t s, int* err) {
-  if (time_major) {
+  const int Tm = T - 1;
+  const int K = ceil_div(Tm, 64);
+  if (time_major && (B > kWaveSeqMaxB || K > 32)) {
     const int block = B >= 256 * 64 ? 256 : 64;
     vtrace_logits_tm_kernel<A_CT><<<ceil_div(B, block), block, 0, s>>>(
         blog, tlog, actions, rew, dones, val, vs, pg, tlp_out, blp_out, T, B, A, gamma,
         clip_rho, clip_pg, err);
     return check_launch();
   }
-  const int Tm = T - 1;
-  const int K = ceil_div(Tm, 64);
   const int block = 256;  // 4 sequences per workgroup
   const int grid = ceil_div((int64_t)B * 64, block);
 #define LAUNCH_EM(KK)                                                                    \
-  vtrace_logits_em_kernel<A_CT, KK><<<grid, block, 0, s>>>(                              \
-      blog, tlog, actions, rew, dones, val, vs, pg, tlp_out, blp_out, T, B, A, gamma,    \
-      clip_rho, clip_pg, err)
+  do {                                                                                   \
+    if (time_major)                                                                      \
+      vtrace_logits_wave_kernel<A_CT, KK, true><<<grid, block, 0, s>>>(                  \
+          blog, tlog, actions, rew, dones, val, vs, pg, tlp_out, blp_out, T, B, A,       \
+          gamma, clip_rho, clip_pg, err);                                                \
+    else                                                                                 \
+      vtrace_logits_wave_kernel<A_CT, KK, false><<<grid, block, 0, s>>>(                 \
+          blog, tlog, actions, rew, dones, val, vs, pg, tlp_out, blp_out, T, B, A,       \
+          gamma, clip_rho, clip_pg, err);                                                \
+  } while (0)
   if (K <= 1) LAUNCH_EM(1);
   else if (K <= 2) LAUNCH_EM(2);
   else if (K <= 4) LAUNCH_EM(4);

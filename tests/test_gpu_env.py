@@ -1,0 +1,120 @@
+"""Device Atari env (HIP emulator + wrapper state machine + frame_post + frame-stack ring, through
+the C ABI) against the CPU oracle: bit-exact RAM, raw frames, observations, rewards, dones and
+MonitorEnv episode records.  Needs a real MI355X: -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GAMES = {'pong': 'PongNoFrameskip-v4', 'breakout': 'BreakoutNoFrameskip-v4'}
+
+
+def _rom(game):
+    from parl_amd.env import find_rom
+    try:
+        return find_rom(game)
+    except FileNotFoundError:
+        pytest.skip('cartridge %s.bin not present' % game)
+
+
+def _run_parity(dev, oracle, game, E, dim, steps, seed, max_episode_steps=400000, cache=True, check_ram=True):
+    from parl_amd.env import DeviceVectorEnv
+    rom = _rom(game)
+    env = DeviceVectorEnv(GAMES[game], E, dim=dim, horizon=8, seed=seed, device=dev, rom_bytes=rom,
+                          max_episode_steps=max_episode_steps, use_reset_cache=cache)
+    orc = oracle.VecEnv(rom, game, E, dim, seed=seed, max_episode_steps=max_episode_steps)
+    assert np.array_equal(env.reset().cpu().numpy(), orc.reset())
+    sb = env.states.numel() // E
+    rng = np.random.default_rng(seed)
+    ndone = 0
+    for i in range(steps):
+        a = rng.integers(0, env.act_dim, E)
+        o, r, d, info = env.step(torch.from_numpy(a).to(dev))
+        oo, orr, od = orc.step(a)
+        assert np.array_equal(r.cpu().numpy(), orr), 'reward, step %d' % i
+        assert np.array_equal(d.cpu().numpy().astype(np.uint8), od), 'done, step %d' % i
+        assert np.array_equal(o.cpu().numpy(), oo), 'obs, step %d' % i
+        if check_ram:
+            ram = env.states.view(E, sb)[:, :128].cpu().numpy()
+            for e in range(E):
+                assert np.array_equal(ram[e], orc.ram(e)), 'ram env %d step %d' % (e, i)
+        ln = info['episode_lengths'].cpu().numpy()
+        rt = info['episode_returns'].cpu().numpy()
+        for e in range(E):
+            eps = orc.pop_episodes(e)
+            if eps:
+                assert (rt[e], ln[e]) == (eps[-1][0], eps[-1][1])
+            else:
+                assert ln[e] == 0
+        ndone += int(od.sum())
+    env.check_faults()
+    return ndone
+
+
+@pytest.mark.parametrize('game,dim', [('pong', 84), ('pong', 42), ('breakout', 84), ('breakout', 42)])
+def test_env_matches_oracle(dev, oracle, game, dim):
+    nd = _run_parity(dev, oracle, game, E=6, dim=dim, steps=160, seed=3)
+    if game == 'breakout':
+        assert nd > 0  # life losses / FIRE resets were exercised
+
+
+def test_env_matches_oracle_timelimit_no_cache(dev, oracle):
+    """TimeLimit + the never-reset CompatWrapper counter + the general (uncached) reset path"""
+    assert _run_parity(dev, oracle, 'breakout', E=4, dim=42, steps=260, seed=8, max_episode_steps=600, cache=False) > 0
+    assert _run_parity(dev, oracle, 'pong', E=4, dim=42, steps=200, seed=9, max_episode_steps=500, cache=True) > 0
+
+
+def test_env_many_envs_ragged_block(dev, oracle):
+    """E not a multiple of the 4 envs per workgroup; more envs than one wave per SIMD"""
+    _run_parity(dev, oracle, 'pong', E=13, dim=42, steps=24, seed=21, check_ram=False)
+
+
+def test_frame_post_rgb_and_colour_paths(dev, oracle):
+    """frame_post on synthetic frames (SURVEY §8d 'frames' row): RGB input (the WarpFrame boundary)
+    and TIA-colour input agree with the oracle bit-exactly, with and without the max."""
+    import ctypes
+    from parl_amd import _native as N
+    rng = np.random.default_rng(0)
+    E = 5
+    L = N.lib()
+    for dim in (84, 42):
+        nb = L.parlhip_frame_post_tables_bytes(dim)
+        blob = np.zeros(nb, np.uint8)
+        N.check(L.parlhip_frame_post_tables_init(blob.ctypes.data, dim), 'tables')
+        tab = torch.from_numpy(blob).to(dev)
+        blocks = rng.integers(0, 128, (E, 2, 27, 20)).astype(np.uint8) * 2  # 8x8 blocks of palette colours
+        col = np.repeat(np.repeat(blocks, 8, 2), 8, 3)[:, :, :210, :160].copy()
+        col[:, :, 100:116, 40:44] = 0x0e  # a "paddle"
+        pal = (ctypes.c_uint32 * 128)()
+        oracle.lib().oracle_palette(pal)
+        p = np.frombuffer(pal, np.uint32)
+        rgbpal = np.stack([(p >> 16) & 255, (p >> 8) & 255, p & 255], -1).astype(np.uint8)
+        rgb = rgbpal[col >> 1]  # [E,2,210,160,3]
+        for two in (True, False):
+            for fmt, src in ((1, col), (0, rgb)):
+                f = torch.from_numpy(np.ascontiguousarray(src)).to(dev)
+                per = f[0, 0].numel()
+                out = torch.zeros((E, dim * dim), dtype=torch.uint8, device=dev)
+                N.check(
+                    L.parlhip_frame_post_u8(f.data_ptr(), (f.data_ptr() + per) if two else None, 2 * per, fmt, None,
+                                            out.data_ptr(), dim * dim, E, dim, tab.data_ptr(), N.stream_ptr()),
+                    'frame_post')
+                ref = oracle.frame_post(src[:, 0], src[:, 1] if two else None, dim, fmt)
+                assert np.array_equal(out.cpu().numpy().reshape(E, dim, dim), ref), (dim, two, fmt)
+
+
+def test_stack_ring_matches_framestack_semantics(dev):
+    """FrameStack.reset fills 4x the first frame (atari_wrappers.py:290-294); the ring reconstructs
+    stacks by index from single frames."""
+    from parl_amd.env import DeviceVectorEnv
+    env = DeviceVectorEnv('PongNoFrameskip-v4', 3, dim=42, horizon=6, seed=1, device=dev, rom_bytes=_rom('pong'))
+    o = env.reset()
+    assert all(torch.equal(o[:, 0], o[:, j]) for j in range(1, 4))
+    prev = o
+    for i in range(5):
+        o, r, d, _ = env.step(torch.zeros(3, dtype=torch.int64, device=dev))
+        assert torch.equal(o[:, :3], prev[:, 1:])  # shift by one frame when no reset happened
+        prev = o
+    env.roll()
+    assert torch.equal(env.current_obs(), prev)  # rolling the ring keeps the history
