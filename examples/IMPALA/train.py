@@ -1,0 +1,179 @@
+"""IMPALA learner — the structure of examples/IMPALA/train.py:34-258 (Learner with a sample
+queue, a learn thread, actor threads, schedulers, WindowStat metrics) on the device path.
+
+    python examples/IMPALA/train.py [--updates N] [--env-num E] [--minutes M]
+
+The reference file imports paddle (`paddle.io.DataLoader.from_generator`, train.py:129-130); this
+twin feeds `agent.learn` directly from the queue."""
+import argparse
+import os
+import queue
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import parl_amd as parl  # noqa: E402
+from actor import Actor  # noqa: E402
+from atari_agent import AtariAgent  # noqa: E402
+from atari_model import AtariModel  # noqa: E402
+from parl_amd.env import GAMES  # noqa: E402
+from parl_amd.utils import logger, summary  # noqa: E402
+from parl_amd.utils.scheduler import PiecewiseScheduler  # noqa: E402
+from parl_amd.utils.time_stat import TimeStat  # noqa: E402
+from parl_amd.utils.window_stat import WindowStat  # noqa: E402
+
+
+class Learner(object):
+    def __init__(self, config):
+        self.config = config
+        self.sample_data_queue = queue.Queue(maxsize=config['sample_queue_max_size'])
+        self.device = torch.device('cuda')
+        act_dim = 6 if GAMES[config['env_name']][0] == 'pong' else 4
+
+        model = AtariModel(act_dim)
+        algorithm = parl.algorithms.IMPALA(
+            model, sample_batch_steps=config['sample_batch_steps'], gamma=config['gamma'],
+            vf_loss_coeff=config['vf_loss_coeff'], clip_rho_threshold=config['clip_rho_threshold'],
+            clip_pg_rho_threshold=config['clip_pg_rho_threshold'])
+        self.agent = AtariAgent(algorithm, device=self.device)
+
+        self.lr, self.entropy_coeff = None, None
+        self.lr_scheduler = PiecewiseScheduler(config['lr_scheduler'])
+        self.entropy_coeff_scheduler = PiecewiseScheduler(config['entropy_coeff_scheduler'])
+        self.total_loss_stat = WindowStat(100)
+        self.pi_loss_stat = WindowStat(100)
+        self.vf_loss_stat = WindowStat(100)
+        self.entropy_stat = WindowStat(100)
+        self.kl_stat = WindowStat(100)
+        self.learn_time_stat = TimeStat(100)
+        self.start_time = None
+        self.learn_steps = 0
+        self.sample_total_steps = 0
+        self.remote_metrics_queue = queue.Queue()
+        self.stop = False
+
+        self.learn_thread = threading.Thread(target=self.run_learn, daemon=True)
+        self.learn_thread.start()
+        self.create_actors()
+
+    # ------------------------------------------------------------------ learner side
+    def run_learn(self):
+        T = self.config['sample_batch_steps']
+        seqs = max(1, self.config['train_batch_size'] // T)
+        while not self.stop:
+            try:
+                batch = self.sample_data_queue.get(timeout=0.5)
+            except queue.Empty:
+                continue
+            E = batch['actions'].numel() // T
+            view = lambda k: batch[k].reshape((T, E) + tuple(batch[k].shape[1:]))  # noqa: E731
+            obs, act, bl, rew, done = [view(k) for k in ('obs', 'actions', 'behaviour_logits', 'rewards', 'dones')]
+            for e0 in range(0, E, seqs):  # train_batch_size rows per update, whole sequences
+                sl = slice(e0, min(E, e0 + seqs))
+                self.lr = self.lr_scheduler.step()
+                self.entropy_coeff = self.entropy_coeff_scheduler.step()
+                flat = lambda t: t[:, sl].reshape((-1, ) + tuple(t.shape[2:]))  # noqa: E731
+                with self.learn_time_stat:
+                    total_loss, pi_loss, vf_loss, entropy, kl = self.agent.learn(
+                        flat(obs), flat(act), flat(bl), flat(rew), flat(done), self.lr, self.entropy_coeff,
+                        time_major=True)
+                self.learn_steps += 1
+                self.total_loss_stat.add(total_loss)
+                self.pi_loss_stat.add(pi_loss)
+                self.vf_loss_stat.add(vf_loss)
+                self.entropy_stat.add(entropy)
+                self.kl_stat.add(kl)
+            self.sample_total_steps += T * E
+            self.consumed.set()
+
+    # ------------------------------------------------------------------ actor side
+    def create_actors(self):
+        parl.connect(self.config['master_address'])
+        self.consumed = threading.Event()
+        self.consumed.set()
+        self.actors = []
+        for i in range(self.config['actor_num']):
+            if self.start_time is None:
+                self.start_time = time.time()
+            t = threading.Thread(target=self.run_remote_sample, args=(i, ), daemon=True)
+            t.start()
+
+    def run_remote_sample(self, actor_id):
+        remote_actor = Actor(self.config, actor_id, model=self.agent.alg.model, device=self.device)
+        cnt = 0
+        while not self.stop:
+            # the rollout buffers are reused: wait until the learner has consumed the previous batch
+            self.consumed.wait()
+            self.consumed.clear()
+            batch = remote_actor.sample().get()
+            self.sample_data_queue.put(batch)
+            cnt += 1
+            if cnt % self.config['get_remote_metrics_interval'] == 0:
+                metrics = remote_actor.get_metrics().get()
+                if metrics:
+                    self.remote_metrics_queue.put(metrics)
+
+    # ------------------------------------------------------------------ logging (train.py:196-247)
+    def log_metrics(self):
+        if self.start_time is None:
+            return None
+        rewards, steps = [], []
+        while True:
+            try:
+                m = self.remote_metrics_queue.get_nowait()
+            except queue.Empty:
+                break
+            rewards += m['episode_rewards']
+            steps += m['episode_steps']
+        elapsed = time.time() - self.start_time
+        metric = {
+            'sample_steps': self.sample_total_steps,
+            'mean_episode_rewards': float(np.mean(rewards)) if rewards else None,
+            'mean_episode_steps': float(np.mean(steps)) if steps else None,
+            'episodes': len(rewards),
+            'learn_steps': self.learn_steps,
+            'total_loss': self.total_loss_stat.mean,
+            'pi_loss': self.pi_loss_stat.mean,
+            'vf_loss': self.vf_loss_stat.mean,
+            'entropy': self.entropy_stat.mean,
+            'kl': self.kl_stat.mean,
+            'learn_time_s': self.learn_time_stat.mean,
+            'elapsed_time_s': int(elapsed),
+            'env_frames_per_s': 4 * self.sample_total_steps / max(elapsed, 1e-9),
+            'lr': self.lr,
+            'entropy_coeff': self.entropy_coeff,
+        }
+        for key, value in metric.items():
+            if value is not None:
+                summary.add_scalar(key, value, self.sample_total_steps)
+        logger.info(metric)
+        return metric
+
+
+if __name__ == '__main__':
+    from impala_config import config
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--minutes', type=float, default=None, help='stop after this many minutes')
+    ap.add_argument('--env-num', type=int, default=None)
+    ap.add_argument('--train-batch-size', type=int, default=None)
+    ap.add_argument('--log-interval', type=float, default=None)
+    args = ap.parse_args()
+    if args.env_num:
+        config['env_num'] = args.env_num
+    if args.train_batch_size:
+        config['train_batch_size'] = args.train_batch_size
+    if args.log_interval:
+        config['log_metrics_interval_s'] = args.log_interval
+    learner = Learner(config)
+    assert config['log_metrics_interval_s'] > 0
+    t0 = time.time()
+    while args.minutes is None or time.time() - t0 < args.minutes * 60:
+        time.sleep(config['log_metrics_interval_s'])
+        learner.log_metrics()
+    learner.stop = True
