@@ -74,3 +74,63 @@ class DeviceRollout(object):
         self.ep_return_sum.zero_()
         self.ep_length_sum.zero_()
         return n, (r / n if n else None), (l / n if n else None)
+
+
+class DeviceA2CRollout(object):
+    """On-device A2C actor: the work of examples/A2C/actor.py:51-101 (Actor.sample) for E envs.
+
+    Reference flow: per step agent.sample (probs + values to the host, np.random.choice per env) ->
+    vector_env.step; whenever an env finishes an episode or the rollout ends, a batch-1 value
+    forward for its next obs and calc_gae on that (env, segment) (actor.py:73-85).
+    Here: policy_and_value forward -> ops.policy_sample -> DeviceVectorEnv.step_async for T steps,
+    ONE batched value forward for the bootstrap of all envs, and ONE ops.gae launch over the
+    [T,E] slabs whose done mask reproduces the per-segment semantics (next_value = 0 after a
+    terminal step, carry reset).  Rows come out time-major; A2C's losses are sums (a2c.py:67-79),
+    so the order is immaterial."""
+
+    def __init__(self, env, sample_batch_steps, gamma, lam, seed=0):
+        assert env.horizon >= sample_batch_steps, 'env ring too short for the rollout'
+        self.env, self.T, self.seed = env, int(sample_batch_steps), int(seed)
+        self.gamma, self.lam = float(gamma), float(lam)
+        E, dev, T = env.envs_num, env.device, self.T
+        self.actions = torch.zeros((T, E), dtype=torch.int64, device=dev)
+        self.values = torch.zeros((T, E), dtype=torch.float32, device=dev)
+        self.rewards = torch.zeros((T, E), dtype=torch.float32, device=dev)
+        self.dones = torch.zeros((T, E), dtype=torch.uint8, device=dev)
+        self.obs = torch.zeros((T * E, 4, env.dim, env.dim), dtype=torch.uint8, device=dev)
+        self._obs_step = torch.zeros((E, 4, env.dim, env.dim), dtype=torch.uint8, device=dev)
+        self._slots = (torch.arange(T, dtype=torch.int32, device=dev) + 3).repeat_interleave(E)
+        self._envs = torch.arange(E, dtype=torch.int32, device=dev).repeat(T)
+        self.step_count = 0
+        self.ep_count = torch.zeros((), dtype=torch.float64, device=dev)
+        self.ep_return_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.ep_length_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.started = False
+
+    @torch.no_grad()
+    def collect(self, model):
+        env = self.env
+        if not self.started:
+            env.reset()
+            self.started = True
+        else:
+            env.roll()
+        for t in range(self.T):
+            obs = env.current_obs(self._obs_step)
+            logits, values = model.policy_and_value(obs)
+            self.values[t].copy_(values)
+            ops.policy_sample_into(logits, self.actions[t], self.seed, self.step_count, env.env_id0)
+            env.step_async(self.actions[t], self.rewards[t], self.dones[t])
+            closed = env.ep_lengths > 0
+            self.ep_count += closed.sum()
+            self.ep_return_sum += (env.ep_returns * closed).sum()
+            self.ep_length_sum += (env.ep_lengths * closed).sum()
+            self.step_count += 1
+        next_value = model.value(env.current_obs(self._obs_step))  # ignored where the last step was terminal
+        adv, target = ops.gae(self.rewards, self.values, self.dones, next_value, self.gamma, self.lam)
+        env.gather(self._slots, self._envs, self.obs)
+        n = self.T * env.envs_num
+        return {'obs': self.obs, 'actions': self.actions.reshape(n), 'advantages': adv.reshape(n),
+                'target_values': target.reshape(n)}
+
+    pop_episode_stats = DeviceRollout.pop_episode_stats

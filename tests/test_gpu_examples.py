@@ -1,0 +1,75 @@
+"""The example twins (examples/IMPALA, examples/A2C) run end to end on the device path, and the
+on-device A2C rollout reproduces the reference's per-segment calc_gae semantics.  -m gpu."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, timeout=240):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=timeout, text=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    return p.stdout
+
+
+def test_a2c_example_runs():
+    out = _run(['examples/A2C/train.py', '--max_sample_steps', '1600', '--env-num', '16', '--log-interval', '1'])
+    assert "'sample_steps': " in out and "'total_loss': " in out
+
+
+def test_impala_example_runs():
+    out = _run(['examples/IMPALA/train.py', '--minutes', '0.2', '--env-num', '16', '--train-batch-size', '400',
+                '--log-interval', '3'])
+    assert "'learn_steps': " in out and "'kl': " in out
+
+
+def test_a2c_rollout_matches_per_segment_calc_gae(dev, oracle):
+    """DeviceA2CRollout's one batched GAE launch == the reference's per-(env, segment) calc_gae with
+    next_value = 0 after a terminal step (examples/A2C/actor.py:73-85), on a real Breakout rollout
+    (life losses give mid-rollout dones)."""
+    import parl_amd as parl
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel84
+    from parl_amd.rollout import DeviceA2CRollout
+    torch.manual_seed(0)
+    E, T = 12, 40
+    env = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=84, horizon=T, seed=4, device=dev)
+    model = AtariModel84(env.act_dim).to(dev)
+    ro = DeviceA2CRollout(env, T, gamma=0.99, lam=0.95, seed=2)
+    for _ in range(3):  # a few rollouts so that some envs lose lives
+        b = ro.collect(model)
+    rew, val, done = ro.rewards.cpu().numpy(), ro.values.cpu().numpy(), ro.dones.cpu().numpy()
+    with torch.no_grad():
+        nv = model.value(env.current_obs()).cpu().numpy()
+    adv = b['advantages'].reshape(T, E).cpu().numpy()
+    tgt = b['target_values'].reshape(T, E).cpu().numpy()
+    assert done.sum() > 0
+    # float64 restatement of calc_gae per segment (rl_utils.py:34-51)
+    for e in range(E):
+        start = 0
+        for t in range(T):
+            if done[t, e] or t == T - 1:
+                r, v = rew[start:t + 1, e].astype(np.float64), val[start:t + 1, e].astype(np.float64)
+                nxt = 0.0 if done[t, e] else float(nv[e])
+                td = r + 0.99 * np.append(v[1:], nxt) - v
+                a = np.zeros_like(td)
+                acc = 0.0
+                for i in range(len(td) - 1, -1, -1):
+                    acc = td[i] + 0.99 * 0.95 * acc
+                    a[i] = acc
+                np.testing.assert_allclose(adv[start:t + 1, e], a, rtol=1e-5, atol=1e-5)
+                np.testing.assert_allclose(tgt[start:t + 1, e], a + v, rtol=1e-5, atol=1e-5)
+                start = t + 1
+    # the learner consumes it
+    alg = parl.algorithms.A2C(model, vf_loss_coeff=0.5)
+    total, pi, vf, ent = alg.learn(b['obs'], b['actions'], b['advantages'], b['target_values'], 1e-4, -0.01)
+    assert np.isfinite(float(total))
