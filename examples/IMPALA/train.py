@@ -103,6 +103,15 @@ class Learner(object):
                 self.start_time = time.time()
             t = threading.Thread(target=self.run_remote_sample, args=(i, ), daemon=True)
             t.start()
+            self.actors.append(t)
+
+    def shutdown(self):
+        """stop the actor / learner threads and wait for in-flight GPU work"""
+        self.stop = True
+        self.consumed.set()
+        for t in self.actors + [self.learn_thread]:
+            t.join(timeout=30)
+        torch.cuda.synchronize()
 
     def run_remote_sample(self, actor_id):
         remote_actor = Actor(self.config, actor_id, model=self.agent.alg.model, device=self.device)
@@ -176,4 +185,6 @@ if __name__ == '__main__':
     while args.minutes is None or time.time() - t0 < args.minutes * 60:
         time.sleep(config['log_metrics_interval_s'])
         learner.log_metrics()
-    learner.stop = True
+    learner.shutdown()
+    sys.stdout.flush()
+    os._exit(0)  # daemon proxy threads (parl_amd.remote) never return; skip interpreter teardown

@@ -113,6 +113,19 @@ int parlhip_gae_f32(const float* rewards, const float* values, const void* dones
                     float lam, int done_convention, int dones_are_f32,
                     parlhip_stream_t stream);
 
+/* Same arithmetic with a caller workspace, for long rollouts over few sequences (PPO: T=2048,
+ * E=4096, examples/PPO/storage.py:45-64): T is cut into chunks that run in parallel (affine
+ * recurrence: chunk aggregates, serial combine over chunks, final pass seeded with the exact-order
+ * recurrence inside each chunk).  parlhip_gae_workspace_bytes() returns 0 when the single-pass
+ * kernel is the better plan for (T, B); parlhip_gae_ws_f32 then forwards to parlhip_gae_f32 and
+ * workspace may be NULL.  Results agree with parlhip_gae_f32 to fp32 re-association (<=1e-6 rel). */
+size_t parlhip_gae_workspace_bytes(int T, int B);
+int parlhip_gae_ws_f32(const float* rewards, const float* values, const void* dones,
+                       const float* next_value, const void* last_done, float* advantages,
+                       float* returns, int T, int B, float gamma, float lam, int done_convention,
+                       int dones_are_f32, void* workspace, size_t workspace_bytes,
+                       parlhip_stream_t stream);
+
 /* calc_discount_sum_rewards (parl/utils/rl_utils.py:21-31), batched: x [T,B] float32,
  * out[t] = x[t] + gamma*out[t+1]; optional uint8 dones [T,B] reset the carry after a
  * terminal step (NULL = plain lfilter semantics).                                       */

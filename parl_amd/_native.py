@@ -36,6 +36,8 @@ SIGNATURES = {
     'parlhip_vtrace_from_logits_f32':
     (_i, [_p] * 10 + [_i, _i, _i, _i, _f, _f, _f, _p]),
     'parlhip_gae_f32': (_i, [_p] * 7 + [_i, _i, _f, _f, _i, _i, _p]),
+    'parlhip_gae_workspace_bytes': (_sz, [_i, _i]),
+    'parlhip_gae_ws_f32': (_i, [_p] * 7 + [_i, _i, _f, _f, _i, _i, _p, _sz, _p]),
     'parlhip_discount_cumsum_f32': (_i, [_p, _p, _p, _i, _i, _f, _p]),
     'parlhip_adv_normalize_workspace_bytes': (_sz, [_i64]),
     'parlhip_adv_normalize_f32': (_i, [_p, _p, _p, _i64, _f, _p, _sz, _p, _p]),

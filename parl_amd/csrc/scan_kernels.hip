@@ -454,6 +454,109 @@ __global__ __launch_bounds__(256) void gae_tm_kernel(
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// GAE for long T / small B (PPO config: T=2048, B=4096 -> only 64 lane-per-sequence waves, each
+// a chain of 2048 dependent steps: latency-bound at ~0.8 TB/s).  The recurrence
+//   adv_t = d_t + a_t * adv_{t+1}
+// is affine, so T is cut into C chunks that run in parallel (grid.y = chunk):
+//   pass 0 (MODE_AGG)   per (chunk, b): A = prod a_t, D = chunk-local suffix value at its first step
+//   combine             per b, serial over C chunks: carry_in[c] = adv at the first step of chunk c+1
+//   pass 1 (MODE_FINAL) the ordinary sequential recurrence inside the chunk, seeded with carry_in
+// Traffic: inputs are read twice (12 B/elt; the second read of a <=256 MB working set is served
+// by the Infinity Cache), outputs written once.  Results differ from the single-pass kernel only by
+// fp32 re-association of the carry (<= 1e-6 relative), within the 1e-5 contract.
+// ----------------------------------------------------------------------------------------
+enum : int { MODE_AGG = 0, MODE_FINAL = 1 };
+
+template <bool DONE_F32, int CONV, int MODE>
+__global__ __launch_bounds__(256) void gae_chunk_kernel(
+    const float* __restrict__ rew, const float* __restrict__ val,
+    const void* __restrict__ dones_v, const float* __restrict__ next_value,
+    const void* __restrict__ last_done_v, float* __restrict__ adv, float* __restrict__ ret,
+    int T, int B, float gamma, float gl, int L, float* __restrict__ wsA,
+    float* __restrict__ wsD, const float* __restrict__ carry_in) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int c = blockIdx.y;
+  const int t0 = c * L;
+  const int t1 = (t0 + L < T) ? t0 + L : T;
+  if (t0 >= T) return;
+  const float* dones_f = (const float*)dones_v;
+  const uint8_t* dones_u = (const uint8_t*)dones_v;
+  auto done_at = [&](int64_t i) -> float { return DONE_F32 ? dones_f[i] : (float)dones_u[i]; };
+  float v_next, nnt_next = 1.f;
+  if (t1 == T) {
+    v_next = next_value[b];
+    if (CONV == PARLHIP_GAE_DONE_STARTS_STEP)
+      nnt_next = 1.0f - (DONE_F32 ? ((const float*)last_done_v)[b] : (float)((const uint8_t*)last_done_v)[b]);
+  } else {
+    v_next = val[(int64_t)t1 * B + b];
+    if (CONV == PARLHIP_GAE_DONE_STARTS_STEP) nnt_next = 1.0f - done_at((int64_t)t1 * B + b);
+  }
+  float carry = (MODE == MODE_FINAL) ? carry_in[(int64_t)c * B + b] : 0.f;
+  float Aprod = 1.f;
+  constexpr int U = 8;
+  for (int t = t1 - 1; t >= t0; t -= U) {
+    float lr[U], lv[U], ld[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (t - u < t0) continue;
+      const int64_t i = (int64_t)(t - u) * B + b;
+      lr[u] = rew[i];
+      lv[u] = val[i];
+      ld[u] = done_at(i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (t - u < t0) continue;
+      const int64_t i = (int64_t)(t - u) * B + b;
+      const float r = lr[u], v = lv[u];
+      float a, d;
+      if (CONV == PARLHIP_GAE_DONE_ENDS_STEP) {
+        const bool done = ld[u] != 0.f;
+        const float nv = done ? 0.f : v_next;
+        d = r + gamma * nv - v;
+        a = done ? 0.f : gl;
+      } else {
+        const float nnt = nnt_next;
+        d = r + gamma * v_next * nnt - v;
+        a = gl * nnt;
+        nnt_next = 1.0f - ld[u];
+      }
+      if (MODE == MODE_FINAL) {
+        // same expression shapes as gae_tm_kernel: done ? td : td + gl*carry  /  delta + gl*nnt*carry
+        if (CONV == PARLHIP_GAE_DONE_ENDS_STEP) carry = (a == 0.f) ? d : d + gl * carry;
+        else carry = d + a * carry;
+        if (adv) adv[i] = carry;
+        if (ret) ret[i] = carry + v;
+      } else {
+        carry = d + a * carry;
+        Aprod = a * Aprod;
+      }
+      v_next = v;
+    }
+  }
+  if (MODE == MODE_AGG) {
+    wsA[(int64_t)c * B + b] = Aprod;
+    wsD[(int64_t)c * B + b] = carry;
+  }
+}
+
+// carry_in[c] = adv at the first step of chunk c+1 (0 for the last chunk), serial over chunks
+__global__ __launch_bounds__(256) void gae_chunk_combine_kernel(const float* __restrict__ wsA,
+                                                                const float* __restrict__ wsD,
+                                                                float* __restrict__ carry_in, int C,
+                                                                int B) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float x = 0.f;
+  for (int c = C - 1; c >= 0; --c) {
+    const int64_t i = (int64_t)c * B + b;
+    carry_in[i] = x;
+    x = wsD[i] + wsA[i] * x;
+  }
+}
+
 template <int VEC, int U>
 __global__ __launch_bounds__(256) void discount_cumsum_kernel(
     const float* __restrict__ x, const uint8_t* __restrict__ dones,
@@ -690,6 +793,78 @@ PARLHIP_EXPORT int parlhip_gae_f32(const float* rew, const float* val, const voi
                                                                 last_done, adv, ret, T, B, gamma, gl, s)
                : launch_gae<false, PARLHIP_GAE_DONE_STARTS_STEP>(rew, val, dones, next_value,
                                                                  last_done, adv, ret, T, B, gamma, gl, s);
+  }
+  return PARLHIP_EINVAL;
+}
+
+// Chunk plan for the long-T / small-B path: 0 chunks = stay on the single-pass kernel.
+static inline void gae_chunk_plan(int T, int B, int* C_out, int* L_out) {
+  *C_out = 0; *L_out = 0;
+  const int waves = ceil_div(B, 64);
+  if (T < 256 || waves >= 1024) return;
+  int C = ceil_div(2048, waves);           // aim for >= 2048 waves (8 per CU) in flight
+  const int maxC = T / 32;                 // chunks of at least 32 steps
+  if (C > maxC) C = maxC;
+  if (C < 2) return;
+  int L = ceil_div(T, C);
+  L = (L + 7) & ~7;
+  *C_out = ceil_div(T, L);
+  *L_out = L;
+}
+
+PARLHIP_EXPORT size_t parlhip_gae_workspace_bytes(int T, int B) {
+  int C, L;
+  if (T <= 0 || B <= 0) return 0;
+  gae_chunk_plan(T, B, &C, &L);
+  return (size_t)3 * (size_t)C * (size_t)B * sizeof(float);
+}
+
+template <bool DONE_F32, int CONV>
+static int launch_gae_chunked(const float* rew, const float* val, const void* dones,
+                              const float* next_value, const void* last_done, float* adv, float* ret,
+                              int T, int B, float gamma, float gl, int C, int L, float* ws,
+                              hipStream_t s) {
+  float* wsA = ws;
+  float* wsD = ws + (size_t)C * B;
+  float* carry = ws + (size_t)2 * C * B;
+  const int block = B >= 256 ? 256 : 64;
+  dim3 grid(ceil_div(B, block), C);
+  gae_chunk_kernel<DONE_F32, CONV, MODE_AGG><<<grid, block, 0, s>>>(
+      rew, val, dones, next_value, last_done, nullptr, nullptr, T, B, gamma, gl, L, wsA, wsD, nullptr);
+  gae_chunk_combine_kernel<<<ceil_div(B, block), block, 0, s>>>(wsA, wsD, carry, C, B);
+  gae_chunk_kernel<DONE_F32, CONV, MODE_FINAL><<<grid, block, 0, s>>>(
+      rew, val, dones, next_value, last_done, adv, ret, T, B, gamma, gl, L, nullptr, nullptr, carry);
+  return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_gae_ws_f32(const float* rew, const float* val, const void* dones,
+                                  const float* next_value, const void* last_done, float* adv,
+                                  float* ret, int T, int B, float gamma, float lam,
+                                  int done_convention, int dones_are_f32, void* workspace,
+                                  size_t workspace_bytes, parlhip_stream_t stream) {
+  int C = 0, L = 0;
+  if (T > 0 && B > 0) gae_chunk_plan(T, B, &C, &L);
+  if (C == 0)
+    return parlhip_gae_f32(rew, val, dones, next_value, last_done, adv, ret, T, B, gamma, lam,
+                           done_convention, dones_are_f32, stream);
+  if (!rew || !val || !dones || !next_value || (!adv && !ret)) return PARLHIP_EINVAL;
+  if (!workspace || workspace_bytes < (size_t)3 * C * B * sizeof(float)) return PARLHIP_ENOMEM;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  if (done_convention == PARLHIP_GAE_DONE_ENDS_STEP) {
+    const float gl = gamma * lam;
+    return dones_are_f32 ? launch_gae_chunked<true, PARLHIP_GAE_DONE_ENDS_STEP>(
+                               rew, val, dones, next_value, nullptr, adv, ret, T, B, gamma, gl, C, L, ws, s)
+                         : launch_gae_chunked<false, PARLHIP_GAE_DONE_ENDS_STEP>(
+                               rew, val, dones, next_value, nullptr, adv, ret, T, B, gamma, gl, C, L, ws, s);
+  }
+  if (done_convention == PARLHIP_GAE_DONE_STARTS_STEP) {
+    if (!last_done) return PARLHIP_EINVAL;
+    const float gl = (float)((double)gamma * (double)lam);
+    return dones_are_f32 ? launch_gae_chunked<true, PARLHIP_GAE_DONE_STARTS_STEP>(
+                               rew, val, dones, next_value, last_done, adv, ret, T, B, gamma, gl, C, L, ws, s)
+                         : launch_gae_chunked<false, PARLHIP_GAE_DONE_STARTS_STEP>(
+                               rew, val, dones, next_value, last_done, adv, ret, T, B, gamma, gl, C, L, ws, s);
   }
   return PARLHIP_EINVAL;
 }

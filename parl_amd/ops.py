@@ -93,12 +93,14 @@ GAE_DONE_STARTS_STEP = 1
 
 
 def gae(rewards, values, dones, next_value, gamma, lam, last_done=None,
-        done_convention=GAE_DONE_ENDS_STEP):
+        done_convention=GAE_DONE_ENDS_STEP, allow_chunked=True):
     """Batched calc_gae (rl_utils.py:34-51 with examples/A2C/actor.py:73-85 segments) or
     RolloutStorage.compute_returns (examples/PPO/storage.py:45-64).
 
     rewards/values [T,B] f32, dones [T,B] bool/uint8/float32, next_value [B].
-    Returns (advantages, returns) with returns = advantages + values."""
+    Returns (advantages, returns) with returns = advantages + values.
+    allow_chunked=False forces the single-pass kernel (bit-exact fp32 op order of numpy in the
+    PPO convention); the chunk-parallel plan is chosen automatically for long T over few sequences."""
     rew = _f32(rewards, 'rewards')
     val = _f32(values, 'values')
     nv = _f32(next_value, 'next_value').reshape(-1)
@@ -117,6 +119,15 @@ def gae(rewards, values, dones, next_value, gamma, lam, last_done=None,
             raise N.ParlHipError('last_done must have the dtype of dones')
     adv = torch.empty_like(val)
     ret = torch.empty_like(val)
+    wsb = N.lib().parlhip_gae_workspace_bytes(T, B) if allow_chunked else 0
+    if wsb:  # long T over few sequences (PPO storage shape): chunk-parallel plan
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=val.device)
+        N.check(
+            N.lib().parlhip_gae_ws_f32(
+                N.ptr(rew), N.ptr(val), N.ptr(dones), N.ptr(nv), N.ptr(last_done),
+                N.ptr(adv), N.ptr(ret), T, B, float(gamma), float(lam), int(done_convention),
+                1 if is_f32 else 0, N.ptr(ws), wsb, N.stream_ptr()), 'parlhip_gae_ws_f32')
+        return adv, ret
     N.check(
         N.lib().parlhip_gae_f32(
             N.ptr(rew), N.ptr(val), N.ptr(dones), N.ptr(nv), N.ptr(last_done),

@@ -150,7 +150,8 @@ def test_gae_ppo_golden_bit_exact(dev, case):
     np.testing.assert_array_equal(ret.cpu().numpy(), g['returns'])
 
 
-@pytest.mark.parametrize('T,B', [(20, 256), (20, 5), (1, 1), (128, 1031), (33, 131072), (2048, 4096)])
+@pytest.mark.parametrize('T,B', [(20, 256), (20, 5), (1, 1), (128, 1031), (33, 131072), (2048, 4096), (300, 77),
+                                 (1000, 5000)])
 @pytest.mark.parametrize('conv,f32', [(0, False), (1, True), (1, False), (0, True)])
 def test_gae_vs_oracle(dev, oracle, T, B, conv, f32):
     from parl_amd import ops
@@ -165,7 +166,16 @@ def test_gae_vs_oracle(dev, oracle, T, B, conv, f32):
     adv, ret = ops.gae(T_(rew, dev), T_(val, dev), T_(dones, dev), T_(nv, dev), 0.99, 0.95,
                        last_done=T_(last, dev) if conv else None, done_convention=conv)
     oadv, oret = oracle.gae(rew, val, dones, nv, 0.99, 0.95, last_done=last if conv else None, done_convention=conv)
-    if conv == 1:  # same float32 op order on both sides
+    from parl_amd import _native as N
+    chunked = N.lib().parlhip_gae_workspace_bytes(T, B) > 0
+    if conv == 1 and chunked:
+        # chunk-parallel plan (long T, few sequences): fp32 re-association of the carry only;
+        # the single-pass kernel keeps numpy's op order bit-exactly on the same inputs
+        a1, r1 = ops.gae(T_(rew, dev), T_(val, dev), T_(dones, dev), T_(nv, dev), 0.99, 0.95,
+                         last_done=T_(last, dev), done_convention=conv, allow_chunked=False)
+        np.testing.assert_array_equal(a1.cpu().numpy(), oadv)
+        np.testing.assert_array_equal(r1.cpu().numpy(), oret)
+    if conv == 1 and not chunked:  # same float32 op order on both sides
         np.testing.assert_array_equal(adv.cpu().numpy(), oadv)
         np.testing.assert_array_equal(ret.cpu().numpy(), oret)
     else:
