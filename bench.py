@@ -64,6 +64,19 @@ class KernelTimer(object):
         return sum(s.elapsed_time(e) for s, e in self.pairs) * 1e-3 / len(self.pairs)
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 PMC measurement of the same kernel and
+    shape (profiles/r01_scan_hbm_traffic.json, produced by tools/prof_traffic.sh: separate
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction).  bench.py cannot run under two
+    rocprofv3 passes itself; the source file is named next to the number."""
+    path = os.path.join(ROOT, 'profiles', 'r01_scan_hbm_traffic.json')
+    try:
+        t = json.load(open(path))[key]
+        return {'traffic': t['hbm_traffic_bytes'], 'traffic_source': 'profiles/r01_scan_hbm_traffic.json:' + key}
+    except (OSError, KeyError, ValueError):
+        return {'traffic': None}
+
+
 def cpu_baseline(game, dim, seconds_target=12.0):
     """The CPU oracle (a port, 'kind': 'port') stepping the same env chain on host cores."""
     from concurrent.futures import ThreadPoolExecutor
@@ -139,6 +152,8 @@ def main():
     ops.vtrace_from_logits = vt_timer.wrap(ops.vtrace_from_logits)
     env_timer = KernelTimer()
     env.step_async = env_timer.wrap(env.step_async)
+    fp_timer = KernelTimer()
+    env._frame_post = fp_timer.wrap(env._frame_post)
 
     def step():
         batch = rollout.collect(model)
@@ -152,7 +167,7 @@ def main():
         step()
     pdist.barrier()
     torch.cuda.synchronize()
-    vt_timer.enabled = env_timer.enabled = True
+    vt_timer.enabled = env_timer.enabled = fp_timer.enabled = True
     t0 = time.time()
     for _ in range(args.steps):
         loss = step()
@@ -212,11 +227,20 @@ def main():
         torch.cuda.synchronize()
         bys = Ts * Bs * 28 + 4 * Bs
         out['roofline_saturating'] = {
-            'kernel': 'vtrace_tm_kernel<4,4> (from log-probs, T=127 B=262144)', 'bound': 'hbm',
+            'kernel': 'vtrace_tm_kernel (from log-probs, lane per sequence, T=127 B=262144: the saturating shape '
+                      'of SURVEY 8d)', 'bound': 'hbm',
             'achieved': bys / sat.mean_seconds() / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-            'frac': bys / sat.mean_seconds() / 1e9 / HBM_PEAK_GBPS, 'traffic': None, 'bytes_per_launch': bys,
+            'frac': bys / sat.mean_seconds() / 1e9 / HBM_PEAK_GBPS, 'bytes_per_launch': bys,
         }
+        out['roofline_saturating'].update(pmc_traffic('vtrace_T127_B262144'))
         del x
+        fps = fp_timer.mean_seconds()
+        fpb = E * (2 * 33600 + dim * dim)  # two colour frames read, dim^2 written per env-step
+        out['roofline_frame_post'] = {
+            'kernel': 'frame_post_kernel + since_update_kernel (max-2, gray, INTER_AREA %dx%d, E=%d)' % (dim, dim, E),
+            'bound': 'hbm', 'achieved': fpb / fps / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+            'frac': fpb / fps / 1e9 / HBM_PEAK_GBPS, 'traffic': None, 'bytes_per_launch': fpb,
+        }
         es = env_timer.mean_seconds()
         out['kernels'] = {
             'env_step_ms (atari_env_kernel + frame_post + since_update, one agent step of %d envs)' % E: es * 1e3,
