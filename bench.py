@@ -128,6 +128,8 @@ def main():
 
     rank, local, world = pdist.init()
     assert world == args.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+    if os.environ.get('PARL_AMD_SHARE_GPU'):  # test hook: several ranks on the one GPU of a test box
+        local = local % torch.cuda.device_count()
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     torch.manual_seed(0)

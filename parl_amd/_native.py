@@ -14,7 +14,8 @@ import threading
 import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libparl_hip.so')
+# PARL_HIP_LIB: load another build of the same library (kernel experiments); default = in-tree
+LIB_PATH = os.environ.get('PARL_HIP_LIB') or os.path.join(_HERE, 'libparl_hip.so')
 
 c_f32p = ctypes.c_void_p
 _i = ctypes.c_int

@@ -92,6 +92,9 @@ struct Emu {
         c1 = (mode == 1 || mode == 3) ? 16 : ((mode == 2 || mode == 6) ? 32 : (mode == 4 ? 64 : -1));
         c2 = mode == 3 ? 32 : (mode == 6 ? 64 : -1);
       };
+      // NOTE: lane-wise predicates below use the non-short-circuit & and | on purpose: `a && b`
+      // with per-lane operands compiles to a divergent branch (s_and_saveexec), and one divergent
+      // branch inside the interpreter loop makes LLVM structurize the wave-uniform code around it.
       auto player = [&](int pos, int nus, int refl, int grp, int sup) -> bool {
         const int mode = nus & 7;
         const int sh = mode == 5 ? 1 : (mode == 7 ? 2 : 0);
@@ -100,16 +103,16 @@ struct Emu {
         int d = x - pos;
         d += d < 0 ? 160 : 0;
         const int w = 8 << sh;
-        const bool in0 = (d < w) && !sup;
+        const bool in0 = (d < w) & !sup;
         const int o1 = d - c1, o2 = d - c2;
-        const bool in1 = (c1 >= 0) && (o1 >= 0) && (o1 < w);
-        const bool in2 = (c2 >= 0) && (o2 >= 0) && (o2 < w);
+        const bool in1 = (c1 >= 0) & (o1 >= 0) & (o1 < w);
+        const bool in2 = (c2 >= 0) & (o2 >= 0) & (o2 < w);
         const int off = in0 ? d : (in1 ? o1 : o2);
         const int k = (off >> sh) & 7;
         const int bit = (refl & 0x08) ? ((grp >> k) & 1) : ((grp >> (7 - k)) & 1);
-        return (in0 || in1 || in2) && bit;
+        return (in0 | in1 | in2) & (bit != 0);
       };
-      auto missile = [&](int pos, int nus, int enam, int resmp) -> bool {
+      auto missile = [&](int pos, int nus) -> bool {
         const int mode = nus & 7;
         int c1, c2;
         copies(mode, c1, c2);
@@ -117,30 +120,29 @@ struct Emu {
         int d = x - pos;
         d += d < 0 ? 160 : 0;
         const int o1 = d - c1, o2 = d - c2;
-        const bool in = (d < w) || ((c1 >= 0) && (o1 >= 0) && (o1 < w)) ||
-                        ((c2 >= 0) && (o2 >= 0) && (o2 < w));
-        return in && (enam & 0x02) && !(resmp & 0x02);
+        return (d < w) | ((c1 >= 0) & (o1 >= 0) & (o1 < w)) | ((c2 >= 0) & (o2 >= 0) & (o2 < w));
       };
       // wave-uniform enables first: a disabled object costs one scalar branch, not its pixel math
       // (most Pong / Breakout scanlines have no player, missile or ball at all)
       bool p0 = false, p1 = false, m0 = false, m1 = false, bl = false;
-      if (g0) p0 = act && player(t(T_POSP0), nus0, t(T_REFP0), g0, t(T_SUP0));
-      if (g1) p1 = act && player(t(T_POSP1), nus1, t(T_REFP1), g1, t(T_SUP1));
-      const int enam0 = t(T_ENAM0), enam1 = t(T_ENAM1), resmp0 = t(T_RESMP0), resmp1 = t(T_RESMP1);
-      if ((enam0 & 0x02) && !(resmp0 & 0x02)) m0 = act && missile(t(T_POSM0), nus0, enam0, resmp0);
-      if ((enam1 & 0x02) && !(resmp1 & 0x02)) m1 = act && missile(t(T_POSM1), nus1, enam1, resmp1);
+      if (g0) p0 = act & player(t(T_POSP0), nus0, t(T_REFP0), g0, t(T_SUP0));
+      if (g1) p1 = act & player(t(T_POSP1), nus1, t(T_REFP1), g1, t(T_SUP1));
+      if ((t(T_ENAM0) & 0x02) && !(t(T_RESMP0) & 0x02)) m0 = act & missile(t(T_POSM0), nus0);
+      if ((t(T_ENAM1) & 0x02) && !(t(T_RESMP1) & 0x02)) m1 = act & missile(t(T_POSM1), nus1);
       if (ebl) {
         int d = x - t(T_POSBL);
         d += d < 0 ? 160 : 0;
-        bl = act && (d < (1 << ((ctrlpf >> 4) & 3)));
+        bl = act & (d < (1 << ((ctrlpf >> 4) & 3)));
       }
       bool pf;
       {
+        // 20 playfield bits of the half line as one uniform word: bit i = PF0[4+i] (i<4),
+        // PF1[11-i] (i<12), PF2[i-12]; per lane only a shift by its column index remains
+        const int pfw = ((t(T_PF0) >> 4) & 0xf) | ((int)(__builtin_bitreverse32((uint32_t)t(T_PF1)) >> 24) << 4) |
+                        (t(T_PF2) << 12);
         int i = x >> 2;
         i = i >= 20 ? ((ctrlpf & 1) ? 39 - i : i - 20) : i;
-        const int pf0 = t(T_PF0), pf1 = t(T_PF1), pf2 = t(T_PF2);
-        const int b = i < 4 ? (pf0 >> (4 + i)) : (i < 12 ? (pf1 >> (11 - i)) : (pf2 >> (i - 12)));
-        pf = act && (b & 1);
+        pf = act & (((pfw >> (i & 31)) & 1) != 0);
       }
       const unsigned long long P0 = __ballot(p0), P1 = __ballot(p1), M0 = __ballot(m0),
                                M1 = __ballot(m1), BL = __ballot(bl), PF = __ballot(pf);
@@ -158,23 +160,34 @@ struct Emu {
       }
       if (fb) {
         int sel = 0;  // Stella priority encoder: 0 BK, 1 PF, 2 P0, 3 P1
+        const bool o0 = p0 | m0, o1 = p1 | m1;
         if (ctrlpf & 0x04) {
-          sel = (p1 || m1) ? 3 : sel;
-          sel = (p0 || m0) ? 2 : sel;
-          sel = bl ? 1 : sel;
-          sel = pf ? 1 : sel;
+          sel = o1 ? 3 : sel;
+          sel = o0 ? 2 : sel;
+          sel = (bl | pf) ? 1 : sel;
         } else {
+          const int score = (ctrlpf & 0x02) != 0;           // score mode: PF takes the player colours
+          const int pfsel = score ? (x < 80 ? 2 : 3) : 1;   // per-lane select of two uniform values
           sel = bl ? 1 : sel;
-          sel = pf ? ((ctrlpf & 0x02) ? (x < 80 ? 2 : 3) : 1) : sel;
-          sel = (p1 || m1) ? ((sel != 2) ? 3 : 2) : sel;
-          sel = (p0 || m0) ? 2 : sel;
+          sel = pf ? pfsel : sel;
+          sel = o1 ? ((sel != 2) ? 3 : 2) : sel;
+          sel = o0 ? 2 : sel;
         }
-        const int cbk = t(T_COLUBK), cpf = t(T_COLUPF), cp0 = t(T_COLUP0), cp1 = t(T_COLUP1);
-        color = sel == 0 ? cbk : (sel == 1 ? cpf : (sel == 2 ? cp0 : cp1));
-        color = (t(T_HMBLANK) && x < 8) ? 0 : color;
+        // the four colour registers as one uniform word, indexed per lane by a shift (branch-free)
+        const uint32_t cw = (uint32_t)t(T_COLUBK) | ((uint32_t)t(T_COLUPF) << 8) | ((uint32_t)t(T_COLUP0) << 16) |
+                            ((uint32_t)t(T_COLUP1) << 24);
+        color = (int)((cw >> (sel * 8)) & 0xffu);
+        color = ((t(T_HMBLANK) != 0) & (x < 8)) ? 0 : color;
       }
     }
-    if (fb && act) fb[row * kW + x] = (uint8_t)color;
+    if (fb) {
+      // Predication without a divergent branch: inactive lanes store to an out-of-range offset of
+      // a raw buffer resource, which the hardware drops.  A per-lane `if (act)` here would be the
+      // only divergent branch of the whole interpreter loop and would force LLVM to structurize
+      // (and bloat) the otherwise wave-uniform control flow around it.
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(fb, 0, kFrameBytes, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)color, rsrc, act ? row * kW + x : -1, 0, 0);
+    }
   }
 
   // wave-uniform: can any pixel of the current register state set a collision latch?
@@ -217,6 +230,9 @@ struct Emu {
     clock = clock > stop_clock ? stop_clock : clock;
     last_clock = last_clock < start ? start : last_clock;
     if (last_clock >= clock) return;
+#ifdef PARLHIP_EXP_NORENDER
+    last_clock = clock; return;
+#endif
     if (!fb && !can_collide()) {
       // collisions-only frame and nothing to latch in this span (VBLANK on, or no player /
       // missile / ball enabled): skip the pixels, keep the end-of-scanline side effects
@@ -449,11 +465,163 @@ struct Emu {
   }
 
   // ------------------------------------------------------------------------------------
+  // Fast path: instructions whose operand lives in the cartridge, the 128 bytes of RAM or (reads
+  // only) the RIOT — ~85 % of what Pong / Breakout execute.  They need none of the generic path's
+  // bus staging (effective-address / TIA catch-up / operand / write-back stages), only the
+  // cycle count of the documented instruction timing.  Returns false WITHOUT side effects when the
+  // instruction touches the TIA or is a rare one; the generic path below then executes it.
+  // ------------------------------------------------------------------------------------
+  DEVI bool step_fast(const uint32_t w) {
+    const int b1 = w & 0xff, b2 = (w >> 8) & 0xff;
+    const int mode = (w >> 16) & 15, kind = (w >> 20) & 3, op = (w >> 22) & 63;
+    if (kind == K_READ) {
+      int m = 0, dc = 0, dpc = 2;
+      switch (mode) {
+        case M_IMM: m = b1; dc = 2; break;
+        case M_ZP:
+          if (!(b1 & 0x80)) return false;
+          m = ram_rd(b1 & 0x7f); dc = 3;
+          break;
+        case M_ZPX: case M_ZPY: {
+          const int ea = (b1 + (mode == M_ZPX ? X : Y)) & 0xff;
+          if (!(ea & 0x80)) return false;
+          m = ram_rd(ea & 0x7f); dc = 4;
+          break;
+        }
+        case M_ABS: case M_ABX: case M_ABY: {
+          const int base = b1 | (b2 << 8);
+          const int ea = mode == M_ABS ? base : ((base + (mode == M_ABX ? X : Y)) & 0xffff);
+          dc = 4 + (((ea ^ base) & 0xff00) ? 1 : 0);
+          dpc = 3;
+          if (ea & 0x1000) {
+            m = rom_byte(ea);
+          } else if ((ea & 0x280) == 0x80) {
+            m = ram_rd(ea & 0x7f);
+          } else if ((ea & 0x280) == 0x280) {
+            cyc += dc; dc = 0;      // the timer is read at the bus cycle's time
+            m = riot_read(ea);
+          } else {
+            return false;           // TIA
+          }
+          break;
+        }
+        case M_IZY: {
+          if (b1 < 0x80 || b1 == 0xff) return false;  // pointer bytes must both be in RAM
+          const int base = ram_rd(b1 & 0x7f) | (ram_rd((b1 + 1) & 0x7f) << 8);
+          const int ea = (base + Y) & 0xffff;
+          dc = 5 + (((ea ^ base) & 0xff00) ? 1 : 0);
+          if (ea & 0x1000) m = rom_byte(ea);
+          else if ((ea & 0x280) == 0x80) m = ram_rd(ea & 0x7f);
+          else return false;
+          break;
+        }
+        default: return false;  // (zp,X) and the pulls
+      }
+      switch (op) {
+        case O_LDA: A = m; set_nz(A); break;
+        case O_LDX: X = m; set_nz(X); break;
+        case O_LDY: Y = m; set_nz(Y); break;
+        case O_ORA: A |= m; set_nz(A); break;
+        case O_AND: A &= m; set_nz(A); break;
+        case O_EOR: A ^= m; set_nz(A); break;
+        case O_ADC: adc(m); break;
+        case O_SBC: sbc(m); break;
+        case O_CMP: cmp(A, m); break;
+        case O_CPX: cmp(X, m); break;
+        case O_CPY: cmp(Y, m); break;
+        case O_BIT: P = (P & ~(FN | FV | FZ)) | (m & 0xc0) | ((A & m) ? 0 : FZ); break;
+        default: jam |= JAM_OPCODE; break;  // unreachable: every K_READ op of these modes is above
+      }
+      cyc += dc;
+      PC = (PC + dpc) & 0xffff;
+      return true;
+    }
+    if (kind == K_NONE) {
+      int dc = 2, npc = (PC + 1) & 0xffff;
+      switch (op) {
+        case O_ASL_A: P = (P & ~FC) | (A >> 7); A = (A << 1) & 0xff; set_nz(A); break;
+        case O_LSR_A: P = (P & ~FC) | (A & 1); A = A >> 1; set_nz(A); break;
+        case O_ROL_A: { const int c = P & FC; P = (P & ~FC) | (A >> 7); A = ((A << 1) | c) & 0xff; set_nz(A); break; }
+        case O_ROR_A: { const int c = P & FC; P = (P & ~FC) | (A & 1); A = (A >> 1) | (c << 7); set_nz(A); break; }
+        case O_INX: X = (X + 1) & 0xff; set_nz(X); break;
+        case O_INY: Y = (Y + 1) & 0xff; set_nz(Y); break;
+        case O_DEX: X = (X - 1) & 0xff; set_nz(X); break;
+        case O_DEY: Y = (Y - 1) & 0xff; set_nz(Y); break;
+        case O_TAX: X = A; set_nz(X); break;
+        case O_TAY: Y = A; set_nz(Y); break;
+        case O_TXA: A = X; set_nz(A); break;
+        case O_TYA: A = Y; set_nz(A); break;
+        case O_TSX: X = S; set_nz(X); break;
+        case O_TXS: S = X; break;
+        case O_CLC: P &= ~FC; break;
+        case O_SEC: P |= FC; break;
+        case O_CLI: P &= ~FI; break;
+        case O_SEI: P |= FI; break;
+        case O_CLV: P &= ~FV; break;
+        case O_CLD: P &= ~FD; break;
+        case O_SED: P |= FD; break;
+        case O_NOP: break;
+        case O_BPL: case O_BMI: case O_BVC: case O_BVS: case O_BCC: case O_BCS: case O_BNE: case O_BEQ: {
+          const int flag = (op == O_BPL || op == O_BMI) ? FN : ((op == O_BVC || op == O_BVS) ? FV :
+                           ((op == O_BCC || op == O_BCS) ? FC : FZ));
+          const bool want_set = (op == O_BMI || op == O_BVS || op == O_BCS || op == O_BEQ);
+          npc = (PC + 2) & 0xffff;
+          if (((P & flag) != 0) == want_set) {
+            const int tgt = (npc + ((b1 & 0x80) ? b1 - 256 : b1)) & 0xffff;
+            dc += ((tgt ^ npc) & 0xff00) ? 2 : 1;
+            npc = tgt;
+          }
+          break;
+        }
+        case O_JMP: dc = 3; npc = b1 | (b2 << 8); break;
+        default: return false;  // JSR / RTS / RTI / BRK / JMP () / JAM
+      }
+      cyc += dc;
+      PC = npc;
+      return true;
+    }
+    // stores and read-modify-writes to RAM
+    int ea, dc, dpc = 2;
+    switch (mode) {
+      case M_ZP: ea = b1; dc = 3; break;
+      case M_ZPX: ea = (b1 + X) & 0xff; dc = 4; break;
+      case M_ZPY: ea = (b1 + Y) & 0xff; dc = 4; break;
+      case M_PUSH: ea = S; dc = 3; dpc = 1; break;
+      default: return false;  // absolute / indirect stores (RIOT timer writes etc.)
+    }
+    if (!(ea & 0x80)) return false;  // TIA (incl. the PHP-into-ENABL stack trick)
+    int wv;
+    if (kind == K_WRITE) {
+      wv = op == O_STA ? A : (op == O_STX ? X : (op == O_STY ? Y : (op == O_PHA ? A : (P | FB | FU))));
+      if (mode == M_PUSH) S = (S - 1) & 0xff;
+    } else {  // K_RMW: zp / zp,X only reach here
+      const int m = ram_rd(ea & 0x7f);
+      switch (op) {
+        case O_ASL: P = (P & ~FC) | (m >> 7); wv = (m << 1) & 0xff; break;
+        case O_LSR: P = (P & ~FC) | (m & 1); wv = m >> 1; break;
+        case O_ROL: { const int c = P & FC; P = (P & ~FC) | (m >> 7); wv = ((m << 1) | c) & 0xff; break; }
+        case O_ROR: { const int c = P & FC; P = (P & ~FC) | (m & 1); wv = (m >> 1) | (c << 7); break; }
+        case O_INC: wv = (m + 1) & 0xff; break;
+        default: wv = (m - 1) & 0xff; break;  // O_DEC
+      }
+      set_nz(wv);
+      dc += 2;
+    }
+    ram_wr(ea & 0x7f, wv);
+    cyc += dc;
+    PC = (PC + dpc) & 0xffff;
+    return true;
+  }
+
+  // ------------------------------------------------------------------------------------
   // one 6507 instruction
   // ------------------------------------------------------------------------------------
   DEVI void step() {
     const uint32_t w = (uint32_t)rfl((int)romw[PC & rom_mask]);
     if (!(PC & 0x1000)) jam |= JAM_OPCODE;  // executing outside the cartridge is not supported
+#ifndef PARLHIP_EXP_NOFAST
+    if (step_fast(w)) return;
+#endif
     const int b1 = w & 0xff, b2 = (w >> 8) & 0xff;
     const int mode = (w >> 16) & 15, kind = (w >> 20) & 3, op = (w >> 22) & 63;
     cyc++;  // opcode fetch

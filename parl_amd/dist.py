@@ -21,9 +21,12 @@ def init(backend=None):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # PARL_AMD_DIST_BACKEND=gloo: test hook (e.g. two ranks sharing the one GPU of a test box)
+            backend = os.environ.get('PARL_AMD_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
@@ -77,7 +80,12 @@ def all_gather_small(tensors):
     for k, v in tensors.items():
         v = v.contiguous()
         buf = torch.empty((w, ) + tuple(v.shape), dtype=v.dtype, device=v.device)
-        dist.all_gather_into_tensor(buf, v) if v.is_cuda else dist.all_gather(list(buf.unbind(0)), v)
+        if v.is_cuda and dist.get_backend() == 'nccl':
+            dist.all_gather_into_tensor(buf, v)
+        else:
+            parts = [torch.empty_like(v) for _ in range(w)]
+            dist.all_gather(parts, v)
+            buf = torch.stack(parts)
         out[k] = buf
     return out
 
