@@ -201,27 +201,21 @@ struct Emu {
     return (g0 | g1 | ebl | m0 | m1) != 0;
   }
 
-  // Does writing `v` to TIA register `reg` change anything the picture or the collision latches
-  // depend on?  If not, the catch-up render before the write can be skipped: the pending pixels
-  // are drawn later with identical register state.  (Pong rewrites PF1/PF2/GRP1/ENAM0/ENABL with
-  // unchanged values on almost every scanline and strobes WSYNC mid-line.)
-  DEVI bool write_needs_catch_up(int reg, int v) const {
-    switch (reg) {
-      case 0x00: case 0x02: case 0x03:                           // VSYNC, WSYNC, RSYNC
-      case 0x15: case 0x16: case 0x17: case 0x18: case 0x19: case 0x1a:  // audio
-      case 0x20: case 0x21: case 0x22: case 0x23: case 0x24: case 0x2b:  // HMxx, HMCLR: used at HMOVE
-        return false;
-      case 0x01: case 0x04: case 0x05: case 0x0a: case 0x0b: case 0x0c: case 0x0d: case 0x0e:
-      case 0x0f: case 0x1d: case 0x1e: case 0x1f: case 0x25: case 0x26: case 0x27:
-        return t(reg) != v;
-      case 0x06: case 0x07: case 0x08: case 0x09:
-        return t(reg) != (v & 0xfe);
-      case 0x1b: return t(T_GRP0) != v || t(T_DGRP1) != t(T_GRP1);
-      case 0x1c: return t(T_GRP1) != v || t(T_DGRP0) != t(T_GRP0) || t(T_DENABL) != t(T_ENABL);
-      default:
-        return reg <= 0x2c;  // position strobes, RESMPx, HMOVE, CXCLR: always; unmapped: never
-    }
-  }
+  // TIA write classes (bit = register number).  kPlainRegs: the write is "tset(reg, v)" and
+  // nothing else (VBLANK additionally drives the paddle dump) — rewriting the value already held
+  // is a complete no-op, and Pong / Breakout rewrite PF1/PF2/GRPx/ENAxx with unchanged values on
+  // almost every scanline.  kStrobeRegs: position strobes, RESMPx, HMOVE, CXCLR — always need the
+  // picture caught up.  Everything else (VSYNC, WSYNC, RSYNC, audio, HMxx, HMCLR, unmapped) never
+  // does: HMxx only matter at the next HMOVE.  GRP0 / GRP1 (also latching the delayed copies) are
+  // classified in place.
+  static constexpr unsigned long long kPlainRegs =
+      (1ull << 0x01) | (1ull << 0x04) | (1ull << 0x05) | (1ull << 0x06) | (1ull << 0x07) | (1ull << 0x08) |
+      (1ull << 0x09) | (1ull << 0x0a) | (1ull << 0x0b) | (1ull << 0x0c) | (1ull << 0x0d) | (1ull << 0x0e) |
+      (1ull << 0x0f) | (1ull << 0x1d) | (1ull << 0x1e) | (1ull << 0x1f) | (1ull << 0x25) | (1ull << 0x26) |
+      (1ull << 0x27);
+  static constexpr unsigned long long kStrobeRegs =
+      (1ull << 0x10) | (1ull << 0x11) | (1ull << 0x12) | (1ull << 0x13) | (1ull << 0x14) | (1ull << 0x28) |
+      (1ull << 0x29) | (1ull << 0x2a) | (1ull << 0x2c);
 
   DEVI void tia_update(int clock) {
     const int c0 = cyc0 * 3;
@@ -471,7 +465,8 @@ struct Emu {
   // cycle count of the documented instruction timing.  Returns false WITHOUT side effects when the
   // instruction touches the TIA or is a rare one; the generic path below then executes it.
   // ------------------------------------------------------------------------------------
-  DEVI bool step_fast(const uint32_t w) {
+  enum : int { FAST_DONE = 0, FAST_GENERIC = 1, FAST_TIA_STORE = 2 };
+  DEVI int step_fast(const uint32_t w, int& tia_ea, int& tia_wv) {
     const int b1 = w & 0xff, b2 = (w >> 8) & 0xff;
     const int mode = (w >> 16) & 15, kind = (w >> 20) & 3, op = (w >> 22) & 63;
     if (kind == K_READ) {
@@ -479,12 +474,12 @@ struct Emu {
       switch (mode) {
         case M_IMM: m = b1; dc = 2; break;
         case M_ZP:
-          if (!(b1 & 0x80)) return false;
+          if (!(b1 & 0x80)) return FAST_GENERIC;
           m = ram_rd(b1 & 0x7f); dc = 3;
           break;
         case M_ZPX: case M_ZPY: {
           const int ea = (b1 + (mode == M_ZPX ? X : Y)) & 0xff;
-          if (!(ea & 0x80)) return false;
+          if (!(ea & 0x80)) return FAST_GENERIC;
           m = ram_rd(ea & 0x7f); dc = 4;
           break;
         }
@@ -500,22 +495,28 @@ struct Emu {
           } else if ((ea & 0x280) == 0x280) {
             cyc += dc; dc = 0;      // the timer is read at the bus cycle's time
             m = riot_read(ea);
+          } else if ((ea & 0x0f) >= 8) {
+            // TIA input ports (Pong polls INPT0-3 with LDA abs,Y ~185x per frame): no picture
+            // dependence; same bus timing as the generic path (value sampled at the read cycle,
+            // bus noise of an absolute read = the address high byte)
+            cyc += dc; dc = 0;
+            m = tia_read(ea, b2);
           } else {
-            return false;           // TIA
+            return FAST_GENERIC;    // collision latches: the picture must be caught up first
           }
           break;
         }
         case M_IZY: {
-          if (b1 < 0x80 || b1 == 0xff) return false;  // pointer bytes must both be in RAM
+          if (b1 < 0x80 || b1 == 0xff) return FAST_GENERIC;  // pointer bytes must both be in RAM
           const int base = ram_rd(b1 & 0x7f) | (ram_rd((b1 + 1) & 0x7f) << 8);
           const int ea = (base + Y) & 0xffff;
           dc = 5 + (((ea ^ base) & 0xff00) ? 1 : 0);
           if (ea & 0x1000) m = rom_byte(ea);
           else if ((ea & 0x280) == 0x80) m = ram_rd(ea & 0x7f);
-          else return false;
+          else return FAST_GENERIC;
           break;
         }
-        default: return false;  // (zp,X) and the pulls
+        default: return FAST_GENERIC;  // (zp,X) and the pulls
       }
       switch (op) {
         case O_LDA: A = m; set_nz(A); break;
@@ -534,7 +535,7 @@ struct Emu {
       }
       cyc += dc;
       PC = (PC + dpc) & 0xffff;
-      return true;
+      return FAST_DONE;
     }
     if (kind == K_NONE) {
       int dc = 2, npc = (PC + 1) & 0xffff;
@@ -574,11 +575,11 @@ struct Emu {
           break;
         }
         case O_JMP: dc = 3; npc = b1 | (b2 << 8); break;
-        default: return false;  // JSR / RTS / RTI / BRK / JMP () / JAM
+        default: return FAST_GENERIC;  // JSR / RTS / RTI / BRK / JMP () / JAM
       }
       cyc += dc;
       PC = npc;
-      return true;
+      return FAST_DONE;
     }
     // stores and read-modify-writes to RAM
     int ea, dc, dpc = 2;
@@ -587,14 +588,23 @@ struct Emu {
       case M_ZPX: ea = (b1 + X) & 0xff; dc = 4; break;
       case M_ZPY: ea = (b1 + Y) & 0xff; dc = 4; break;
       case M_PUSH: ea = S; dc = 3; dpc = 1; break;
-      default: return false;  // absolute / indirect stores (RIOT timer writes etc.)
+      default: return FAST_GENERIC;  // absolute / indirect stores (RIOT timer writes etc.)
     }
-    if (!(ea & 0x80)) return false;  // TIA (incl. the PHP-into-ENABL stack trick)
     int wv;
     if (kind == K_WRITE) {
       wv = op == O_STA ? A : (op == O_STX ? X : (op == O_STY ? Y : (op == O_PHA ? A : (P | FB | FU))));
       if (mode == M_PUSH) S = (S - 1) & 0xff;
+      if (!(ea & 0x80)) {
+        // TIA register write (incl. the PHP-into-ENABL stack trick), ~1000x per frame: hand the
+        // generic path a finished effective address / value so that it only runs its TIA stages
+        // (the catch-up render keeps a single site in the instruction stream)
+        cyc += dc - 1;  // the write cycle itself is counted by stage D
+        PC = (PC + dpc) & 0xffff;
+        tia_ea = ea & 0xff; tia_wv = wv;
+        return FAST_TIA_STORE;
+      }
     } else {  // K_RMW: zp / zp,X only reach here
+      if (!(ea & 0x80)) return FAST_GENERIC;  // read-modify-write of a TIA address: flagged there
       const int m = ram_rd(ea & 0x7f);
       switch (op) {
         case O_ASL: P = (P & ~FC) | (m >> 7); wv = (m << 1) & 0xff; break;
@@ -610,7 +620,7 @@ struct Emu {
     ram_wr(ea & 0x7f, wv);
     cyc += dc;
     PC = (PC + dpc) & 0xffff;
-    return true;
+    return FAST_DONE;
   }
 
   // ------------------------------------------------------------------------------------
@@ -619,14 +629,16 @@ struct Emu {
   DEVI void step() {
     const uint32_t w = (uint32_t)rfl((int)romw[PC & rom_mask]);
     if (!(PC & 0x1000)) jam |= JAM_OPCODE;  // executing outside the cartridge is not supported
-#ifndef PARLHIP_EXP_NOFAST
-    if (step_fast(w)) return;
-#endif
+    int ea = 0, wv = 0;
+    const int fast = step_fast(w, ea, wv);
+    if (fast == FAST_DONE) return;
+    const bool pre = fast == FAST_TIA_STORE;  // stages A and C already done by the fast decoder
     const int b1 = w & 0xff, b2 = (w >> 8) & 0xff;
     const int mode = (w >> 16) & 15, kind = (w >> 20) & 3, op = (w >> 22) & 63;
-    cyc++;  // opcode fetch
-    int ea = 0, noise = b1, m = 0;
+    int noise = b1, m = 0;
     // ---- stage A: effective address ----
+    if (!pre) {
+    cyc++;  // opcode fetch
     switch (mode) {
       case M_IMM: cyc++; m = b1; PC = (PC + 2) & 0xffff; break;
       case M_ZP: cyc++; ea = b1; PC = (PC + 2) & 0xffff; break;
@@ -671,25 +683,43 @@ struct Emu {
         break;
       default: break;  // M_IMP / M_REL handled by the operation
     }
+    }
     const bool has_ea = kind != K_NONE && mode != M_IMM;
     const bool is_tia = has_ea && !(ea & 0x1080);
     // ---- stage R: catch the picture up before a TIA access (single render site) ----
+    // Writes are classified first: rewriting a register with the value it already holds (what the
+    // cartridges do on almost every scanline) neither needs the picture nor changes anything.
+    enum : int { W_GENERAL = 0, W_NOP, W_PLAIN };
+    int upd = -1, wkind = W_GENERAL, wreg = 0, wval = 0;
     if (is_tia) {
       if (kind == K_READ) {
         // only the collision latches (CXxx, 0x0-0x7) depend on the picture; INPTx do not
-        if ((ea & 0x0f) < 8) tia_update((cyc + 1) * 3);
+        if ((ea & 0x0f) < 8) upd = (cyc + 1) * 3;
       } else if (kind == K_WRITE) {
-        const int reg = ea & 0x3f;
-        const int wvp = op == O_STA ? A : (op == O_STX ? X : (op == O_STY ? Y : (op == O_PHA ? A : (P | FB | FU))));
-        if (write_needs_catch_up(reg, wvp)) {
-          const int clock = (cyc + 1) * 3;
-          const int hpos = (clock - cyc0 * 3) % kClocksPerLine;
-          tia_update(clock + poke_delay(reg, hpos));
+        wreg = ea & 0x3f;
+        if (!pre) wv = op == O_STA ? A : (op == O_STX ? X : (op == O_STY ? Y : (op == O_PHA ? A : (P | FB | FU))));
+        const int clock = (cyc + 1) * 3;
+        if ((kPlainRegs >> wreg) & 1ull) {
+          wval = (wreg >= 0x06 && wreg <= 0x09) ? (wv & 0xfe) : wv;
+          if (t(wreg) == wval) {
+            wkind = W_NOP;
+          } else {
+            wkind = W_PLAIN;
+            upd = clock + poke_delay(wreg, (clock - cyc0 * 3) % kClocksPerLine);
+          }
+        } else if (wreg == 0x1b) {
+          if (t(T_GRP0) == wv && t(T_DGRP1) == t(T_GRP1)) wkind = W_NOP; else upd = clock + 1;
+        } else if (wreg == 0x1c) {
+          if (t(T_GRP1) == wv && t(T_DGRP0) == t(T_GRP0) && t(T_DENABL) == t(T_ENABL)) wkind = W_NOP;
+          else upd = clock + 1;
+        } else if ((kStrobeRegs >> wreg) & 1ull) {
+          upd = clock;  // position strobes, RESMPx, HMOVE, CXCLR (poke delay 0)
         }
       } else {
         jam |= JAM_RMW_TIA;
       }
     }
+    if (upd >= 0) tia_update(upd);
     // ---- stage B: operand read ----
     if (has_ea && kind != K_WRITE) {
       cyc++;
@@ -699,7 +729,7 @@ struct Emu {
       else m = riot_read(ea);
     }
     // ---- stage C: operation ----
-    int wv = 0;
+    if (!pre) {
     switch (op) {
       case O_ORA: A |= m; set_nz(A); break;
       case O_AND: A &= m; set_nz(A); break;
@@ -800,13 +830,29 @@ struct Emu {
       }
       default: break;
     }
+    }
     // ---- stage D: write back ----
     if (has_ea && kind != K_READ) {
       if (kind == K_RMW) cyc++;  // internal modify cycle
       cyc++;
       if (ea & 0x1000) {
       } else if (!(ea & 0x80)) {
-        if (kind == K_WRITE) tia_write(ea & 0x3f, wv);
+        if (kind == K_WRITE) {
+          if (wkind == W_NOP) {
+          } else if (wkind == W_PLAIN) {
+            if (wreg == 0x01) {  // VBLANK: paddle dump transistor
+              const int old = t(T_VBLANK);
+              if (!(old & 0x80) && (wval & 0x80)) dump_en = 1;
+              if ((old & 0x80) && !(wval & 0x80)) { dump_en = 0; dump_dis_cyc = cyc; }
+            }
+            tset(wreg, wval);
+          } else if (wreg == 0x02) {  // WSYNC: halt the CPU until the end of the scanline
+            const int into = (cyc - cyc0) % kCyclesPerLine;
+            cyc += into ? kCyclesPerLine - into : 0;
+          } else {
+            tia_write(wreg, wv);
+          }
+        }
       } else if (!(ea & 0x200)) {
         ram_wr(ea & 0x7f, wv);
       } else {
