@@ -5,9 +5,12 @@ Metric (BASELINE.json): env frames/sec (whole job) + learner updates/sec.
 One timed "step" = one full actor-learner iteration of the reference's IMPALA example
 (examples/IMPALA, config examples/IMPALA/impala_config.py) executed on the device:
     T = sample_batch_steps env steps for every env (policy forward -> categorical sample ->
-    emulator 4 frames -> max/gray/resize -> ring), then ONE learner update on the T*E batch
+    emulator 4 frames -> max/gray/resize -> ring), and ONE learner update on a T*E batch
     (fwd, fused V-trace, bwd, [RCCL grad all-reduce], global-norm clip, Adam).
-Nothing is skipped inside the timed region.  Frames counted = emulated 2600 frames of agent
+As in the reference (actors and learner are decoupled, the behaviour policy lags the learner),
+the update on batch i-1 runs on a second HIP stream WHILE batch i is collected
+(parl_amd.rollout.AsyncActorLearner; --no-overlap runs them back to back).  Every timed step
+contains exactly one full rollout and one full update.  Nothing is skipped inside the timed region.  Frames counted = emulated 2600 frames of agent
 steps (4 per step, frame-skip 4); reset frames are not counted.
 
     python bench.py --gpus 1 --steps K --warmup W
@@ -32,7 +35,7 @@ from parl_amd import dist as pdist  # noqa: E402
 from parl_amd import ops  # noqa: E402
 from parl_amd.env import DeviceVectorEnv  # noqa: E402
 from parl_amd.models import AtariModel42, AtariModel84  # noqa: E402
-from parl_amd.rollout import DeviceRollout  # noqa: E402
+from parl_amd.rollout import AsyncActorLearner, DeviceRollout  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
 
@@ -123,7 +126,8 @@ def main():
     ap.add_argument('--sample-batch-steps', type=int, default=50)
     ap.add_argument('--game', default='PongNoFrameskip-v4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--learn-chunks', type=int, default=1)
+    ap.add_argument('--no-overlap', action='store_true',
+                    help='run rollout and learner update back to back on one stream instead of overlapped')
     args = ap.parse_args()
 
     rank, local, world = pdist.init()
@@ -146,7 +150,6 @@ def main():
     pdist.broadcast_model(model)
     if world > 1:
         alg.grad_hook = pdist.FlatGradAllReduce(model)
-    rollout = DeviceRollout(env, T, seed=99)
     lr_s = parl.utils.PiecewiseScheduler(cfg['lr_scheduler'])
     ent_s = parl.utils.PiecewiseScheduler(cfg['entropy_coeff_scheduler'])
 
@@ -157,13 +160,32 @@ def main():
     fp_timer = KernelTimer()
     env._frame_post = fp_timer.wrap(env._frame_post)
 
-    def step():
-        batch = rollout.collect(model)
-        loss, kl = alg.learn(batch['obs'], batch['actions'], batch['behaviour_logits'], batch['rewards'],
-                             batch['dones'], lr_s.step(), ent_s.step(), time_major=True)
-        if world > 1:  # small-tensor trajectory all-gather (global statistics), SURVEY §8e
-            pdist.all_gather_small({'rewards': rollout.rewards, 'dones': rollout.dones, 'actions': rollout.actions})
-        return loss
+    if args.no_overlap:
+        pipe = None
+        rollout = DeviceRollout(env, T, seed=99)
+
+        def step():
+            batch = rollout.collect(model)
+            loss, kl = alg.learn(batch['obs'], batch['actions'], batch['behaviour_logits'], batch['rewards'],
+                                 batch['dones'], lr_s.step(), ent_s.step(), time_major=True)
+            if world > 1:  # small-tensor trajectory all-gather (global statistics), SURVEY 8e
+                pdist.all_gather_small({'rewards': rollout.rewards, 'dones': rollout.dones,
+                                        'actions': rollout.actions})
+            return loss
+    else:
+        # IMPALA's actor/learner decoupling on one GPU: the learner update on batch i-1 runs on its
+        # own stream while the actors collect batch i (behaviour policy lags by one update)
+        pipe = AsyncActorLearner(alg, env, T, seed=99)
+        rollout = pipe.rollout
+        pipe.prime()  # untimed: every timed step = one rollout + one learner update
+
+        def step():
+            loss, kl = pipe.step(lr_s.step(), ent_s.step())
+            if world > 1:
+                with torch.cuda.stream(pipe.actor_stream):
+                    pdist.all_gather_small({'rewards': rollout.rewards, 'dones': rollout.dones,
+                                            'actions': rollout.actions})
+            return loss
 
     for _ in range(args.warmup):
         step()
@@ -199,6 +221,7 @@ def main():
             'workload': 'BASELINE configs[2]: PongNoFrameskip-v4 IMPALA V-trace, %d actors per GPU' % E,
             'envs_per_gpu': E, 'sample_batch_steps': T, 'obs_dim': dim, 'train_batch': T * E * world,
             'frame_skip': 4, 'parallelism': 'dp%d (envs sharded by rank, grad all-reduce)' % world,
+            'actor_learner_overlap': not args.no_overlap,
         },
         'learner_updates_per_sec': K / dt,
         'agent_steps_per_sec': K * T * E * world / dt,

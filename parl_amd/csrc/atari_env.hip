@@ -104,6 +104,7 @@ DEVI void store_env(const Emu& e, const Wrap& v, uint8_t* blob, int lane) {
 
 // One wavefront per env.  mode STEP: VectorEnv.step; RESET: VectorEnv.reset; SNAPSHOT: wave k
 // builds reset snapshot k (noops = k+1) for the O(1) real-reset path.
+template <int GAME>
 __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
     uint8_t* __restrict__ states, const uint32_t* __restrict__ romw_g, EnvParams prm,
     const long long* __restrict__ actions, uint8_t* __restrict__ frames,
@@ -118,6 +119,9 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
   const int e = blockIdx.x * kEnvsPerBlock + wave;
   if (e >= prm.E) return;
   const int mode = prm.mode, game = prm.game;
+  // translated code is only used for the cartridge it was generated from (tag set by
+  // parlhip_atari_rom_table_build after a CRC match)
+  const bool native_ok = NativeCart<GAME>::present && rfl((int)(rom_lds[0] >> 28)) == GAME;
   const long long max_steps = prm.max_episode_steps;
 
   Emu emu;
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
       emu.fire1 = swap ? fire : 0;
     }
     // ------------------------------------------------------------------ THE frame
-    emu.frame(fbp);
+    emu.frame<GAME>(fbp, native_ok);
     // ------------------------------------------------------------------ after the frame
     if (phase == PH_ALE) {
       ale_j++;
@@ -377,6 +381,18 @@ PARLHIP_EXPORT int parlhip_atari_rom_table_build(const uint8_t* rom_host, uint32
   if (!rom_host || !table_host) return PARLHIP_EINVAL;
   if (rom_size != 2048 && rom_size != 4096) return PARLHIP_ENOSUP;  // unbanked 2K/4K carts
   build_rom_words(rom_host, rom_size, table_host);
+  // tag the table (free top bits of word 0) when this is a cartridge the library carries
+  // natively translated code for
+  uint32_t crc = 0xffffffffu;
+  for (uint32_t i = 0; i < rom_size; ++i) {
+    crc ^= rom_host[i];
+    for (int k = 0; k < 8; ++k) crc = (crc >> 1) ^ (0xedb88320u & (0u - (crc & 1u)));
+  }
+  crc = ~crc;
+  uint32_t tag = 0;
+  if (NativeCart<GAME_PONG>::present && crc == NativeCart<GAME_PONG>::rom_crc32) tag = GAME_PONG;
+  if (NativeCart<GAME_BREAKOUT>::present && crc == NativeCart<GAME_BREAKOUT>::rom_crc32) tag = GAME_BREAKOUT;
+  table_host[0] = (table_host[0] & 0x0fffffffu) | (tag << 28);
   return PARLHIP_OK;
 }
 
@@ -396,9 +412,14 @@ static int launch_env(int mode, void* states, const uint32_t* romw, uint32_t rom
                       uint8_t* obs_flags, float* ep_returns, int32_t* ep_lengths, int E, uint64_t seed,
                       uint64_t env_id0, int64_t max_steps, void* snap, int32_t* jam, hipStream_t s) {
   EnvParams prm{game, (int)rom_size, E, mode, seed, env_id0, (long long)max_steps};
-  atari_env_kernel<<<ceil_div(E, kEnvsPerBlock), 64 * kEnvsPerBlock, 0, s>>>(
-      (uint8_t*)states, romw, prm, (const long long*)actions, frames, rewards, dones, obs_flags,
-      ep_returns, ep_lengths, (uint8_t*)snap, jam);
+  const dim3 grid(ceil_div(E, kEnvsPerBlock)), block(64 * kEnvsPerBlock);
+#define PARLHIP_LAUNCH_ENV(G)                                                                           \
+  atari_env_kernel<G><<<grid, block, 0, s>>>((uint8_t*)states, romw, prm, (const long long*)actions,     \
+                                             frames, rewards, dones, obs_flags, ep_returns, ep_lengths, \
+                                             (uint8_t*)snap, jam)
+  if (game == GAME_PONG) PARLHIP_LAUNCH_ENV(GAME_PONG);
+  else PARLHIP_LAUNCH_ENV(GAME_BREAKOUT);
+#undef PARLHIP_LAUNCH_ENV
   return check_launch();
 }
 

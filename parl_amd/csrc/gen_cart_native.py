@@ -1,0 +1,361 @@
+#!/usr/bin/env python3
+"""gen_cart_native.py — static translation of an Atari 2600 cartridge into straight-line gfx950
+code for the one-env-per-wavefront emulator (atari_core.hpp).
+
+Why: the 6507 interpreter is wave-uniform scalar code whose time goes into instruction DISPATCH,
+not execution.  Measured on MI355X with one wavefront per SIMD (tools/issue_microbench.hip):
+a dependent SALU op costs 4.5 clk, a NOT-taken conditional branch 12 clk, a taken one 30 clk, an
+LDS round trip 90 clk; the compiler lowers every `switch` to a compare/branch tree (AMDGPU has no
+jump tables), so decoding mode / kind / operation costs ~15 branches = ~400 of the ~680 clk an
+interpreted 6507 instruction takes.  The cartridge is read-only and known when the library is
+built, so each reachable instruction is emitted here as its own block of C++ with mode, operation,
+operand bytes, cycle count, page-crossing penalty and branch target folded to constants;
+control flow between instructions is the program's own (fall-through / goto).
+
+Exactness: a block implements precisely what Emu::step_fast does for that instruction (same
+helpers, same cycle accounting).  Anything else — real TIA register changes (the picture must be
+caught up first), collision-latch reads, JSR/RTS/BRK/RTI, stack-in-TIA tricks with a changing
+value, undocumented opcodes — sets PC and returns to the caller, which executes that ONE
+instruction with the interpreter and re-enters through the dispatch switch.  The result is
+bit-identical to pure interpretation (tests/test_gpu_env.py compare against the CPU oracle).
+
+Output: cart_native.gen.hpp (not committed: derived from user-supplied ROM data).
+Usage: gen_cart_native.py <out.hpp> [name=path.bin ...]   (name in {pong, breakout})
+"""
+import sys
+import zlib
+
+# ---- mirrors atari_defs.hpp (decode_opcode) ------------------------------------------------------
+M_IMP, M_IMM, M_ZP, M_ZPX, M_ZPY, M_ABS, M_ABX, M_ABY, M_IZX, M_IZY, M_REL, M_PUSH, M_PULL = range(13)
+K_NONE, K_READ, K_WRITE, K_RMW = range(4)
+OPS = ('JAM NOP ORA AND EOR ADC SBC CMP CPX CPY LDA LDX LDY STA STX STY BIT ASL LSR ROL ROR INC DEC ASL_A LSR_A '
+       'ROL_A ROR_A INX INY DEX DEY TAX TAY TXA TYA TSX TXS CLC SEC CLI SEI CLV CLD SED PHA PHP PLA PLP BPL BMI BVC '
+       'BVS BCC BCS BNE BEQ JMP JMPI JSR RTS RTI BRK').split()
+O = {n: i for i, n in enumerate(OPS)}
+
+
+def decode_opcode(op):
+    cc, bbb, aaa = op & 3, (op >> 2) & 7, op >> 5
+    m01 = [M_IZX, M_ZP, M_IMM, M_ABS, M_IZY, M_ZPX, M_ABY, M_ABX]
+    if cc == 1:
+        o01 = ['ORA', 'AND', 'EOR', 'ADC', 'STA', 'LDA', 'CMP', 'SBC']
+        if op == 0x89:
+            return (M_IMP, K_NONE, 'JAM')
+        return (m01[bbb], K_WRITE if aaa == 4 else K_READ, o01[aaa])
+    single = {
+        0x00: (M_IMP, K_NONE, 'BRK'), 0x20: (M_IMP, K_NONE, 'JSR'), 0x40: (M_IMP, K_NONE, 'RTI'),
+        0x60: (M_IMP, K_NONE, 'RTS'), 0x4c: (M_IMP, K_NONE, 'JMP'), 0x6c: (M_IMP, K_NONE, 'JMPI'),
+        0x08: (M_PUSH, K_WRITE, 'PHP'), 0x28: (M_PULL, K_READ, 'PLP'), 0x48: (M_PUSH, K_WRITE, 'PHA'),
+        0x68: (M_PULL, K_READ, 'PLA'), 0x88: (M_IMP, K_NONE, 'DEY'), 0xa8: (M_IMP, K_NONE, 'TAY'),
+        0xc8: (M_IMP, K_NONE, 'INY'), 0xe8: (M_IMP, K_NONE, 'INX'), 0x18: (M_IMP, K_NONE, 'CLC'),
+        0x38: (M_IMP, K_NONE, 'SEC'), 0x58: (M_IMP, K_NONE, 'CLI'), 0x78: (M_IMP, K_NONE, 'SEI'),
+        0x98: (M_IMP, K_NONE, 'TYA'), 0xb8: (M_IMP, K_NONE, 'CLV'), 0xd8: (M_IMP, K_NONE, 'CLD'),
+        0xf8: (M_IMP, K_NONE, 'SED'), 0x8a: (M_IMP, K_NONE, 'TXA'), 0x9a: (M_IMP, K_NONE, 'TXS'),
+        0xaa: (M_IMP, K_NONE, 'TAX'), 0xba: (M_IMP, K_NONE, 'TSX'), 0xca: (M_IMP, K_NONE, 'DEX'),
+        0xea: (M_IMP, K_NONE, 'NOP'), 0x0a: (M_IMP, K_NONE, 'ASL_A'), 0x2a: (M_IMP, K_NONE, 'ROL_A'),
+        0x4a: (M_IMP, K_NONE, 'LSR_A'), 0x6a: (M_IMP, K_NONE, 'ROR_A'), 0x10: (M_REL, K_NONE, 'BPL'),
+        0x30: (M_REL, K_NONE, 'BMI'), 0x50: (M_REL, K_NONE, 'BVC'), 0x70: (M_REL, K_NONE, 'BVS'),
+        0x90: (M_REL, K_NONE, 'BCC'), 0xb0: (M_REL, K_NONE, 'BCS'), 0xd0: (M_REL, K_NONE, 'BNE'),
+        0xf0: (M_REL, K_NONE, 'BEQ'), 0x24: (M_ZP, K_READ, 'BIT'), 0x2c: (M_ABS, K_READ, 'BIT'),
+        0x84: (M_ZP, K_WRITE, 'STY'), 0x94: (M_ZPX, K_WRITE, 'STY'), 0x8c: (M_ABS, K_WRITE, 'STY'),
+        0xa0: (M_IMM, K_READ, 'LDY'), 0xa4: (M_ZP, K_READ, 'LDY'), 0xb4: (M_ZPX, K_READ, 'LDY'),
+        0xac: (M_ABS, K_READ, 'LDY'), 0xbc: (M_ABX, K_READ, 'LDY'), 0xc0: (M_IMM, K_READ, 'CPY'),
+        0xc4: (M_ZP, K_READ, 'CPY'), 0xcc: (M_ABS, K_READ, 'CPY'), 0xe0: (M_IMM, K_READ, 'CPX'),
+        0xe4: (M_ZP, K_READ, 'CPX'), 0xec: (M_ABS, K_READ, 'CPX'), 0x86: (M_ZP, K_WRITE, 'STX'),
+        0x96: (M_ZPY, K_WRITE, 'STX'), 0x8e: (M_ABS, K_WRITE, 'STX'), 0xa2: (M_IMM, K_READ, 'LDX'),
+        0xa6: (M_ZP, K_READ, 'LDX'), 0xb6: (M_ZPY, K_READ, 'LDX'), 0xae: (M_ABS, K_READ, 'LDX'),
+        0xbe: (M_ABY, K_READ, 'LDX'),
+    }
+    if op in single:
+        return single[op]
+    if cc == 2 and bbb in (1, 3, 5, 7) and aaa not in (4, 5):
+        o10 = ['ASL', 'ROL', 'LSR', 'ROR', None, None, 'DEC', 'INC']
+        m10 = [0, M_ZP, 0, M_ABS, 0, M_ZPX, 0, M_ABX]
+        return (m10[bbb], K_RMW, o10[aaa])
+    return (M_IMP, K_NONE, 'JAM')
+
+
+def length(mode):
+    if mode in (M_IMP, M_PUSH, M_PULL):
+        return 1
+    if mode in (M_ABS, M_ABX, M_ABY):
+        return 3
+    return 2
+
+
+FLAGS = dict(FN=0x80, FV=0x40, FU=0x20, FB=0x10, FD=0x08, FI=0x04, FZ=0x02, FC=0x01)
+
+
+class Cart(object):
+    def __init__(self, name, rom):
+        assert len(rom) in (2048, 4096)
+        self.name, self.rom, self.mask = name, rom, len(rom) - 1
+        self.code = {}  # 16-bit address -> (mode, kind, op, b1, b2)
+        self.discover()
+
+    def byte(self, a):
+        return self.rom[a & self.mask]
+
+    def word(self, a):
+        return self.byte(a) | (self.byte(a + 1) << 8)
+
+    def discover(self):
+        """The instruction starts we emit.  A block is a faithful translation of whatever bytes sit
+        at its address, so over-approximating the set of entry points is harmless (a block that is
+        never reached is never fetched) while a missing one only means that instruction gets
+        interpreted.  So: EVERY address of the cartridge mirror the reset vector points into
+        (computed jumps, RTS tricks and BRK/RTI calls need no analysis), plus recursive descent
+        from the vectors through branches / JMP / JSR for code reached through another mirror."""
+        reset = self.word(0xfffc)
+        lo = reset & ~self.mask & 0xffff
+        work = [reset, self.word(0xfffe)] + list(range(lo, lo + len(self.rom)))
+        while work:
+            a = work.pop() & 0xffff
+            while True:
+                if a in self.code or not (a & 0x1000):
+                    break
+                opc = self.byte(a)
+                mode, kind, op = decode_opcode(opc)
+                b1, b2 = self.byte(a + 1), self.byte(a + 2)
+                self.code[a] = (mode, kind, op, b1, b2)
+                if op in ('JMP', 'JSR'):
+                    work.append(b1 | (b2 << 8))
+                if mode == M_REL:
+                    work.append((a + 2 + (b1 - 256 if b1 & 0x80 else b1)) & 0xffff)
+                if op in ('JAM', 'BRK', 'RTS', 'RTI', 'JMPI', 'JMP'):
+                    break
+                a = (a + length(mode)) & 0xffff
+
+    # ---- emission ----------------------------------------------------------------------------
+    def label(self, a):
+        return 'L_%04X' % a
+
+    def goto(self, a):
+        if a in self.code:
+            return 'goto %s;' % self.label(a)
+        return '{ e.PC = 0x%04x; return; }' % a
+
+    def fallback(self, a):
+        return ['{ e.PC = 0x%04x; return; }' % a]
+
+    def emit_read_op(self, op):
+        P = 'e.P'
+        return {
+            'LDA': 'e.A = m; e.set_nz(e.A);', 'LDX': 'e.X = m; e.set_nz(e.X);', 'LDY': 'e.Y = m; e.set_nz(e.Y);',
+            'ORA': 'e.A |= m; e.set_nz(e.A);', 'AND': 'e.A &= m; e.set_nz(e.A);', 'EOR': 'e.A ^= m; e.set_nz(e.A);',
+            'ADC': 'e.adc(m);', 'SBC': 'e.sbc(m);', 'CMP': 'e.cmp(e.A, m);', 'CPX': 'e.cmp(e.X, m);',
+            'CPY': 'e.cmp(e.Y, m);',
+            'BIT': '%s = (%s & ~(FN | FV | FZ)) | (m & 0xc0) | ((e.A & m) ? 0 : FZ);' % (P, P),
+        }[op]
+
+    def emit(self, a):
+        mode, kind, op, b1, b2 = self.code[a]
+        L = []
+        nxt = (a + length(mode)) & 0xffff
+        fb = self.fallback(a)
+        if kind == K_READ:
+            pre = []
+            dc = None  # None: dynamic `dc` variable
+            if mode == M_IMM:
+                pre, dc = ['const int m = 0x%02x;' % b1], 2
+            elif mode == M_ZP:
+                if b1 < 0x80:
+                    return fb
+                pre, dc = ['const int m = e.ram_rd(0x%02x);' % (b1 & 0x7f)], 3
+            elif mode in (M_ZPX, M_ZPY):
+                idx = 'e.X' if mode == M_ZPX else 'e.Y'
+                pre = ['const int ea = (0x%02x + %s) & 0xff;' % (b1, idx),
+                       'if (!(ea & 0x80)) { --n; e.PC = 0x%04x; return; }' % a, 'const int m = e.ram_rd(ea & 0x7f);']
+                dc = 4
+            elif mode == M_ABS:
+                ea = b1 | (b2 << 8)
+                dc = 4
+                if ea & 0x1000:
+                    pre = ['const int m = 0x%02x;' % self.byte(ea)]
+                elif (ea & 0x280) == 0x80:
+                    pre = ['const int m = e.ram_rd(0x%02x);' % (ea & 0x7f)]
+                elif (ea & 0x280) == 0x280:
+                    pre, dc = ['e.cyc += 4;', 'const int m = e.riot_read(0x%04x);' % ea], 0
+                elif (ea & 0x0f) >= 8:
+                    pre, dc = ['e.cyc += 4;', 'const int m = e.tia_read(0x%04x, 0x%02x);' % (ea, b2)], 0
+                else:
+                    return fb
+            elif mode in (M_ABX, M_ABY):
+                idx = 'e.X' if mode == M_ABX else 'e.Y'
+                base = b1 | (b2 << 8)
+                pre = ['const int ea = (0x%04x + %s) & 0xffff;' % (base, idx),
+                       'int dc = 4 + (((ea ^ 0x%04x) & 0xff00) ? 1 : 0);' % base, 'int m;']
+                always_rom = (base & 0x1000) and base + 255 <= 0xffff and ((base + 255) >> 12) == (base >> 12)
+                if always_rom:
+                    pre += ['m = e.rom_byte(ea);']
+                else:
+                    pre += [
+                        'if (ea & 0x1000) m = e.rom_byte(ea);', 'else if ((ea & 0x280) == 0x80) m = e.ram_rd(ea & 0x7f);',
+                        'else if ((ea & 0x280) == 0x280) { e.cyc += dc; dc = 0; m = e.riot_read(ea); }',
+                        'else if ((ea & 0x0f) >= 8) { e.cyc += dc; dc = 0; m = e.tia_read(ea, 0x%02x); }' % b2,
+                        'else { --n; e.PC = 0x%04x; return; }' % a
+                    ]
+            elif mode == M_IZY:
+                if b1 < 0x80 or b1 == 0xff:
+                    return fb
+                pre = [
+                    'const int base = e.ram_rd(0x%02x) | (e.ram_rd(0x%02x) << 8);' % (b1 & 0x7f, (b1 + 1) & 0x7f),
+                    'const int ea = (base + e.Y) & 0xffff;', 'const int dc = 5 + (((ea ^ base) & 0xff00) ? 1 : 0);',
+                    'int m;', 'if (ea & 0x1000) m = e.rom_byte(ea);',
+                    'else if ((ea & 0x280) == 0x80) m = e.ram_rd(ea & 0x7f);', 'else { --n; e.PC = 0x%04x; return; }' % a
+                ]
+            else:
+                return fb  # (zp,X), PLA / PLP
+            L += pre
+            L.append(self.emit_read_op(op))
+            if dc is None:
+                L.append('e.cyc += dc;')
+            elif dc:
+                L.append('e.cyc += %d;' % dc)
+            return L
+        if kind == K_NONE:
+            simple = {
+                'ASL_A': 'e.P = (e.P & ~FC) | (e.A >> 7); e.A = (e.A << 1) & 0xff; e.set_nz(e.A);',
+                'LSR_A': 'e.P = (e.P & ~FC) | (e.A & 1); e.A = e.A >> 1; e.set_nz(e.A);',
+                'ROL_A': '{ const int c = e.P & FC; e.P = (e.P & ~FC) | (e.A >> 7); e.A = ((e.A << 1) | c) & 0xff; e.set_nz(e.A); }',
+                'ROR_A': '{ const int c = e.P & FC; e.P = (e.P & ~FC) | (e.A & 1); e.A = (e.A >> 1) | (c << 7); e.set_nz(e.A); }',
+                'INX': 'e.X = (e.X + 1) & 0xff; e.set_nz(e.X);', 'INY': 'e.Y = (e.Y + 1) & 0xff; e.set_nz(e.Y);',
+                'DEX': 'e.X = (e.X - 1) & 0xff; e.set_nz(e.X);', 'DEY': 'e.Y = (e.Y - 1) & 0xff; e.set_nz(e.Y);',
+                'TAX': 'e.X = e.A; e.set_nz(e.X);', 'TAY': 'e.Y = e.A; e.set_nz(e.Y);',
+                'TXA': 'e.A = e.X; e.set_nz(e.A);', 'TYA': 'e.A = e.Y; e.set_nz(e.A);',
+                'TSX': 'e.X = e.S; e.set_nz(e.X);', 'TXS': 'e.S = e.X;', 'CLC': 'e.P &= ~FC;', 'SEC': 'e.P |= FC;',
+                'CLI': 'e.P &= ~FI;', 'SEI': 'e.P |= FI;', 'CLV': 'e.P &= ~FV;', 'CLD': 'e.P &= ~FD;',
+                'SED': 'e.P |= FD;', 'NOP': '',
+            }
+            if op in simple:
+                return [simple[op], 'e.cyc += 2;']
+            if mode == M_REL:
+                flag, want = {
+                    'BPL': ('FN', 0), 'BMI': ('FN', 1), 'BVC': ('FV', 0), 'BVS': ('FV', 1), 'BCC': ('FC', 0),
+                    'BCS': ('FC', 1), 'BNE': ('FZ', 0), 'BEQ': ('FZ', 1)
+                }[op]
+                npc = (a + 2) & 0xffff
+                tgt = (npc + (b1 - 256 if b1 & 0x80 else b1)) & 0xffff
+                dc = 2 + (2 if ((tgt ^ npc) & 0xff00) else 1)
+                cond = '(e.P & %s)' % flag if want else '!(e.P & %s)' % flag
+                body = 'e.cyc += %d; ' % dc
+                if tgt <= a:  # backward edge: the only place a frame can loop without bound
+                    body += 'if (n > kNativeInstrLimit) { e.PC = 0x%04x; return; } ' % tgt
+                body += self.goto(tgt)
+                return ['if (%s) { %s }' % (cond, body), 'e.cyc += 2;']
+            if op == 'JMP':
+                tgt = b1 | (b2 << 8)
+                return ['e.cyc += 3;', 'if (n > kNativeInstrLimit) { e.PC = 0x%04x; return; }' % tgt, self.goto(tgt)]
+            return fb  # JSR / RTS / RTI / BRK / JMP () / JAM
+        # ---- stores and read-modify-writes (zero-page class only, as in step_fast) ----
+        if mode == M_ZP:
+            ea, dc, static = '0x%02x' % b1, 3, b1
+        elif mode == M_ZPX:
+            ea, dc, static = '((0x%02x + e.X) & 0xff)' % b1, 4, None
+        elif mode == M_ZPY:
+            ea, dc, static = '((0x%02x + e.Y) & 0xff)' % b1, 4, None
+        elif mode == M_PUSH:
+            ea, dc, static = 'e.S', 3, None
+        else:
+            return fb
+        if kind == K_WRITE:
+            val = {'STA': 'e.A', 'STX': 'e.X', 'STY': 'e.Y', 'PHA': 'e.A', 'PHP': '(e.P | FB | FU)'}[op]
+            dec_s = ' e.S = (e.S - 1) & 0xff;' if mode == M_PUSH else ''
+            if static is not None:
+                if static & 0x80:
+                    return ['e.ram_wr(0x%02x, %s);' % (static & 0x7f, val), 'e.cyc += %d;' % dc]
+                reg = static & 0x3f
+                if reg == 0x02:  # WSYNC
+                    return ['e.wsync(e.cyc + %d);' % dc]
+                return ['if (!e.tia_store_is_nop(0x%02x, %s)) { --n; e.PC = 0x%04x; return; }' % (reg, val, a),
+                        'e.cyc += %d;' % dc]
+            return [
+                'const int ea = %s;' % ea,
+                'if (ea & 0x80) e.ram_wr(ea & 0x7f, %s);' % val,
+                'else if (!e.tia_store_is_nop(ea & 0x3f, %s)) { --n; e.PC = 0x%04x; return; }' % (val, a),
+                ('%s e.cyc += %d;' % (dec_s, dc)).strip()
+            ]
+        # K_RMW
+        rmw = {
+            'ASL': 'e.P = (e.P & ~FC) | (m >> 7); wv = (m << 1) & 0xff;',
+            'LSR': 'e.P = (e.P & ~FC) | (m & 1); wv = m >> 1;',
+            'ROL': '{ const int c = e.P & FC; e.P = (e.P & ~FC) | (m >> 7); wv = ((m << 1) | c) & 0xff; }',
+            'ROR': '{ const int c = e.P & FC; e.P = (e.P & ~FC) | (m & 1); wv = (m >> 1) | (c << 7); }',
+            'INC': 'wv = (m + 1) & 0xff;', 'DEC': 'wv = (m - 1) & 0xff;',
+        }[op]
+        if static is not None and not (static & 0x80):
+            return fb
+        return [
+            'const int ea = %s;' % ea, 'if (!(ea & 0x80)) { --n; e.PC = 0x%04x; return; }' % a,
+            'const int m = e.ram_rd(ea & 0x7f);', 'int wv;', rmw, 'e.set_nz(wv);', 'e.ram_wr(ea & 0x7f, wv);',
+            'e.cyc += %d;' % (dc + 2)
+        ]
+
+    def source(self, game_const):
+        addrs = sorted(self.code)
+        out = []
+        crc = zlib.crc32(bytes(self.rom)) & 0xffffffff
+        out.append('// ---- %s: %d instruction blocks, rom crc32 %08x ----' % (self.name, len(addrs), crc))
+        out.append('template <> struct NativeCart<%s> { static constexpr bool present = true; '
+                   'static constexpr uint32_t rom_crc32 = 0x%08xu; };' % (game_const, crc))
+        out.append('template <> DEVI void native_run<%s>(Emu& e, int& n) {' % game_const)
+        out.append('  if (n > kNativeInstrLimit) return;')
+        out.append('  switch (e.PC) {')
+        for a in addrs:
+            out.append('    case 0x%04x: goto %s;' % (a, self.label(a)))
+        out.append('    default: return;')
+        out.append('  }')
+        native = 0
+        for i, a in enumerate(addrs):
+            mode, kind, op, b1, b2 = self.code[a]
+            body = self.emit(a)
+            is_fb = len(body) == 1 and body[0].startswith('{ e.PC')
+            native += 0 if is_fb else 1
+            out.append('  %s: {  // %s mode %d' % (self.label(a), op, mode))
+            if is_fb:
+                out.append('    ' + body[0])
+            else:
+                out.append('    ++n;')
+                for ln in body:
+                    if ln:
+                        out.append('    ' + ln)
+            out.append('  }')
+            nxt = (a + length(mode)) & 0xffff
+            terminal = op in ('JMP', 'JAM', 'BRK', 'RTS', 'RTI', 'JMPI', 'JSR') or is_fb
+            if not terminal and nxt not in self.code:
+                out.append('  { e.PC = 0x%04x; return; }' % nxt)
+            elif not terminal and (i + 1 >= len(addrs) or addrs[i + 1] != nxt):
+                out.append('  goto %s;' % self.label(nxt))
+        out.append('}')
+        out.insert(1, '// natively translated: %d, deferred to the interpreter: %d' % (native, len(addrs) - native))
+        return '\n'.join(out)
+
+
+HEADER = '''// cart_native.gen.hpp — GENERATED by gen_cart_native.py from the cartridges in roms/ (do not edit,
+// do not commit: derived from user-supplied ROM data).  Included by atari_core.hpp.
+#pragma once
+'''
+
+
+def main():
+    out_path = sys.argv[1]
+    parts = [HEADER]
+    consts = {'pong': 'GAME_PONG', 'breakout': 'GAME_BREAKOUT'}
+    for spec in sys.argv[2:]:
+        name, path = spec.split('=', 1)
+        try:
+            rom = open(path, 'rb').read()
+        except OSError:
+            continue
+        parts.append(Cart(name, rom).source(consts[name]))
+    text = '\n'.join(parts) + '\n'
+    try:
+        if open(out_path).read() == text:
+            return
+    except OSError:
+        pass
+    open(out_path, 'w').write(text)
+
+
+if __name__ == '__main__':
+    main()

@@ -73,3 +73,41 @@ def test_a2c_rollout_matches_per_segment_calc_gae(dev, oracle):
     alg = parl.algorithms.A2C(model, vf_loss_coeff=0.5)
     total, pi, vf, ent = alg.learn(b['obs'], b['actions'], b['advantages'], b['target_values'], 1e-4, -0.01)
     assert np.isfinite(float(total))
+
+
+def test_async_actor_learner_pipeline(dev):
+    """AsyncActorLearner (learner update on batch i-1 overlapped with the collection of batch i on
+    a second stream): the first batch is bit-identical to a plain DeviceRollout's, the behaviour
+    policy lags the learner by exactly one update, the two trajectory buffers alternate."""
+    import copy
+    import parl_amd as parl
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel42
+    from parl_amd.rollout import AsyncActorLearner, DeviceRollout
+    torch.manual_seed(0)
+    E, T = 16, 8
+    model = AtariModel42(6).to(dev)
+    ref_model = copy.deepcopy(model)
+    mk = lambda: DeviceVectorEnv('PongNoFrameskip-v4', E, dim=42, horizon=T, seed=11, device=dev)
+    alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
+                                 clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+    pipe = AsyncActorLearner(alg, mk(), T, seed=5)
+    pipe.prime()
+    pipe.synchronize()
+    b0 = {k: v.clone() for k, v in pipe.pending[0].items()}
+    ref = DeviceRollout(mk(), T, seed=5).collect(ref_model)
+    for k in ref:
+        assert torch.equal(b0[k], ref[k]), k
+    used = [pipe.pending[1]]
+    for i in range(3):
+        before = [p.detach().clone() for p in model.parameters()]
+        loss, kl = pipe.step(1e-3, -0.01)
+        used.append(pipe.pending[1])
+        pipe.synchronize()
+        assert np.isfinite(float(loss.total_loss.item()))
+        # the rollout enqueued by this step() acted with the parameters from BEFORE this update
+        for a, b in zip(pipe.actor_model.parameters(), before):
+            assert torch.equal(a, b)
+        assert any(not torch.equal(p, b) for p, b in zip(model.parameters(), before))
+    assert used == [0, 1, 0, 1]
+    pipe.env.check_faults()
