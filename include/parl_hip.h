@@ -194,9 +194,16 @@ size_t parlhip_atari_frame_bytes(void);       /* per-env raw frame pair (device)
 size_t parlhip_atari_rom_table_bytes(uint32_t rom_size);
 size_t parlhip_atari_reset_cache_bytes(void); /* 30 reset snapshots (device)                 */
 int parlhip_atari_num_actions(int game);      /* ALE minimal action set size                 */
-/* HOST: pre-decode an unbanked 2K/4K cartridge into one 32-bit word per address.             */
+/* HOST: pre-decode an unbanked 2K/4K cartridge into one 32-bit word per address.  When the     */
+/* library carries natively translated code for exactly this cartridge (CRC-32 match, see        */
+/* parlhip_atari_native_cart) the table is tagged and the env kernel runs the translated code,   */
+/* otherwise it interprets; results are identical either way.                                    */
 int parlhip_atari_rom_table_build(const uint8_t* rom_host, uint32_t rom_size,
                                   uint32_t* table_host);
+/* CRC-32 of the cartridge whose program was statically translated to gfx950 code for `game`     */
+/* when the library was built (csrc/gen_cart_native.py; stands for the ALE core's interpreter    */
+/* loop behind gym.make, examples/IMPALA/actor.py:34), or 0 if the library only interprets.      */
+uint32_t parlhip_atari_native_cart(int game);
 /* Build the 30 real-reset snapshots (noop count 1..30) on the device.  jam_flag_dev: int32
  * word OR-ed with emulator fault bits (undocumented opcode etc.); 0 = clean.                 */
 int parlhip_atari_reset_cache_build(const uint32_t* rom_table_dev, uint32_t rom_size, int game,

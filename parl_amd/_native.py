@@ -53,6 +53,7 @@ SIGNATURES = {
     'parlhip_atari_rom_table_bytes': (_sz, [ctypes.c_uint32]),
     'parlhip_atari_reset_cache_bytes': (_sz, []),
     'parlhip_atari_num_actions': (_i, [_i]),
+    'parlhip_atari_native_cart': (ctypes.c_uint32, [_i]),
     'parlhip_atari_rom_table_build': (_i, [_p, ctypes.c_uint32, _p]),
     'parlhip_atari_reset_cache_build': (_i, [_p, ctypes.c_uint32, _i, _i64, _p, _p, _p]),
     'parlhip_atari_vec_reset':

@@ -396,6 +396,12 @@ PARLHIP_EXPORT int parlhip_atari_rom_table_build(const uint8_t* rom_host, uint32
   return PARLHIP_OK;
 }
 
+PARLHIP_EXPORT uint32_t parlhip_atari_native_cart(int game) {
+  if (game == GAME_PONG && NativeCart<GAME_PONG>::present) return NativeCart<GAME_PONG>::rom_crc32;
+  if (game == GAME_BREAKOUT && NativeCart<GAME_BREAKOUT>::present) return NativeCart<GAME_BREAKOUT>::rom_crc32;
+  return 0;
+}
+
 PARLHIP_EXPORT int parlhip_atari_num_actions(int game) {
   return game == GAME_BREAKOUT ? 4 : (game == GAME_PONG ? 6 : -1);
 }

@@ -43,7 +43,7 @@ def find_rom(name, rom_dir=None):
 
 class DeviceVectorEnv(object):
     def __init__(self, env_name, num_envs, dim=84, horizon=1, seed=0, env_id0=0, device=None,
-                 rom_dir=None, max_episode_steps=400000, use_reset_cache=True, rom_bytes=None):
+                 rom_dir=None, max_episode_steps=400000, use_reset_cache=True, rom_bytes=None, native=True):
         if env_name not in GAMES:
             raise ValueError('unsupported env %r (have %s)' % (env_name, sorted(GAMES)))
         name, self.game, md5 = GAMES[env_name]
@@ -66,6 +66,10 @@ class DeviceVectorEnv(object):
         rom_np = np.frombuffer(rom, np.uint8)
         N.check(L.parlhip_atari_rom_table_build(rom_np.ctypes.data, self.rom_size, table.ctypes.data),
                 'parlhip_atari_rom_table_build')
+        if not native:  # A/B and tests: run the 6507 interpreter even if translated code exists
+            table[0] &= 0x0fffffff
+        # True when the env kernel runs this cartridge as translated native code (else interpreted)
+        self.native = int(table[0] >> 28) == self.game
         self.rom_table = torch.from_numpy(table.view(np.int32)).to(dev)
         # --- per-env state, raw frame pairs, per-step outputs
         self.states = torch.zeros(E * L.parlhip_atari_state_bytes(), **u8)

@@ -76,3 +76,29 @@ def test_no_oracle_in_product():
             if fn.endswith(('.py', '.hip', '.hpp', '.cpp', '.h', 'Makefile')):
                 s = open(os.path.join(d, fn)).read()
                 assert not bad.search(s), '%s references the oracle' % os.path.join(d, fn)
+
+
+def test_native_cartridge_translation_is_built_and_tagged(built_lib):
+    """When roms/ holds the cartridges, the library is built with their statically translated
+    code (csrc/gen_cart_native.py) and parlhip_atari_rom_table_build tags exactly those ROMs; a
+    modified ROM is not tagged (it would be interpreted).  Host-only: no GPU needed."""
+    import zlib
+    import numpy as np
+    from parl_amd import _native
+    lib = _native.lib()
+    for name, game in (('pong', 1), ('breakout', 2)):
+        path = os.path.join(ROOT, 'roms', name + '.bin')
+        if not os.path.exists(path):
+            pytest.skip('no cartridges in roms/')
+        rom = np.frombuffer(open(path, 'rb').read(), np.uint8).copy()
+        assert lib.parlhip_atari_native_cart(game) == (zlib.crc32(rom.tobytes()) & 0xffffffff)
+        table = np.zeros(len(rom), np.uint32)
+        assert lib.parlhip_atari_rom_table_build(rom.ctypes.data, len(rom), table.ctypes.data) == 0
+        assert int(table[0] >> 28) == game
+        assert np.all(table[1:] >> 28 == 0)
+        # decode fields untouched by the tag: b1/b2 are the next two ROM bytes
+        assert int(table[0] & 0xff) == rom[1] and int((table[0] >> 8) & 0xff) == rom[2]
+        rom[100] ^= 0xff
+        assert lib.parlhip_atari_rom_table_build(rom.ctypes.data, len(rom), table.ctypes.data) == 0
+        assert int(table[0] >> 28) == 0
+    assert lib.parlhip_atari_native_cart(0) == 0
