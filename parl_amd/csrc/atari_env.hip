@@ -114,6 +114,9 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
   __shared__ uint32_t rom_lds[kMaxRomWords];
   for (int i = threadIdx.x; i < prm.rom_size; i += blockDim.x) rom_lds[i] = romw_g[i];
   __syncthreads();
+  // One wavefront per env is a long serial dependency chain: when other kernels (the learner's
+  // GEMMs on another stream) share the SIMD, this wave should win every issue arbitration.
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63;
   const int wave = rfl((int)(threadIdx.x >> 6));
   const int e = blockIdx.x * kEnvsPerBlock + wave;

@@ -175,8 +175,9 @@ class AsyncActorLearner(object):
         for p in self.actor_model.parameters():
             p.requires_grad_(False)
         dev = env.device
-        self.actor_stream = torch.cuda.Stream(device=dev)
-        self.learn_stream = torch.cuda.Stream(device=dev)
+        # the rollout is the critical path (latency-bound emulator): high-priority queue for it
+        self.actor_stream = torch.cuda.Stream(device=dev, priority=-1)
+        self.learn_stream = torch.cuda.Stream(device=dev, priority=0)
         self.weights_ready = torch.cuda.Event()
         self.snapshot_done = torch.cuda.Event()
         self.batch_ready = [torch.cuda.Event(), torch.cuda.Event()]
