@@ -126,6 +126,7 @@ def main():
     ap.add_argument('--sample-batch-steps', type=int, default=50)
     ap.add_argument('--game', default='PongNoFrameskip-v4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--actor-groups', type=int, default=2, help='env groups (actor streams) per GPU')
     ap.add_argument('--no-overlap', action='store_true',
                     help='run rollout and learner update back to back on one stream instead of overlapped')
     args = ap.parse_args()
@@ -142,7 +143,15 @@ def main():
     # reference config: examples/IMPALA/impala_config.py:15-46
     cfg = dict(gamma=0.99, vf_loss_coeff=0.5, clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0,
                lr_scheduler=[(0, 0.001), (20000, 0.0005), (40000, 0.0001)], entropy_coeff_scheduler=[(0, -0.01)])
-    env = DeviceVectorEnv(args.game, E, dim=dim, horizon=T, seed=1234, env_id0=rank * E, device=dev)
+    # env groups: the E envs of this GPU are stepped as G independent groups on G streams so that one
+    # group's policy forward overlaps the other groups' emulator kernels (env ids / RNG streams are
+    # those of a single E-env vector)
+    G = 1 if args.no_overlap else max(1, args.actor_groups)
+    assert E % G == 0
+    Eg = E // G
+    envs = [DeviceVectorEnv(args.game, Eg, dim=dim, horizon=T, seed=1234, env_id0=rank * E + g * Eg, device=dev)
+            for g in range(G)]
+    env = envs[0]
     model = (AtariModel42 if dim == 42 else AtariModel84)(env.act_dim).to(dev)
     alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=cfg['gamma'], vf_loss_coeff=cfg['vf_loss_coeff'],
                                  clip_rho_threshold=cfg['clip_rho_threshold'],
@@ -155,10 +164,10 @@ def main():
 
     vt_timer = KernelTimer()
     ops.vtrace_from_logits = vt_timer.wrap(ops.vtrace_from_logits)
-    env_timer = KernelTimer()
-    env.step_async = env_timer.wrap(env.step_async)
-    fp_timer = KernelTimer()
-    env._frame_post = fp_timer.wrap(env._frame_post)
+    env_timer, fp_timer = KernelTimer(), KernelTimer()
+    for e in envs:
+        e.step_async = env_timer.wrap(e.step_async)
+        e._frame_post = fp_timer.wrap(e._frame_post)
 
     if args.no_overlap:
         pipe = None
@@ -175,16 +184,16 @@ def main():
     else:
         # IMPALA's actor/learner decoupling on one GPU: the learner update on batch i-1 runs on its
         # own stream while the actors collect batch i (behaviour policy lags by one update)
-        pipe = AsyncActorLearner(alg, env, T, seed=99)
+        pipe = AsyncActorLearner(alg, envs, T, seed=99)
         rollout = pipe.rollout
         pipe.prime()  # untimed: every timed step = one rollout + one learner update
 
         def step():
             loss, kl = pipe.step(lr_s.step(), ent_s.step())
             if world > 1:
-                with torch.cuda.stream(pipe.actor_stream):
-                    pdist.all_gather_small({'rewards': rollout.rewards, 'dones': rollout.dones,
-                                            'actions': rollout.actions})
+                for st, ro in zip(pipe.actor_streams, pipe.rollouts):
+                    with torch.cuda.stream(st):
+                        pdist.all_gather_small({'rewards': ro.rewards, 'dones': ro.dones, 'actions': ro.actions})
             return loss
 
     for _ in range(args.warmup):
@@ -198,7 +207,8 @@ def main():
     pdist.barrier()
     torch.cuda.synchronize()
     dt = pdist.all_reduce_max_scalar(time.time() - t0)
-    env.check_faults()
+    for e in envs:
+        e.check_faults()
     total_loss = float(loss.total_loss.item())
     assert np.isfinite(total_loss)
 
@@ -221,7 +231,7 @@ def main():
             'workload': 'BASELINE configs[2]: PongNoFrameskip-v4 IMPALA V-trace, %d actors per GPU' % E,
             'envs_per_gpu': E, 'sample_batch_steps': T, 'obs_dim': dim, 'train_batch': T * E * world,
             'frame_skip': 4, 'parallelism': 'dp%d (envs sharded by rank, grad all-reduce)' % world,
-            'actor_learner_overlap': not args.no_overlap,
+            'actor_learner_overlap': not args.no_overlap, 'actor_groups': G,
         },
         'learner_updates_per_sec': K / dt,
         'agent_steps_per_sec': K * T * E * world / dt,
@@ -230,9 +240,10 @@ def main():
         # --- roofline of the V-trace kernel at the workload shape (HBM-bound scan) ---
         A = env.act_dim
         vt = vt_timer.mean_seconds()
-        by = T * E * (2 * A * 4 + 8 + 4 + 1 + 4 + 8)  # 73 B/elt at A=6, fused from logits
+        by = T * Eg * (2 * A * 4 + 8 + 4 + 1 + 4 + 8)  # 73 B/elt at A=6, fused from logits
         out['roofline'] = {
-            'kernel': 'vtrace_logits_tm_kernel (fused log-prob gather + V-trace, T=%d B=%d A=%d)' % (T, E, A),
+            'kernel': 'vtrace_logits_tm_kernel (fused log-prob gather + V-trace, T=%d B=%d A=%d; %d launch(es) per '
+                      'update, one per actor group)' % (T, Eg, A, G),
             'bound': 'hbm', 'achieved': by / vt / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
             'frac': by / vt / 1e9 / HBM_PEAK_GBPS, 'traffic': None, 'bytes_per_launch': by,
             'note': 'workload shape is %.1f MB: launch-latency-bound by construction (SURVEY §8d); '
@@ -260,16 +271,16 @@ def main():
         out['roofline_saturating'].update(pmc_traffic('vtrace_T127_B262144'))
         del x
         fps = fp_timer.mean_seconds()
-        fpb = E * (2 * 33600 + dim * dim)  # two colour frames read, dim^2 written per env-step
+        fpb = Eg * (2 * 33600 + dim * dim)  # two colour frames read, dim^2 written per env-step
         out['roofline_frame_post'] = {
-            'kernel': 'frame_post_kernel + since_update_kernel (max-2, gray, INTER_AREA %dx%d, E=%d)' % (dim, dim, E),
+            'kernel': 'frame_post_kernel + since_update_kernel (max-2, gray, INTER_AREA %dx%d, E=%d)' % (dim, dim, Eg),
             'bound': 'hbm', 'achieved': fpb / fps / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
             'frac': fpb / fps / 1e9 / HBM_PEAK_GBPS, 'traffic': None, 'bytes_per_launch': fpb,
         }
         es = env_timer.mean_seconds()
         out['kernels'] = {
-            'env_step_ms (atari_env_kernel + frame_post + since_update, one agent step of %d envs)' % E: es * 1e3,
-            'env_only_frames_per_sec_per_gpu': 4 * E / es,
+            'env_step_ms (atari_env_kernel + frame_post + since_update, one agent step of one %d-env group; %d '
+            'groups run concurrently)' % (Eg, G): es * 1e3,
             'note': 'atari_env_kernel is instruction/latency-bound (serial 6507 per wavefront): no roofline fraction',
         }
         if not args.no_cpu_baseline and world == 1:

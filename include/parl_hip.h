@@ -241,6 +241,26 @@ int parlhip_stack_gather_u8(const uint8_t* ring, const uint8_t* since, int E, in
                             const int32_t* slots, const int32_t* envs, int64_t n, uint8_t* out,
                             parlhip_stream_t stream);
 
+/* MonitorEnv.next_episode_results (atari_wrappers.py:88-95) reduced on the device: for the
+ * episodes parlhip_atari_vec_step reported closed this step (ep_lengths[e] > 0):
+ * acc3[0] += count, acc3[1] += sum of unclipped returns, acc3[2] += sum of lengths (f64).   */
+int parlhip_episode_stats_accum_f64(const float* ep_returns, const int32_t* ep_lengths, int E,
+                                    double* acc3, parlhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Actor-side network trunk: conv1 + conv2 of the IMPALA Atari model on the matrix cores
+ * ------------------------------------------------------------------------------------ */
+/* examples/IMPALA/atari_model.py:59-71 (AtariModel.policy/value trunk), first two layers:
+ * x = obs / 255; conv1 4->16 k4 s2 p1 + ReLU (42x42 -> 21x21); conv2 16->32 k4 s2 p2 + ReLU
+ * (-> 11x11).  obs u8 [n,4,42,42] (the stacked observations of the rollout ring), w1 f32
+ * [16,4,4,4], b1 [16], w2 f32 [32,16,4,4], b2 [32] (nn.Conv2d / paddle Conv2D layout), out f32
+ * [n, 32*11*11] in NCHW flatten order (the input of conv3 = a 3872->256 linear layer).
+ * Inference only (no gradient): the actors' forward pass.  One fused MFMA kernel, nothing but
+ * obs in / activations out touches HBM.                                                      */
+int parlhip_atari42_conv12_u8_f32(const uint8_t* obs, const float* w1, const float* b1,
+                                  const float* w2, const float* b2, float* out, int n_obs,
+                                  parlhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,14 +95,8 @@ class IMPALA(Algorithm):
             return self.model.policy_and_value(obs)
         return self.model.policy(obs), self.model.value(obs)
 
-    def learn(self, obs, actions, behaviour_logits, rewards, dones, learning_rate, entropy_coeff,
-              time_major=False):
-        """Reference contract (impala.py:134-215): flat batches of N = B*T rows, ENV-major
-        ([env0 t0..tT-1, env1 ...], examples/IMPALA/actor.py:78-89).  time_major=True takes the
-        device rollout layout instead (rows ordered [t0 all envs, t1 all envs, ...]).
-
-        obs [N,C,H,W] (uint8 or float32), actions int64 [N], behaviour_logits f32 [N,A],
-        rewards f32 [N], dones bool [N].  Returns (vtrace_loss, kl)."""
+    def _vtrace_loss(self, obs, actions, behaviour_logits, rewards, dones, entropy_coeff, time_major):
+        """forward pass + fused V-trace + loss terms for one flat batch (no parameter update)"""
         T = self.sample_batch_steps
         N = obs.shape[0]
         B = N // T
@@ -127,15 +121,50 @@ class IMPALA(Algorithm):
         # drop the last step of every sequence: it only supplies the bootstrap (impala.py:186-194)
         vtrace_loss = _FusedVTraceLoss(vs, pg_adv, cut(target_actions_log_probs), cut(values), cut(policy_entropy),
                                        entropy_coeff, self.vf_loss_coeff)
-        for g in self.optimizer.param_groups:
-            g['lr'] = learning_rate
-        self.optimizer.zero_grad(set_to_none=True)
-        vtrace_loss.total_loss.backward()
+        return vtrace_loss, kl
+
+    def _apply_gradients(self, learning_rate):
         if self.grad_hook is not None:
             self.grad_hook(self.model)  # e.g. RCCL all-reduce (sum) of the flattened gradient
+        for g in self.optimizer.param_groups:
+            g['lr'] = learning_rate
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.grad_clip_norm)
         self.optimizer.step()
+
+    def learn(self, obs, actions, behaviour_logits, rewards, dones, learning_rate, entropy_coeff,
+              time_major=False):
+        """Reference contract (impala.py:134-215): flat batches of N = B*T rows, ENV-major
+        ([env0 t0..tT-1, env1 ...], examples/IMPALA/actor.py:78-89).  time_major=True takes the
+        device rollout layout instead (rows ordered [t0 all envs, t1 all envs, ...]).
+
+        obs [N,C,H,W] (uint8 or float32), actions int64 [N], behaviour_logits f32 [N,A],
+        rewards f32 [N], dones bool [N].  Returns (vtrace_loss, kl)."""
+        vtrace_loss, kl = self._vtrace_loss(obs, actions, behaviour_logits, rewards, dones, entropy_coeff, time_major)
+        self.optimizer.zero_grad(set_to_none=True)
+        vtrace_loss.total_loss.backward()
+        self._apply_gradients(learning_rate)
         return vtrace_loss, kl
+
+    def learn_batches(self, batches, learning_rate, entropy_coeff, time_major=False):
+        """ONE parameter update on the union of several flat batches (dicts with the arguments of
+        learn()).  The losses are sums over rows (impala.py:67-79), so the gradient of the union is
+        the sum of the per-batch gradients: each batch is forwarded / backpropagated on its own
+        (accumulating into .grad), then clip + Adam run once.  Used by the multi-group actor
+        pipeline, whose groups deliver their trajectories in separate buffers."""
+        self.optimizer.zero_grad(set_to_none=True)
+        out, kls = None, []
+        for b in batches:
+            loss, kl = self._vtrace_loss(b['obs'], b['actions'], b['behaviour_logits'], b['rewards'], b['dones'],
+                                         entropy_coeff, time_major)
+            loss.total_loss.backward()
+            kls.append(kl)
+            if out is None:
+                out = loss
+            else:  # report the sums over the union, like one big batch would
+                for k in ('total_loss', 'pi_loss', 'vf_loss', 'entropy'):
+                    setattr(out, k, getattr(out, k).detach() + getattr(loss, k).detach())
+        self._apply_gradients(learning_rate)
+        return out, torch.stack(kls).mean()
 
     @torch.no_grad()
     def sample(self, obs):

@@ -127,6 +127,20 @@ __global__ void since_update_kernel(const uint8_t* __restrict__ flags,
   since_next[e] = (flags[e] & 2) ? 0 : (uint8_t)(p + 1 > 3 ? 3 : p + 1);
 }
 
+// MonitorEnv bookkeeping reduced on the device: acc[0] += #episodes closed this step,
+// acc[1] += their unclipped returns, acc[2] += their lengths (few lanes ever take the atomics)
+__global__ void episode_stats_kernel(const float* __restrict__ ep_returns, const int* __restrict__ ep_lengths,
+                                     int E, double* __restrict__ acc) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int len = ep_lengths[e];
+  if (len > 0) {
+    atomicAdd(acc + 0, 1.0);
+    atomicAdd(acc + 1, (double)ep_returns[e]);
+    atomicAdd(acc + 2, (double)len);
+  }
+}
+
 }  // namespace atari
 }  // namespace parlhip
 
@@ -237,5 +251,14 @@ PARLHIP_EXPORT int parlhip_stack_gather_u8(const uint8_t* ring, const uint8_t* s
   if (n * 4 > 0x7fffffffLL) return PARLHIP_ENOSUP;
   stack_gather_kernel<<<(unsigned)(n * 4), 256, 0, (hipStream_t)stream>>>(ring, since, E, frame_bytes, slots,
                                                                           envs, n, out);
+  return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_episode_stats_accum_f64(const float* ep_returns, const int32_t* ep_lengths, int E,
+                                                   double* acc3, parlhip_stream_t stream) {
+  if (E < 0) return PARLHIP_EINVAL;
+  if (E == 0) return PARLHIP_OK;
+  if (!ep_returns || !ep_lengths || !acc3) return PARLHIP_EINVAL;
+  episode_stats_kernel<<<ceil_div(E, 256), 256, 0, (hipStream_t)stream>>>(ep_returns, ep_lengths, E, acc3);
   return check_launch();
 }

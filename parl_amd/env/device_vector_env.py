@@ -92,6 +92,7 @@ class DeviceVectorEnv(object):
         self.since = torch.zeros((self.slots, E), **u8)
         self.t = 0
         self._env_idx = torch.arange(E, dtype=torch.int32, device=dev)
+        self._slot_const = {}
         # --- O(1) real resets
         self.reset_cache = None
         if use_reset_cache:
@@ -128,8 +129,18 @@ class DeviceVectorEnv(object):
         return out
 
     def current_obs(self, out=None):
-        slots = torch.full((self.envs_num, ), self.t + 3, dtype=torch.int32, device=self.device)
+        slots = self._slot_const.get(self.t)
+        if slots is None:  # one constant index tensor per ring position, made once
+            slots = torch.full((self.envs_num, ), self.t + 3, dtype=torch.int32, device=self.device)
+            self._slot_const[self.t] = slots
         return self.gather(slots, self._env_idx, out)
+
+    def accumulate_episode_stats(self, acc3):
+        """acc3 (f64 [3] on the device) += (episodes closed by the last step, their unclipped
+        returns, their lengths) — MonitorEnv.next_episode_results without a host round trip."""
+        N.check(
+            N.lib().parlhip_episode_stats_accum_f64(N.ptr(self.ep_returns), N.ptr(self.ep_lengths), self.envs_num,
+                                                    N.ptr(acc3), N.stream_ptr()), 'parlhip_episode_stats_accum_f64')
 
     # ---------------------------------------------------------------- VectorEnv contract
     def reset(self):

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from ..core import Model
 
 __all__ = ['AtariModel42', 'AtariModel84', 'GemmConv2d']
@@ -59,6 +60,11 @@ class AtariModel42(Model):
             nn.init.normal_(fc.bias, 0.0, 1.0)
 
     def _trunk(self, obs):
+        if (not torch.is_grad_enabled()) and obs.dtype == torch.uint8 and obs.is_cuda and obs.shape[0] > 0:
+            # the actors' path (no autograd): conv1+conv2 as one fused MFMA kernel on the uint8
+            # observations (ops.atari42_conv12), conv3 is a 3872 -> 256 linear layer
+            h = ops.atari42_conv12(obs, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
+            return F.relu(F.linear(h, self.conv3.weight.flatten(1), self.conv3.bias))
         x = obs.float() / 255.0
         x = F.relu(self.conv1(x))
         x = F.relu(self.conv2(x))
@@ -67,6 +73,11 @@ class AtariModel42(Model):
 
     def policy(self, obs):
         return self.policy_fc(self._trunk(obs))
+
+    @torch.no_grad()
+    def policy_into(self, obs, out):
+        """policy(obs) written straight into `out` (a [E, A] slab of a rollout buffer)"""
+        return torch.addmm(self.policy_fc.bias, self._trunk(obs), self.policy_fc.weight.t(), out=out)
 
     def value(self, obs):
         return self.value_fc(self._trunk(obs)).squeeze(1)

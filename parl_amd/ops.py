@@ -227,6 +227,25 @@ def policy_sample_into(logits, actions_out, seed, offset, row0=0):
     return actions_out
 
 
+def atari42_conv12(obs, conv1_weight, conv1_bias, conv2_weight, conv2_bias, out=None):
+    """conv1 + ReLU + conv2 + ReLU of the IMPALA Atari network (examples/IMPALA/atari_model.py:59-71)
+    for uint8 observations [n,4,42,42], as ONE fused MFMA kernel (inference only).  Returns f32
+    [n, 3872] = the NCHW-flattened [n,32,11,11] activation."""
+    if obs.dtype != torch.uint8 or obs.dim() != 4 or tuple(obs.shape[1:]) != (4, 42, 42):
+        raise N.ParlHipError('atari42_conv12: obs must be uint8 [n,4,42,42]')
+    if tuple(conv1_weight.shape) != (16, 4, 4, 4) or tuple(conv2_weight.shape) != (32, 16, 4, 4):
+        raise N.ParlHipError('atari42_conv12: weights must be [16,4,4,4] and [32,16,4,4]')
+    n = obs.shape[0]
+    if out is None:
+        out = torch.empty((n, 32 * 11 * 11), dtype=torch.float32, device=obs.device)
+    w1, b1 = _f32(conv1_weight.detach(), 'conv1_weight'), _f32(conv1_bias.detach(), 'conv1_bias')
+    w2, b2 = _f32(conv2_weight.detach(), 'conv2_weight'), _f32(conv2_bias.detach(), 'conv2_bias')
+    N.check(
+        N.lib().parlhip_atari42_conv12_u8_f32(N.ptr(obs.contiguous()), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(b2),
+                                             N.ptr(out), n, N.stream_ptr()), 'parlhip_atari42_conv12_u8_f32')
+    return out
+
+
 def consume_device_errors():
     """Synchronise and return/clear the device-side data-error flag (bad action index)."""
     return N.check(N.lib().parlhip_consume_device_errors(N.stream_ptr()),

@@ -38,10 +38,9 @@ class DeviceRollout(object):
         self._slots = (torch.arange(T, dtype=torch.int32, device=dev) + 3).repeat_interleave(E)
         self._envs = torch.arange(E, dtype=torch.int32, device=dev).repeat(T)
         self.step_count = 0  # Philox offset: one uniform per (global step, env)
-        # MonitorEnv statistics (atari_wrappers.py:44-100), reduced on the device
-        self.ep_count = torch.zeros((), dtype=torch.float64, device=dev)
-        self.ep_return_sum = torch.zeros((), dtype=torch.float64, device=dev)
-        self.ep_length_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        # MonitorEnv statistics (atari_wrappers.py:44-100), reduced on the device:
+        # (episodes closed, sum of unclipped returns, sum of lengths)
+        self.ep_stats = torch.zeros(3, dtype=torch.float64, device=dev)
         self.started = False
 
     def _select(self, k):
@@ -50,8 +49,7 @@ class DeviceRollout(object):
         self.rewards, self.dones, self.obs = b['rewards'], b['dones'], b['obs']
 
     @torch.no_grad()
-    def collect(self, model):
-        """Run T env steps with `model` as behaviour policy; returns the time-major batch."""
+    def collect_begin(self):
         env = self.env
         self._cur = (self._cur + 1) % len(self._bufs)
         self._select(self._cur)
@@ -60,17 +58,24 @@ class DeviceRollout(object):
             self.started = True
         else:
             env.roll()
-        for t in range(self.T):
-            obs = env.current_obs(self._obs_step)
-            logits = model.policy(obs)
-            self.behaviour_logits[t].copy_(logits)
-            ops.policy_sample_into(logits, self.actions[t], self.seed, self.step_count, env.env_id0)
-            env.step_async(self.actions[t], self.rewards[t], self.dones[t])
-            closed = env.ep_lengths > 0
-            self.ep_count += closed.sum()
-            self.ep_return_sum += (env.ep_returns * closed).sum()
-            self.ep_length_sum += (env.ep_lengths * closed).sum()
-            self.step_count += 1
+
+    @torch.no_grad()
+    def collect_step(self, model, t):
+        env = self.env
+        obs = env.current_obs(self._obs_step)
+        logits = self.behaviour_logits[t]
+        if hasattr(model, 'policy_into'):
+            model.policy_into(obs, logits)  # the head's GEMM writes the [E, A] slab directly
+        else:
+            logits.copy_(model.policy(obs))
+        ops.policy_sample_into(logits, self.actions[t], self.seed, self.step_count, env.env_id0)
+        env.step_async(self.actions[t], self.rewards[t], self.dones[t])
+        env.accumulate_episode_stats(self.ep_stats)
+        self.step_count += 1
+
+    @torch.no_grad()
+    def collect_end(self):
+        env = self.env
         env.gather(self._slots, self._envs, self.obs)
         E = env.envs_num
         return {
@@ -81,14 +86,17 @@ class DeviceRollout(object):
             'dones': self.dones.reshape(self.T * E).bool(),
         }
 
+    def collect(self, model):
+        """Run T env steps with `model` as behaviour policy; returns the time-major batch."""
+        self.collect_begin()
+        for t in range(self.T):
+            self.collect_step(model, t)
+        return self.collect_end()
+
     def pop_episode_stats(self):
         """(episodes closed, mean unclipped return, mean length in emulated frames); syncs."""
-        n = float(self.ep_count.item())
-        r = float(self.ep_return_sum.item())
-        l = float(self.ep_length_sum.item())
-        self.ep_count.zero_()
-        self.ep_return_sum.zero_()
-        self.ep_length_sum.zero_()
+        n, r, l = (float(x) for x in self.ep_stats.tolist())
+        self.ep_stats.zero_()
         return n, (r / n if n else None), (l / n if n else None)
 
 
@@ -118,9 +126,7 @@ class DeviceA2CRollout(object):
         self._slots = (torch.arange(T, dtype=torch.int32, device=dev) + 3).repeat_interleave(E)
         self._envs = torch.arange(E, dtype=torch.int32, device=dev).repeat(T)
         self.step_count = 0
-        self.ep_count = torch.zeros((), dtype=torch.float64, device=dev)
-        self.ep_return_sum = torch.zeros((), dtype=torch.float64, device=dev)
-        self.ep_length_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.ep_stats = torch.zeros(3, dtype=torch.float64, device=dev)
         self.started = False
 
     @torch.no_grad()
@@ -137,10 +143,7 @@ class DeviceA2CRollout(object):
             self.values[t].copy_(values)
             ops.policy_sample_into(logits, self.actions[t], self.seed, self.step_count, env.env_id0)
             env.step_async(self.actions[t], self.rewards[t], self.dones[t])
-            closed = env.ep_lengths > 0
-            self.ep_count += closed.sum()
-            self.ep_return_sum += (env.ep_returns * closed).sum()
-            self.ep_length_sum += (env.ep_lengths * closed).sum()
+            env.accumulate_episode_stats(self.ep_stats)
             self.step_count += 1
         next_value = model.value(env.current_obs(self._obs_step))  # ignored where the last step was terminal
         adv, target = ops.gae(self.rewards, self.values, self.dones, next_value, self.gamma, self.lam)
@@ -156,37 +159,49 @@ class AsyncActorLearner(object):
     """IMPALA's actor / learner decoupling (examples/IMPALA/train.py:155-194: sample threads fill a
     queue while the learn thread drains it; actors act with parameters that lag the learner by up
     to `params_broadcast_interval` updates and V-trace corrects for the lag) on ONE GPU:
-    two HIP streams instead of threads and processes.
+    HIP streams instead of threads and processes.
 
-      actor stream    weights snapshot -> T env steps (policy fwd, sample, emulator, frame_post) -> batch i
-      learner stream  IMPALA.learn on batch i-1 (fwd, fused V-trace, bwd, [all-reduce], clip, Adam)
+      actor stream g  weights snapshot -> T env steps of env group g (policy fwd, sample, emulator,
+                      frame_post) -> batch i of group g
+      learner stream  ONE update on the union of the groups' batches i-1 (fwd, fused V-trace, bwd
+                      per group, accumulated; [all-reduce], clip, Adam once)
 
-    Both are enqueued by one host thread; events order them.  The emulator kernel keeps one
-    wavefront per SIMD busy and is latency-bound, so the learner's GEMMs run in the issue slots it
-    leaves free.  The actor's parameter snapshot plays the role of the reference actor's
-    `set_weights` (actor.py:103-104): it is refreshed from the learner before every rollout, so the
-    behaviour policy lags the learner by exactly one update."""
+    All of it is enqueued by one host thread; events order the streams.  The emulator kernel keeps
+    one wavefront per env busy and is latency-bound, so (a) the learner's GEMMs run in the issue
+    slots it leaves free, and (b) with G >= 2 env groups the policy forward / sampling of one
+    group runs while the other groups' emulator kernels are in flight (the reference gets the
+    same effect from its 32 independent actor processes).  The actors' parameter snapshot plays
+    the role of the reference actor's `set_weights` (actor.py:103-104): it is refreshed from the
+    learner before every rollout, so the behaviour policy lags the learner by exactly one update."""
 
-    def __init__(self, alg, env, sample_batch_steps, seed=0):
+    def __init__(self, alg, envs, sample_batch_steps, seed=0):
         import copy
-        self.alg, self.env = alg, env
-        self.rollout = DeviceRollout(env, sample_batch_steps, seed=seed, n_buffers=2)
+        self.alg = alg
+        self.envs = list(envs) if isinstance(envs, (list, tuple)) else [envs]
+        self.env = self.envs[0]
+        self.T = int(sample_batch_steps)
+        # one Philox key for all groups: streams are told apart by the global env id
+        self.rollouts = [DeviceRollout(e, sample_batch_steps, seed=seed, n_buffers=2) for e in self.envs]
+        self.rollout = self.rollouts[0]
         self.actor_model = copy.deepcopy(alg.model)
         for p in self.actor_model.parameters():
             p.requires_grad_(False)
-        dev = env.device
-        # the rollout is the critical path (latency-bound emulator): high-priority queue for it
-        self.actor_stream = torch.cuda.Stream(device=dev, priority=-1)
+        dev = self.env.device
+        # the rollouts are the critical path (latency-bound emulator): high-priority queues
+        self.actor_streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in self.envs]
+        self.actor_stream = self.actor_streams[0]
         self.learn_stream = torch.cuda.Stream(device=dev, priority=0)
         self.weights_ready = torch.cuda.Event()
         self.snapshot_done = torch.cuda.Event()
-        self.batch_ready = [torch.cuda.Event(), torch.cuda.Event()]
+        G = len(self.envs)
+        self.batch_ready = [[torch.cuda.Event(), torch.cuda.Event()] for _ in range(G)]
         self.batch_free = [torch.cuda.Event(), torch.cuda.Event()]
-        self.pending = None  # (batch, buffer index) collected but not yet learned
+        self.pending = None  # ([batch per group], buffer index) collected but not yet learned
         self._src = [p for p in alg.model.parameters()] + [b for b in alg.model.buffers()]
         self._dst = [p for p in self.actor_model.parameters()] + [b for b in self.actor_model.buffers()]
         cur = torch.cuda.current_stream(dev)
-        self.actor_stream.wait_stream(cur)  # env construction (reset cache, tables) ran on `cur`
+        for st in self.actor_streams:
+            st.wait_stream(cur)  # env construction (reset cache, tables) ran on `cur`
         self.learn_stream.wait_stream(cur)
         self.weights_ready.record(cur)
         for e in self.batch_free:
@@ -194,19 +209,35 @@ class AsyncActorLearner(object):
 
     def _snapshot(self):
         """actor parameters <- learner parameters (the reference actor's set_weights)"""
-        with torch.cuda.stream(self.actor_stream):
-            self.actor_stream.wait_event(self.weights_ready)
+        s0 = self.actor_streams[0]
+        k = self.rollouts[0]._cur
+        with torch.cuda.stream(s0):
+            s0.wait_event(self.weights_ready)
+            if k >= 0:  # every group must be done acting with the old snapshot
+                for g in range(len(self.envs)):
+                    s0.wait_event(self.batch_ready[g][k])
             with torch.no_grad():
                 torch._foreach_copy_(self._dst, self._src)
-            self.snapshot_done.record(self.actor_stream)
+            self.snapshot_done.record(s0)
 
     def _collect(self):
-        k = (self.rollout._cur + 1) % 2
-        with torch.cuda.stream(self.actor_stream):
-            self.actor_stream.wait_event(self.batch_free[k])
-            batch = self.rollout.collect(self.actor_model)
-            self.batch_ready[k].record(self.actor_stream)
-        return batch, k
+        k = (self.rollouts[0]._cur + 1) % 2
+        for st, ro in zip(self.actor_streams, self.rollouts):
+            with torch.cuda.stream(st):
+                st.wait_event(self.snapshot_done)
+                st.wait_event(self.batch_free[k])
+                ro.collect_begin()
+        # step-interleaved enqueue: every group's stream always has work queued
+        for t in range(self.T):
+            for st, ro in zip(self.actor_streams, self.rollouts):
+                with torch.cuda.stream(st):
+                    ro.collect_step(self.actor_model, t)
+        batches = []
+        for g, (st, ro) in enumerate(zip(self.actor_streams, self.rollouts)):
+            with torch.cuda.stream(st):
+                batches.append(ro.collect_end())
+                self.batch_ready[g][k].record(st)
+        return batches, k
 
     def prime(self):
         """Collect the first batch so that every later step() has one to learn from."""
@@ -215,25 +246,42 @@ class AsyncActorLearner(object):
             self.pending = self._collect()
 
     def step(self, learning_rate, entropy_coeff):
-        """Enqueue one learner update on the previously collected batch and, concurrently, the
-        collection of the next one.  Returns (vtrace_loss, kl) of the update (device tensors)."""
+        """Enqueue one learner update on the previously collected batches and, concurrently, the
+        collection of the next ones.  Returns (vtrace_loss, kl) of the update (device tensors)."""
         self.prime()
-        batch, k = self.pending
+        batches, k = self.pending
         # the snapshot for the next rollout is taken first; the learner may not touch the
         # parameters before it is done
         self._snapshot()
-        with torch.cuda.stream(self.learn_stream):
-            self.learn_stream.wait_event(self.snapshot_done)
-            self.learn_stream.wait_event(self.batch_ready[k])
-            out = self.alg.learn(batch['obs'], batch['actions'], batch['behaviour_logits'], batch['rewards'],
-                                 batch['dones'], learning_rate, entropy_coeff, time_major=True)
-            self.weights_ready.record(self.learn_stream)
-            self.batch_free[k].record(self.learn_stream)
-        for v in batch.values():  # tensors made on the actor stream (e.g. dones.bool()), read on the learner's
-            v.record_stream(self.learn_stream)
+        ls = self.learn_stream
+        with torch.cuda.stream(ls):
+            ls.wait_event(self.snapshot_done)
+            for g in range(len(batches)):
+                ls.wait_event(self.batch_ready[g][k])
+            if len(batches) == 1:
+                b = batches[0]
+                out = self.alg.learn(b['obs'], b['actions'], b['behaviour_logits'], b['rewards'], b['dones'],
+                                     learning_rate, entropy_coeff, time_major=True)
+            else:
+                out = self.alg.learn_batches(batches, learning_rate, entropy_coeff, time_major=True)
+            self.weights_ready.record(ls)
+            self.batch_free[k].record(ls)
+        for b in batches:
+            for v in b.values():  # tensors made on an actor stream (e.g. dones.bool()), read on the learner's
+                v.record_stream(ls)
         self.pending = self._collect()
         return out
 
+    def pop_episode_stats(self):
+        """(episodes closed, mean unclipped return, mean length) over all groups; syncs."""
+        n = r = l = 0.0
+        for ro in self.rollouts:
+            gn, gr, gl = ro.pop_episode_stats()
+            if gn:
+                n, r, l = n + gn, r + gr * gn, l + gl * gn
+        return n, (r / n if n else None), (l / n if n else None)
+
     def synchronize(self):
-        self.actor_stream.synchronize()
+        for st in self.actor_streams:
+            st.synchronize()
         self.learn_stream.synchronize()

@@ -1,0 +1,69 @@
+"""Fused conv1+conv2 MFMA kernel of the IMPALA Atari model (parlhip_atari42_conv12_u8_f32, through
+the C ABI) against a plain PyTorch fp32/fp64 reference of the same layers
+(examples/IMPALA/atari_model.py:59-71).  Tolerance: 1e-5 relative to the activation scale (exact
+f32 MFMA accumulation, only the summation order differs).  -m gpu."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(obs_u8, w1, b1, w2, b2, dtype):
+    x = obs_u8.to(dtype) / 255.0
+    x = F.relu(F.conv2d(x, w1.to(dtype), b1.to(dtype), stride=2, padding=1))
+    x = F.relu(F.conv2d(x, w2.to(dtype), b2.to(dtype), stride=2, padding=2))
+    return x.flatten(1)
+
+
+@pytest.mark.parametrize('n', [1, 37, 1024])
+def test_conv12_matches_torch_reference(dev, n):
+    from parl_amd import ops
+    g = torch.Generator().manual_seed(n)
+    obs = torch.randint(0, 256, (n, 4, 42, 42), generator=g, dtype=torch.uint8)
+    w1 = torch.randn(16, 4, 4, 4, generator=g) * 0.2
+    b1 = torch.randn(16, generator=g) * 0.1
+    w2 = torch.randn(32, 16, 4, 4, generator=g) * 0.1
+    b2 = torch.randn(32, generator=g) * 0.1
+    out = ops.atari42_conv12(obs.to(dev), w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev)).cpu()
+    ref64 = _reference(obs, w1, b1, w2, b2, torch.float64)
+    assert out.shape == (n, 3872)
+    scale = float(ref64.abs().max())
+    err = float((out.double() - ref64).abs().max())
+    assert err <= 1e-5 * scale, (err, scale)
+    # and no worse than the fp32 CPU convolution itself
+    ref32 = _reference(obs, w1, b1, w2, b2, torch.float32)
+    assert err <= 4 * float((ref32.double() - ref64).abs().max()) + 1e-7 * scale
+
+
+def test_conv12_edges_and_zero_obs(dev):
+    """all-zero and all-255 observations (padding / border taps), bias-only output"""
+    from parl_amd import ops
+    g = torch.Generator().manual_seed(3)
+    w1 = torch.randn(16, 4, 4, 4, generator=g) * 0.2
+    b1 = torch.randn(16, generator=g)
+    w2 = torch.randn(32, 16, 4, 4, generator=g) * 0.1
+    b2 = torch.randn(32, generator=g)
+    for fill in (0, 255):
+        obs = torch.full((3, 4, 42, 42), fill, dtype=torch.uint8)
+        out = ops.atari42_conv12(obs.to(dev), w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev)).cpu()
+        ref = _reference(obs, w1, b1, w2, b2, torch.float64)
+        np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    assert ops.atari42_conv12(torch.zeros((0, 4, 42, 42), dtype=torch.uint8, device=dev), w1.to(dev), b1.to(dev),
+                              w2.to(dev), b2.to(dev)).shape == (0, 3872)
+
+
+def test_model_actor_path_equals_autograd_path(dev):
+    """AtariModel42.policy under no_grad (fused kernel) == the autograd trunk (GEMM-lowered convs)"""
+    from parl_amd.models import AtariModel42
+    torch.manual_seed(0)
+    model = AtariModel42(6).to(dev)
+    obs = torch.randint(0, 256, (64, 4, 42, 42), dtype=torch.uint8, device=dev)
+    with torch.no_grad():
+        fast = model.policy(obs)
+        slab = torch.empty((64, 6), device=dev)
+        model.policy_into(obs, slab)
+    slow = model.policy(obs)  # grad enabled -> GemmConv2d path
+    np.testing.assert_allclose(fast.cpu().numpy(), slow.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    assert torch.equal(fast, slab)

@@ -94,7 +94,7 @@ def test_async_actor_learner_pipeline(dev):
     pipe = AsyncActorLearner(alg, mk(), T, seed=5)
     pipe.prime()
     pipe.synchronize()
-    b0 = {k: v.clone() for k, v in pipe.pending[0].items()}
+    b0 = {k: v.clone() for k, v in pipe.pending[0][0].items()}
     ref = DeviceRollout(mk(), T, seed=5).collect(ref_model)
     for k in ref:
         assert torch.equal(b0[k], ref[k]), k
@@ -111,3 +111,39 @@ def test_async_actor_learner_pipeline(dev):
         assert any(not torch.equal(p, b) for p, b in zip(model.parameters(), before))
     assert used == [0, 1, 0, 1]
     pipe.env.check_faults()
+
+
+def test_async_actor_learner_two_groups_equals_one_vector(dev):
+    """Two env groups on two actor streams produce exactly the trajectories of ONE vector env of
+    all envs (same env ids => same Philox streams), and learn_batches() on the two group batches
+    gives the same update as learn() on the union batch."""
+    import copy
+    import parl_amd as parl
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel42
+    from parl_amd.rollout import AsyncActorLearner, DeviceRollout
+    torch.manual_seed(0)
+    E, T = 16, 8
+    model = AtariModel42(6).to(dev)
+    model_b = copy.deepcopy(model)
+    mk = lambda n, id0: DeviceVectorEnv('PongNoFrameskip-v4', n, dim=42, horizon=T, seed=11, env_id0=id0, device=dev)
+    kw = dict(sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5, clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+    alg = parl.algorithms.IMPALA(model, **kw)
+    pipe = AsyncActorLearner(alg, [mk(E // 2, 0), mk(E // 2, E // 2)], T, seed=5)
+    pipe.prime()
+    pipe.synchronize()
+    ref = DeviceRollout(mk(E, 0), T, seed=5).collect(model_b)
+    ga, gb = pipe.pending[0]
+    for k in ref:
+        full = ref[k].reshape((T, E) + tuple(ref[k].shape[1:]))
+        assert torch.equal(ga[k].reshape((T, E // 2) + tuple(ga[k].shape[1:])), full[:, :E // 2]), k
+        assert torch.equal(gb[k].reshape((T, E // 2) + tuple(gb[k].shape[1:])), full[:, E // 2:]), k
+    # one update on the union == accumulated update on the two halves
+    alg_b = parl.algorithms.IMPALA(model_b, **kw)
+    la, _ = alg.learn_batches([{k: v.clone() for k, v in ga.items()}, {k: v.clone() for k, v in gb.items()}],
+                              1e-3, -0.01, time_major=True)
+    lb, _ = alg_b.learn(ref['obs'], ref['actions'], ref['behaviour_logits'], ref['rewards'], ref['dones'], 1e-3,
+                        -0.01, time_major=True)
+    np.testing.assert_allclose(float(la.total_loss), float(lb.total_loss), rtol=1e-5)
+    for pa, pb in zip(model.parameters(), model_b.parameters()):
+        np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-4, atol=2e-6)
