@@ -126,7 +126,7 @@ def main():
     ap.add_argument('--sample-batch-steps', type=int, default=50)
     ap.add_argument('--game', default='PongNoFrameskip-v4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--actor-groups', type=int, default=2, help='env groups (actor streams) per GPU')
+    ap.add_argument('--actor-groups', type=int, default=1, help='env groups (actor streams) per GPU')
     ap.add_argument('--no-overlap', action='store_true',
                     help='run rollout and learner update back to back on one stream instead of overlapped')
     args = ap.parse_args()
