@@ -16,6 +16,7 @@
 //     lane l owns time steps [l*K, l*K+K), loads are coalesced along T, and the affine
 //     recurrence acc_t = d_t + a_t*acc_{t+1} is solved with a 6-step wavefront-shuffle suffix
 //     scan over (a, d) pairs; neighbours' V_{t+1} / vs_{t+1} come from one more shuffle.
+#include <cstdlib>
 #include "common.hpp"
 #include <math.h>
 
@@ -29,6 +30,18 @@ template <> struct Vec<1> {
   float v[1];
   __device__ static Vec load(const float* p) { Vec r; r.v[0] = *p; return r; }
   __device__ void store(float* p) const { *p = v[0]; }
+  __device__ void store_nt(float* p) const { __builtin_nontemporal_store(v[0], p); }
+};
+template <> struct Vec<2> {
+  float v[2];
+  __device__ static Vec load(const float* p) {
+    float2 q = *reinterpret_cast<const float2*>(p);
+    Vec r; r.v[0] = q.x; r.v[1] = q.y; return r;
+  }
+  __device__ void store(float* p) const { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+  __device__ void store_nt(float* p) const {
+    __builtin_nontemporal_store(v[0], p); __builtin_nontemporal_store(v[1], p + 1);
+  }
 };
 template <> struct Vec<4> {
   float v[4];
@@ -38,6 +51,10 @@ template <> struct Vec<4> {
   }
   __device__ void store(float* p) const {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  __device__ void store_nt(float* p) const {
+    __builtin_nontemporal_store(v[0], p); __builtin_nontemporal_store(v[1], p + 1);
+    __builtin_nontemporal_store(v[2], p + 2); __builtin_nontemporal_store(v[3], p + 3);
   }
 };
 
@@ -63,7 +80,7 @@ __device__ __forceinline__ float clip_max(float x, float thr) {
 // ----------------------------------------------------------------------------------------
 // V-trace, lane-per-sequence, time-major, from log-probs.  28 B per (t,b) element.
 // ----------------------------------------------------------------------------------------
-template <int VEC, int U>
+template <int VEC, int U, bool NT = false>
 __global__ __launch_bounds__(256) void vtrace_tm_kernel(
     const float* __restrict__ blp, const float* __restrict__ tlp,
     const float* __restrict__ disc, const float* __restrict__ rew,
@@ -109,8 +126,8 @@ __global__ __launch_bounds__(256) void vtrace_tm_kernel(
         vs_next[j] = vst;
         v_next[j] = v;
       }
-      o_vs.store(vs + i);
-      o_pg.store(pg + i);
+      if (NT) { o_vs.store_nt(vs + i); o_pg.store_nt(pg + i); }
+      else { o_vs.store(vs + i); o_pg.store(pg + i); }
     }
   }
   for (; t >= 0; --t) {
@@ -132,8 +149,8 @@ __global__ __launch_bounds__(256) void vtrace_tm_kernel(
       vs_next[j] = vst;
       v_next[j] = v;
     }
-    o_vs.store(vs + i);
-    o_pg.store(pg + i);
+    if (NT) { o_vs.store_nt(vs + i); o_pg.store_nt(pg + i); }
+    else { o_vs.store(vs + i); o_pg.store(pg + i); }
   }
 }
 
@@ -668,13 +685,20 @@ PARLHIP_EXPORT int parlhip_vtrace_f32(const float* blp, const float* tlp,
 #undef LAUNCH_W
     return check_launch();
   }
-  if (use_vec4(B, {blp, tlp, discounts, rewards, values, bootstrap, vs, pg})) {
-    const int threads = B / 4;
-    vtrace_tm_kernel<4, 4><<<ceil_div(threads, 256), 256, 0, s>>>(
+  // Launch shape measured on MI355X at T'=127 (tools/vt_variants.py, profiles/r01d_vtrace_variants.log):
+  // outputs are written with nontemporal stores (they are not re-read by this kernel: +3 %);
+  // float2 lanes x 4 time steps in flight win once B/2 lanes still fill the chip (5.67 vs 5.20 TB/s
+  // for float4 x 4 at B = 1 M), scalar lanes x 8 steps win below (5.56 TB/s at B = 262,144).
+  bool al8 = B % 2 == 0;
+  for (const void* p : {(const void*)blp, (const void*)tlp, (const void*)discounts, (const void*)rewards,
+                        (const void*)values, (const void*)bootstrap, (const void*)vs, (const void*)pg})
+    al8 = al8 && (reinterpret_cast<uintptr_t>(p) % 8 == 0);
+  if (al8 && (int64_t)B / 2 >= (int64_t)kNumCU * 4 * kWave * 4) {
+    vtrace_tm_kernel<2, 4, true><<<ceil_div(B / 2, 256), 256, 0, s>>>(
         blp, tlp, discounts, rewards, values, bootstrap, vs, pg, T, B, clip_rho, clip_pg);
   } else {
     const int block = B >= 256 * 64 ? 256 : 64;
-    vtrace_tm_kernel<1, 8><<<ceil_div(B, block), block, 0, s>>>(
+    vtrace_tm_kernel<1, 8, true><<<ceil_div(B, block), block, 0, s>>>(
         blp, tlp, discounts, rewards, values, bootstrap, vs, pg, T, B, clip_rho, clip_pg);
   }
   return check_launch();

@@ -87,6 +87,14 @@ def main():
     lg = torch.randn((1024, 6), device=dev)
     s = timeit(lambda: ops.policy_sample(lg, 1, 2, 3))
     res['policy_sample_1024x6'] = {'us': s * 1e6}
+    for n in (1024, 8192):
+        obs = torch.randint(0, 256, (n, 4, 42, 42), dtype=torch.uint8, device=dev)
+        w1, b1 = torch.randn(16, 4, 4, 4, device=dev), torch.randn(16, device=dev)
+        w2, b2 = torch.randn(32, 16, 4, 4, device=dev), torch.randn(32, device=dev)
+        out = torch.empty((n, 3872), device=dev)
+        s = timeit(lambda: ops.atari42_conv12(obs, w1, b1, w2, b2, out=out))
+        fl = n * 2.0 * (441 * 16 * 64 + 121 * 32 * 256)
+        res['conv12_u8_mfma_n%d' % n] = {'us': s * 1e6, 'TFLOPs': fl / s / 1e12, 'GBps': n * (7056 + 15488) / s / 1e9}
     for k, v in res.items():
         print(k, {a: (round(b, 2) if isinstance(b, float) else b) for a, b in v.items()})
     if args.json:
