@@ -261,6 +261,14 @@ int parlhip_atari42_conv12_u8_f32(const uint8_t* obs, const float* w1, const flo
                                   const float* w2, const float* b2, float* out, int n_obs,
                                   parlhip_stream_t stream);
 
+/* examples/A2C/atari_model.py:21-104 (AtariModel trunk), first layer — the 84x84 -> 20x20
+ * contraction: x = obs / 255; conv1 4->32 k8 s4 p1 + ReLU.  obs u8 [n,4,84,84], w1 f32
+ * [32,4,8,8], b1 [32] (nn.Conv2d layout), out f32 [n,32,20,20] (NCHW, the input of conv2).
+ * Inference only (the actors' / bootstrap-value forward).  Implicit GEMM [400 x 256] x [256 x 32]
+ * per observation on v_mfma_f32_16x16x4_f32; obs must be 4-byte and out 16-byte aligned.       */
+int parlhip_atari84_conv1_u8_f32(const uint8_t* obs, const float* w1, const float* b1, float* out,
+                                 int n_obs, parlhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

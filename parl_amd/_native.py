@@ -63,6 +63,7 @@ SIGNATURES = {
     'parlhip_stack_since_update_u8': (_i, [_p, _p, _p, _i, _p]),
     'parlhip_stack_gather_u8': (_i, [_p, _p, _i, _i, _p, _p, _i64, _p, _p]),
     'parlhip_atari42_conv12_u8_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _p]),
+    'parlhip_atari84_conv1_u8_f32': (_i, [_p, _p, _p, _p, _i, _p]),
     'parlhip_episode_stats_accum_f64': (_i, [_p, _p, _i, _p, _p]),
 }
 

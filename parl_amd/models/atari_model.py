@@ -98,8 +98,12 @@ class AtariModel84(Model):
         self.value_fc = nn.Linear(512, 1)
 
     def _trunk(self, obs):
-        x = obs.float() / 255.0
-        x = F.relu(self.conv1(x))
+        if (not torch.is_grad_enabled()) and obs.dtype == torch.uint8 and obs.is_cuda and obs.shape[0] > 0:
+            # the actors' / bootstrap-value path (no autograd): the 84x84 -> 20x20 contraction as one
+            # MFMA kernel on the uint8 observations with /255, bias and ReLU fused (ops.atari84_conv1)
+            x = ops.atari84_conv1(obs, self.conv1.weight, self.conv1.bias)
+        else:
+            x = F.relu(self.conv1(obs.float() / 255.0))
         x = F.relu(self.conv2(x))
         x = F.relu(self.conv3(x))
         return F.relu(self.fc(x.flatten(1)))

@@ -246,6 +246,26 @@ def atari42_conv12(obs, conv1_weight, conv1_bias, conv2_weight, conv2_bias, out=
     return out
 
 
+def atari84_conv1(obs, conv1_weight, conv1_bias, out=None):
+    """conv1 + ReLU of the A2C Atari network (examples/A2C/atari_model.py:21-104: 4->32 k8 s4 p1,
+    84x84 -> 20x20) for uint8 observations [n,4,84,84] as one MFMA kernel with the /255 fused
+    (inference only).  Returns f32 [n,32,20,20]."""
+    if obs.dtype != torch.uint8 or obs.dim() != 4 or tuple(obs.shape[1:]) != (4, 84, 84):
+        raise N.ParlHipError('atari84_conv1: obs must be uint8 [n,4,84,84]')
+    if tuple(conv1_weight.shape) != (32, 4, 8, 8) or tuple(conv1_bias.shape) != (32, ):
+        raise N.ParlHipError('atari84_conv1: weight must be [32,4,8,8], bias [32]')
+    n = obs.shape[0]
+    if out is None:
+        out = torch.empty((n, 32, 20, 20), dtype=torch.float32, device=obs.device)
+    elif out.dtype != torch.float32 or out.numel() != n * 12800 or not out.is_contiguous():
+        raise N.ParlHipError('atari84_conv1: out must be contiguous f32 [n,32,20,20]')
+    w1, b1 = _f32(conv1_weight.detach(), 'conv1_weight'), _f32(conv1_bias.detach(), 'conv1_bias')
+    N.check(
+        N.lib().parlhip_atari84_conv1_u8_f32(N.ptr(obs.contiguous()), N.ptr(w1), N.ptr(b1), N.ptr(out), n,
+                                            N.stream_ptr()), 'parlhip_atari84_conv1_u8_f32')
+    return out
+
+
 def consume_device_errors():
     """Synchronise and return/clear the device-side data-error flag (bad action index)."""
     return N.check(N.lib().parlhip_consume_device_errors(N.stream_ptr()),

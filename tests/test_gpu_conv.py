@@ -67,3 +67,72 @@ def test_model_actor_path_equals_autograd_path(dev):
     slow = model.policy(obs)  # grad enabled -> GemmConv2d path
     np.testing.assert_allclose(fast.cpu().numpy(), slow.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
     assert torch.equal(fast, slab)
+
+
+# ---- conv1 of the A2C model: the 84x84 -> 20x20 contraction (parlhip_atari84_conv1_u8_f32) ----
+def _reference84(obs_u8, w1, b1, dtype):
+    """examples/A2C/atari_model.py:21-104, first layer: obs / 255 -> conv 4->32 k8 s4 p1 -> ReLU"""
+    return F.relu(F.conv2d(obs_u8.to(dtype) / 255.0, w1.to(dtype), b1.to(dtype), stride=4, padding=1))
+
+
+@pytest.mark.parametrize('n', [1, 5, 256, 700])
+def test_conv1_84_matches_torch_reference(dev, n):
+    from parl_amd import ops
+    g = torch.Generator().manual_seed(100 + n)
+    obs = torch.randint(0, 256, (n, 4, 84, 84), generator=g, dtype=torch.uint8)
+    w1 = torch.randn(32, 4, 8, 8, generator=g) * 0.1
+    b1 = torch.randn(32, generator=g) * 0.1
+    out = ops.atari84_conv1(obs.to(dev), w1.to(dev), b1.to(dev)).cpu()
+    ref64 = _reference84(obs, w1, b1, torch.float64)
+    assert out.shape == (n, 32, 20, 20)
+    scale = float(ref64.abs().max())
+    err = float((out.double() - ref64).abs().max())
+    assert err <= 1e-5 * scale, (err, scale)
+    ref32 = _reference84(obs, w1, b1, torch.float32)
+    assert err <= 4 * float((ref32.double() - ref64).abs().max()) + 1e-7 * scale
+
+
+def test_conv1_84_taps_and_borders(dev):
+    """One-hot weights select single input taps, so the gather index arithmetic (channel, kernel row /
+    column, padding row 0 / column 0, the unused last input row / column) is checked exactly; plus
+    constant images and the empty batch."""
+    from parl_amd import ops
+    g = torch.Generator().manual_seed(9)
+    obs = torch.randint(0, 256, (3, 4, 84, 84), generator=g, dtype=torch.uint8)
+    b1 = torch.zeros(32)
+    for rep in range(4):
+        w1 = torch.zeros(32, 4, 8, 8)
+        taps = []
+        for o in range(32):
+            c, kh, kw = int(torch.randint(0, 4, (1, ), generator=g)), (o + rep) % 8, (3 * o + rep) % 8
+            w1[o, c, kh, kw] = 1.0
+            taps.append((c, kh, kw))
+        out = ops.atari84_conv1(obs.to(dev), w1.to(dev), b1.to(dev)).cpu()
+        pad = F.pad(obs.float() / 255.0, (1, 1, 1, 1))
+        for o, (c, kh, kw) in enumerate(taps):
+            want = pad[:, c, kh:kh + 77:4, kw:kw + 77:4]
+            assert torch.equal(out[:, o], want), (rep, o, c, kh, kw)
+    w1 = torch.randn(32, 4, 8, 8, generator=g) * 0.1
+    b1 = torch.randn(32, generator=g)
+    for fill in (0, 255):
+        o8 = torch.full((2, 4, 84, 84), fill, dtype=torch.uint8)
+        out = ops.atari84_conv1(o8.to(dev), w1.to(dev), b1.to(dev)).cpu()
+        ref = _reference84(o8, w1, b1, torch.float64)
+        np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    assert ops.atari84_conv1(torch.zeros((0, 4, 84, 84), dtype=torch.uint8, device=dev), w1.to(dev),
+                             b1.to(dev)).shape == (0, 32, 20, 20)
+    with pytest.raises(Exception):
+        ops.atari84_conv1(torch.zeros((2, 4, 42, 42), dtype=torch.uint8, device=dev), w1.to(dev), b1.to(dev))
+
+
+def test_model84_actor_path_equals_autograd_path(dev):
+    """AtariModel84 under no_grad (MFMA conv1 on uint8) == the autograd trunk (GEMM-lowered conv1)"""
+    from parl_amd.models import AtariModel84
+    torch.manual_seed(0)
+    model = AtariModel84(6).to(dev)
+    obs = torch.randint(0, 256, (48, 4, 84, 84), dtype=torch.uint8, device=dev)
+    with torch.no_grad():
+        fp, fv = model.policy_and_value(obs)
+    sp, sv = model.policy_and_value(obs)
+    np.testing.assert_allclose(fp.cpu().numpy(), sp.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(fv.cpu().numpy(), sv.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
