@@ -269,6 +269,42 @@ int parlhip_atari42_conv12_u8_f32(const uint8_t* obs, const float* w1, const flo
 int parlhip_atari84_conv1_u8_f32(const uint8_t* obs, const float* w1, const float* b1, float* out,
                                  int n_obs, parlhip_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * PPO: running observation / return normalisation and the minibatch gather
+ * ------------------------------------------------------------------------------------ */
+/* VecNormalizeEnv._obfilt (parl/env/mujoco_wrappers.py:140-156) for E host-stepped envs at once,
+ * each with its OWN RunningMeanStd (mujoco_wrappers.py:73-92; one VecNormalizeEnv per env,
+ * examples/PPO/env_utils.py:118-127), i.e. update_mean_var_count_from_moments
+ * (mujoco_wrappers.py:185-206) with batch_mean = x, batch_var = 0, batch_count = 1, in float64
+ * with numpy's operation order (bit-identical statistics and outputs).
+ * raw f64 [E,D]; mean, var f64 [E,D] and count f64 [E] are updated in place when update != 0
+ * (training mode); mask u8 [E] or NULL selects the envs to process (the reset path,
+ * env_utils.py:95-103: only envs that just finished filter their reset observation);
+ * out f32 [E,D] = the cast RolloutStorage.append performs (examples/PPO/storage.py:36) and / or
+ * out64 f64 [E,D]; rows of unselected envs are left untouched.                                   */
+int parlhip_vecnorm_obs_f64(const double* raw, double* mean, double* var, double* count,
+                            const uint8_t* mask, float* out, double* out64, int E, int D,
+                            double clipob, double eps, int update, parlhip_stream_t stream);
+/* VecNormalizeEnv.step, reward half (mujoco_wrappers.py:120-136): ret = ret*gamma + rew;
+ * ret_rms.update(ret); rew = clip(rew / sqrt(ret_rms.var + eps), -cliprew, cliprew);
+ * ret = 0 where done.  rew f64 [E], done u8 [E]; ret, ret_mean, ret_var, ret_count f64 [E] in
+ * place; out f32 [E] and / or out64 f64 [E].                                                     */
+int parlhip_vecnorm_reward_f64(const double* rew, const uint8_t* done, double* ret,
+                               double* ret_mean, double* ret_var, double* ret_count, float* out,
+                               double* out64, int E, double gamma, double cliprew, double eps,
+                               parlhip_stream_t stream);
+/* RolloutStorage.sample_batch (examples/PPO/storage.py:66-76) for one minibatch index
+ * (examples/PPO/agent.py:91-99): out_x[m] = x[idx[m]] for the six flattened rollout arrays in one
+ * launch.  obs f32 [N,obs_dim], actions f32 [N,act_dim] (act_dim 0: scalar actions are passed as
+ * act_dim 1), the others f32 [N]; idx i64 [M].  An index outside [0,N) raises the device data-
+ * error flag (parlhip_consume_device_errors) and writes nothing for that row.                    */
+int parlhip_ppo_sample_batch_f32(const float* obs, const float* actions, const float* logprobs,
+                                 const float* advantages, const float* returns, const float* values,
+                                 const int64_t* idx, float* out_obs, float* out_actions,
+                                 float* out_logprobs, float* out_advantages, float* out_returns,
+                                 float* out_values, int64_t N, int64_t M, int obs_dim, int act_dim,
+                                 parlhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,3 +224,56 @@ class VecEnv:
             self.L.oracle_vec_free(self.h)
         except Exception:
             pass
+
+
+# ---- PPO: VecNormalizeEnv running statistics, minibatch gather (ppo_oracle.c) ----
+class VecNormalize(object):
+    """E independent VecNormalizeEnv instances (parl/env/mujoco_wrappers.py:95-169) as arrays"""
+
+    def __init__(self, E, D, gamma=0.99, clipob=10.0, cliprew=10.0, epsilon=1e-8, rms_epsilon=1e-4):
+        self.E, self.D = E, D
+        self.gamma, self.clipob, self.cliprew, self.eps = gamma, clipob, cliprew, epsilon
+        self.ob_mean = np.zeros((E, D), np.float64)
+        self.ob_var = np.ones((E, D), np.float64)
+        self.ob_count = np.full(E, rms_epsilon, np.float64)
+        self.ret_mean = np.zeros(E, np.float64)
+        self.ret_var = np.ones(E, np.float64)
+        self.ret_count = np.full(E, rms_epsilon, np.float64)
+        self.ret = np.zeros(E, np.float64)
+        self.training = True
+
+    def filter_obs(self, raw, mask=None, out=None):
+        raw = _c(raw, np.float64)
+        if out is None:
+            out = np.zeros((self.E, self.D), np.float64)
+        m = None if mask is None else _c(mask, np.uint8)
+        rc = lib().oracle_vecnorm_obs_f64(_p(raw), _p(self.ob_mean), _p(self.ob_var), _p(self.ob_count), _p(m),
+                                          None, _p(out), self.E, self.D, ctypes.c_double(self.clipob),
+                                          ctypes.c_double(self.eps), 1 if self.training else 0)
+        assert rc == 0
+        return out
+
+    def filter_reward(self, rew, done):
+        rew, done = _c(rew, np.float64), _c(done, np.uint8)
+        out = np.zeros(self.E, np.float64)
+        rc = lib().oracle_vecnorm_reward_f64(_p(rew), _p(done), _p(self.ret), _p(self.ret_mean), _p(self.ret_var),
+                                             _p(self.ret_count), None, _p(out), self.E, ctypes.c_double(self.gamma),
+                                             ctypes.c_double(self.cliprew), ctypes.c_double(self.eps))
+        assert rc == 0
+        return out
+
+
+def ppo_sample_batch(obs, actions, logprobs, advantages, returns, values, idx):
+    """flattened rollout arrays ([N, ...]) gathered by idx -> (obs [M,Do], actions [M,Da], 4 x [M])"""
+    N = logprobs.size
+    obs2, act2 = _c(obs, np.float32).reshape(N, -1), _c(actions, np.float32).reshape(N, -1)
+    idx = _c(idx, np.int64)
+    M = idx.size
+    outs = [np.empty((M, obs2.shape[1]), np.float32), np.empty((M, act2.shape[1]), np.float32)] + \
+           [np.empty(M, np.float32) for _ in range(4)]
+    flat = [_c(x, np.float32).reshape(-1) for x in (logprobs, advantages, returns, values)]
+    rc = lib().oracle_ppo_sample_batch_f32(_p(obs2), _p(act2), *[_p(x) for x in flat], _p(idx),
+                                           *[_p(o) for o in outs], ctypes.c_int64(N), ctypes.c_int64(M),
+                                           obs2.shape[1], act2.shape[1])
+    assert rc == 0
+    return outs

@@ -10,4 +10,5 @@ from .core import Model, Algorithm, Agent  # noqa: F401,E402
 from . import algorithms  # noqa: F401,E402
 from . import utils  # noqa: F401,E402
 from . import env  # noqa: F401,E402
+from .storage import RolloutStorage  # noqa: F401,E402
 from .remote import remote_class, connect, RemoteError  # noqa: F401,E402

@@ -24,6 +24,7 @@ _p = ctypes.c_void_p
 _u64 = ctypes.c_uint64
 _i64 = ctypes.c_int64
 _sz = ctypes.c_size_t
+_d = ctypes.c_double
 
 # name -> (restype, argtypes); kept in lock-step with include/parl_hip.h
 # (tests/test_capi_symbols.py parses the header and checks every declared symbol is here
@@ -64,6 +65,9 @@ SIGNATURES = {
     'parlhip_stack_gather_u8': (_i, [_p, _p, _i, _i, _p, _p, _i64, _p, _p]),
     'parlhip_atari42_conv12_u8_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _p]),
     'parlhip_atari84_conv1_u8_f32': (_i, [_p, _p, _p, _p, _i, _p]),
+    'parlhip_vecnorm_obs_f64': (_i, [_p] * 7 + [_i, _i, _d, _d, _i, _p]),
+    'parlhip_vecnorm_reward_f64': (_i, [_p] * 8 + [_i, _d, _d, _d, _p]),
+    'parlhip_ppo_sample_batch_f32': (_i, [_p] * 13 + [_i64, _i64, _i, _i, _p]),
     'parlhip_episode_stats_accum_f64': (_i, [_p, _p, _i, _p, _p]),
 }
 

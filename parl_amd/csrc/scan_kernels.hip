@@ -613,12 +613,9 @@ __global__ __launch_bounds__(256) void discount_cumsum_kernel(
 // per-thread error flag used by the logits kernels (bad action index)
 __device__ int g_action_err;
 
-}  // namespace parlhip
-
-using namespace parlhip;
-
-// address of the device-side "bad action index" word (resolved once per process)
-static int* action_err_ptr() {
+// address of the device-side data-error word (bad action / minibatch index), resolved once per
+// process; shared with ppo_kernels.hip
+int* device_error_flag() {
   static int* p = nullptr;
   if (!p) {
     int* q = nullptr;
@@ -628,6 +625,12 @@ static int* action_err_ptr() {
   }
   return p;
 }
+
+}  // namespace parlhip
+
+using namespace parlhip;
+
+static int* action_err_ptr() { return device_error_flag(); }
 
 PARLHIP_EXPORT int parlhip_consume_device_errors(parlhip_stream_t stream) {
   int* p = action_err_ptr();

@@ -49,7 +49,10 @@ class FlatGradAllReduce(object):
     all-reduce per update.  The flat buffer is allocated once; grads are views into it after the
     first call, so no pack/unpack copies in steady state."""
 
-    def __init__(self, model):
+    def __init__(self, model, average=False):
+        # average=True: divide by the world size after the sum (PPO / any mean-reduced loss: the
+        # data-parallel gradient of the union minibatch is the mean of the per-rank gradients)
+        self.average = average
         self.params = [p for p in model.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.params[0].device)
@@ -69,6 +72,8 @@ class FlatGradAllReduce(object):
                 v.copy_(p.grad)
                 p.grad = v
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if self.average:
+            self.flat.div_(world_size())
 
 
 def all_gather_small(tensors):

@@ -266,6 +266,92 @@ def atari84_conv1(obs, conv1_weight, conv1_bias, out=None):
     return out
 
 
+def _f64(t, name):
+    if t.dtype != torch.float64 or not t.is_cuda:
+        raise N.ParlHipError('%s must be a float64 CUDA tensor' % name)
+    if not t.is_contiguous():
+        raise N.ParlHipError('%s must be contiguous (it is updated in place)' % name)
+    return t
+
+
+def vecnorm_obs(raw, mean, var, count, mask=None, out=None, clipob=10.0, eps=1e-8, update=True, out64=None):
+    """VecNormalizeEnv._obfilt (parl/env/mujoco_wrappers.py:140-156) for E envs, each with its own
+    RunningMeanStd: raw f64 [E,D]; mean/var f64 [E,D] and count f64 [E] updated IN PLACE when
+    `update`; mask (bool/uint8 [E]) restricts the call to some envs (reset path).  Returns the
+    float32 normalised observations [E,D] (written into `out` when given)."""
+    raw = _f64(raw.contiguous(), 'raw')
+    E, D = raw.shape
+    _f64(mean, 'mean'), _f64(var, 'var'), _f64(count, 'count')
+    if tuple(mean.shape) != (E, D) or tuple(var.shape) != (E, D) or count.numel() != E:
+        raise N.ParlHipError('vecnorm_obs: mean/var must be [E,D], count [E]')
+    if mask is not None:
+        mask = (mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.contiguous())
+        if mask.dtype != torch.uint8 or mask.numel() != E:
+            raise N.ParlHipError('vecnorm_obs: mask must be bool/uint8 [E]')
+    if out is None:
+        out = torch.zeros((E, D), dtype=torch.float32, device=raw.device)
+    elif out.dtype != torch.float32 or tuple(out.shape) != (E, D) or not out.is_contiguous():
+        raise N.ParlHipError('vecnorm_obs: out must be contiguous f32 [E,D]')
+    if out64 is not None:
+        _f64(out64, 'out64')
+    N.check(
+        N.lib().parlhip_vecnorm_obs_f64(N.ptr(raw), N.ptr(mean), N.ptr(var), N.ptr(count), N.ptr(mask), N.ptr(out),
+                                       N.ptr(out64), E, D, float(clipob), float(eps), 1 if update else 0,
+                                       N.stream_ptr()), 'parlhip_vecnorm_obs_f64')
+    return out
+
+
+def vecnorm_reward(rew, done, ret, ret_mean, ret_var, ret_count, gamma=0.99, cliprew=10.0, eps=1e-8, out=None,
+                   out64=None):
+    """VecNormalizeEnv.step's reward half (parl/env/mujoco_wrappers.py:120-136); the four running
+    arrays (f64 [E]) are updated IN PLACE.  Returns the float32 normalised rewards [E]."""
+    rew = _f64(rew.contiguous(), 'rew')
+    E = rew.numel()
+    done = done.contiguous().view(torch.uint8) if done.dtype == torch.bool else done.contiguous()
+    if done.dtype != torch.uint8 or done.numel() != E:
+        raise N.ParlHipError('vecnorm_reward: done must be bool/uint8 [E]')
+    for t, n in ((ret, 'ret'), (ret_mean, 'ret_mean'), (ret_var, 'ret_var'), (ret_count, 'ret_count')):
+        if _f64(t, n).numel() != E:
+            raise N.ParlHipError('vecnorm_reward: %s must be [E]' % n)
+    if out is None:
+        out = torch.empty(E, dtype=torch.float32, device=rew.device)
+    if out64 is not None:
+        _f64(out64, 'out64')
+    N.check(
+        N.lib().parlhip_vecnorm_reward_f64(N.ptr(rew), N.ptr(done), N.ptr(ret), N.ptr(ret_mean), N.ptr(ret_var),
+                                          N.ptr(ret_count), N.ptr(out), N.ptr(out64), E, float(gamma),
+                                          float(cliprew), float(eps), N.stream_ptr()), 'parlhip_vecnorm_reward_f64')
+    return out
+
+
+def ppo_sample_batch(obs, actions, logprobs, advantages, returns, values, idx):
+    """RolloutStorage.sample_batch (examples/PPO/storage.py:66-76): gather the six flattened rollout
+    arrays by one minibatch index in ONE launch.  obs [N,...] / actions [N,...] f32, the others
+    f32 [N], idx int64 [M].  Returns (obs, actions, logprobs, advantages, returns, values)[idx]."""
+    lp, adv, ret, val = [_f32(x, n).reshape(-1) for x, n in ((logprobs, 'logprobs'), (advantages, 'advantages'),
+                                                             (returns, 'returns'), (values, 'values'))]
+    n = lp.numel()
+    obs, actions = _f32(obs, 'obs'), _f32(actions, 'actions')
+    if obs.shape[0] != n or actions.shape[0] != n or adv.numel() != n or ret.numel() != n or val.numel() != n:
+        raise N.ParlHipError('ppo_sample_batch: all arrays must have the same leading size')
+    if idx.dtype != torch.int64:
+        raise N.ParlHipError('idx must be int64')
+    idx = idx.contiguous().reshape(-1)
+    m = idx.numel()
+    do = obs.numel() // n if n else 0
+    da = actions.numel() // n if n else 0
+    dev = lp.device
+    o_obs = torch.empty((m, ) + tuple(obs.shape[1:]), dtype=torch.float32, device=dev)
+    o_act = torch.empty((m, ) + tuple(actions.shape[1:]), dtype=torch.float32, device=dev)
+    o4 = [torch.empty(m, dtype=torch.float32, device=dev) for _ in range(4)]
+    N.check(
+        N.lib().parlhip_ppo_sample_batch_f32(N.ptr(obs), N.ptr(actions), N.ptr(lp), N.ptr(adv), N.ptr(ret), N.ptr(val),
+                                            N.ptr(idx), N.ptr(o_obs), N.ptr(o_act), N.ptr(o4[0]), N.ptr(o4[1]),
+                                            N.ptr(o4[2]), N.ptr(o4[3]), n, m, do, da, N.stream_ptr()),
+        'parlhip_ppo_sample_batch_f32')
+    return (o_obs, o_act) + tuple(o4)
+
+
 def consume_device_errors():
     """Synchronise and return/clear the device-side data-error flag (bad action index)."""
     return N.check(N.lib().parlhip_consume_device_errors(N.stream_ptr()),

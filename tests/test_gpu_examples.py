@@ -147,3 +147,28 @@ def test_async_actor_learner_two_groups_equals_one_vector(dev):
     np.testing.assert_allclose(float(la.total_loss), float(lb.total_loss), rtol=1e-5)
     for pa, pb in zip(model.parameters(), model_b.parameters()):
         np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-4, atol=2e-6)
+
+
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+    """bench.py's N>1 path (env sharding by rank, weight broadcast, flat-gradient all-reduce inside
+    the async actor/learner pipeline, trajectory all-gather, max-over-ranks timing) with two ranks
+    on the one GPU of the test box.  RCCL refuses two ranks per device, so the collectives go over
+    gloo here; the code path above the backend is the one the 8-GPU launch runs."""
+    import json
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PYTHONPATH=ROOT, PARL_AMD_SHARE_GPU='1', PARL_AMD_DIST_BACKEND='gloo',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--envs', '64', '--sample-batch-steps', '10', '--no-cpu-baseline']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=400, text=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(line) == 1, p.stdout[-2000:]
+    out = json.loads(line[0])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0
+    assert out['config']['train_batch'] == 2 * 64 * 10

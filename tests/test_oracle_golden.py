@@ -125,3 +125,63 @@ def test_adv_normalize_matches_torch(oracle):
     ref = ((ti - ti.mean()) / (ti.std() + 1e-8)).numpy()
     out, _ = oracle.adv_normalize(adv, idx)
     np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-6)
+
+
+# ---- PPO rows: VecNormalizeEnv running statistics and RolloutStorage.sample_batch ----
+def drive_vecnormalize(vn, g, filter_obs, filter_reward):
+    """Drive E VecNormalizeEnv twins the way ParallelEnv does (examples/PPO/env_utils.py:62-115):
+    reset; then per step: filter obs, filter reward, and for finished envs filter the reset obs."""
+    raw, rew, done, rst = g['raw_obs'], g['raw_rew'], g['done'], g['reset_obs']
+    S, E, D = raw.shape
+    k = np.zeros(E, np.int64)
+    first = filter_obs(rst[k, np.arange(E)], None)
+    k += 1
+    obs, term, r_out = np.zeros((S, E, D)), np.zeros((S, E, D)), np.zeros((S, E))
+    for t in range(S):
+        o = filter_obs(raw[t], None)
+        term[t] = o
+        r_out[t] = filter_reward(rew[t], done[t])
+        if done[t].any():
+            o2 = filter_obs(rst[k, np.arange(E)], done[t].astype(np.uint8))
+            o = np.where(done[t][:, None], o2, o)
+            k += done[t]
+        obs[t] = o
+    return first, obs, term, r_out
+
+
+@pytest.mark.parametrize('case', ['E6_D17_S60', 'E3_D5_S200'])
+def test_vecnormalize_bit_exact(oracle, case):
+    """oracle/ppo_oracle.c == the reference's VecNormalizeEnv / RunningMeanStd (float64, bit-exact)"""
+    g = golden_cases(load_golden('vecnormalize.npz'))[case]
+    S, E, D = g['raw_obs'].shape
+    vn = oracle.VecNormalize(E, D, gamma=0.99)
+    first, obs, term, rew = drive_vecnormalize(vn, g, vn.filter_obs, vn.filter_reward)
+    assert np.array_equal(first, g['first_obs'])
+    assert np.array_equal(term, g['obs_terminal'])
+    assert np.array_equal(obs, g['obs'])
+    assert np.array_equal(rew, g['rew'])
+    for mine, ref in [(vn.ob_mean, 'ob_mean'), (vn.ob_var, 'ob_var'), (vn.ob_count, 'ob_count'),
+                      (vn.ret_mean, 'ret_mean'), (vn.ret_var, 'ret_var'), (vn.ret_count, 'ret_count'),
+                      (vn.ret, 'ret')]:
+        assert np.array_equal(mine, g[ref]), ref
+
+
+@pytest.mark.parametrize('case', ['T12_E6', 'T9_E4_discrete'])
+def test_ppo_sample_batch_oracle(oracle, case):
+    """ring append (storage.py:35-43) + compute_returns + sample_batch (storage.py:66-76)"""
+    g = golden_cases(load_golden('ppo_sample_batch.npz'))[case]
+    steps, E = g['append_rewards'].shape
+    T = steps - 5
+    ring = {k: np.zeros((T, ) + g['append_' + k].shape[1:], np.float32)
+            for k in ('obs', 'actions', 'logprobs', 'rewards', 'dones', 'values')}
+    cur = 0
+    for t in range(steps):
+        for k in ring:
+            ring[k][cur] = g['append_' + k][t]
+        cur = (cur + 1) % T
+    assert cur == int(g['cur_step'])
+    adv, ret = oracle.gae(ring['rewards'], ring['values'], ring['dones'], g['value'], 0.99, 0.95,
+                          last_done=g['done'], done_convention=1)
+    out = oracle.ppo_sample_batch(ring['obs'], ring['actions'], ring['logprobs'], adv, ret, ring['values'], g['idx'])
+    for o, k in zip(out, ['obs', 'actions', 'logprobs', 'advantages', 'returns', 'values']):
+        assert np.array_equal(o.reshape(g['batch_' + k].shape), g['batch_' + k]), k
