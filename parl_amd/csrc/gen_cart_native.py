@@ -126,6 +126,34 @@ class Cart(object):
                     break
                 a = (a + length(mode)) & 0xffff
 
+    def entries(self):
+        """Addresses native_run can be ENTERED at (the cases of its dispatch switch).  Control only
+        comes back from the interpreter after it executed one deferred instruction, so the entry
+        points are: the vectors, the successor of every instruction with a deferral path (static
+        or dynamic), JSR targets and JSR / BRK return sites.  Every other block is reached only by
+        the program's own fall-through / goto edges, which lets the compiler optimise across
+        instruction boundaries (flag updates that are overwritten, cycle / counter adds that
+        merge) — with every address a switch case, each block had the dispatch as a predecessor.
+        A PC outside this set (computed JMP (), RTS tricks) is always safe: the switch returns, the
+        interpreter executes that instruction and dispatch is tried again at the next one."""
+        ent = {self.word(0xfffc), self.word(0xfffe)}
+        for a in self.code:
+            mode, kind, op, b1, b2 = self.code[a]
+            if mode == M_REL or op == 'JMP':
+                continue  # their only `return` is the instruction-budget guard
+            body = self.emit(a)
+            if not any('return' in ln for ln in body):
+                continue
+            if op == 'JSR':
+                ent |= {b1 | (b2 << 8), (a + 3) & 0xffff}
+            elif op == 'BRK':
+                ent.add((a + 2) & 0xffff)
+            elif op in ('RTS', 'RTI', 'JMPI', 'JAM'):
+                pass
+            else:
+                ent.add((a + length(mode)) & 0xffff)
+        return {a for a in ent if a in self.code}
+
     # ---- emission ----------------------------------------------------------------------------
     def label(self, a):
         return 'L_%04X' % a
@@ -301,7 +329,8 @@ class Cart(object):
         out.append('template <> DEVI void native_run<%s>(Emu& e, int& n) {' % game_const)
         out.append('  if (n > kNativeInstrLimit) return;')
         out.append('  switch (e.PC) {')
-        for a in addrs:
+        entries = self.entries()
+        for a in sorted(entries):
             out.append('    case 0x%04x: goto %s;' % (a, self.label(a)))
         out.append('    default: return;')
         out.append('  }')
