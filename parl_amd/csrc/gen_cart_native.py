@@ -22,8 +22,13 @@ bit-identical to pure interpretation (tests/test_gpu_env.py compare against the 
 Output: cart_native.gen.hpp (not committed: derived from user-supplied ROM data).
 Usage: gen_cart_native.py <out.hpp> [name=path.bin ...]   (name in {pong, breakout})
 """
+import os
 import sys
 import zlib
+
+# PARLHIP_CART_MARKERS=1: emit an asm comment at every block start (profiling builds only:
+# tools/cart_profile.py maps the compiled ISA back to 6507 addresses)
+MARKERS = bool(os.environ.get('PARLHIP_CART_MARKERS'))
 
 # ---- mirrors atari_defs.hpp (decode_opcode) ------------------------------------------------------
 M_IMP, M_IMM, M_ZP, M_ZPX, M_ZPY, M_ABS, M_ABX, M_ABY, M_IZX, M_IZY, M_REL, M_PUSH, M_PULL = range(13)
@@ -268,12 +273,12 @@ class Cart(object):
                 cond = '(e.P & %s)' % flag if want else '!(e.P & %s)' % flag
                 body = 'e.cyc += %d; ' % dc
                 if tgt <= a:  # backward edge: the only place a frame can loop without bound
-                    body += 'if (n > kNativeInstrLimit) { e.PC = 0x%04x; return; } ' % tgt
+                    body += 'if (__builtin_expect(n > kNativeInstrLimit, 0)) { e.PC = 0x%04x; return; } ' % tgt
                 body += self.goto(tgt)
                 return ['if (%s) { %s }' % (cond, body), 'e.cyc += 2;']
             if op == 'JMP':
                 tgt = b1 | (b2 << 8)
-                return ['e.cyc += 3;', 'if (n > kNativeInstrLimit) { e.PC = 0x%04x; return; }' % tgt, self.goto(tgt)]
+                return ['e.cyc += 3;', 'if (__builtin_expect(n > kNativeInstrLimit, 0)) { e.PC = 0x%04x; return; }' % tgt, self.goto(tgt)]
             return fb  # JSR / RTS / RTI / BRK / JMP () / JAM
         # ---- stores and read-modify-writes (zero-page class only, as in step_fast) ----
         if mode == M_ZP:
@@ -289,18 +294,22 @@ class Cart(object):
         if kind == K_WRITE:
             val = {'STA': 'e.A', 'STX': 'e.X', 'STY': 'e.Y', 'PHA': 'e.A', 'PHP': '(e.P | FB | FU)'}[op]
             dec_s = ' e.S = (e.S - 1) & 0xff;' if mode == M_PUSH else ''
+            # A real TIA register change: the block finishes what step_fast does for the store (S,
+            # cycles up to the write cycle, PC) and hands (address, value) to the interpreter's TIA
+            # stages through e.pend — no opcode fetch / decode there (Emu::step).
+            pend = '{ --n;%s e.cyc += %d; e.pend = %%s | ((%s) << 8); e.PC = 0x%04x; return; }' % (dec_s, dc - 1, val, nxt)
             if static is not None:
                 if static & 0x80:
                     return ['e.ram_wr(0x%02x, %s);' % (static & 0x7f, val), 'e.cyc += %d;' % dc]
                 reg = static & 0x3f
                 if reg == 0x02:  # WSYNC
                     return ['e.wsync(e.cyc + %d);' % dc]
-                return ['if (!e.tia_store_is_nop(0x%02x, %s)) { --n; e.PC = 0x%04x; return; }' % (reg, val, a),
+                return ['if (__builtin_expect(!e.tia_store_is_nop(0x%02x, %s), 0)) %s' % (reg, val, pend % ('0x%02x' % static)),
                         'e.cyc += %d;' % dc]
             return [
                 'const int ea = %s;' % ea,
                 'if (ea & 0x80) e.ram_wr(ea & 0x7f, %s);' % val,
-                'else if (!e.tia_store_is_nop(ea & 0x3f, %s)) { --n; e.PC = 0x%04x; return; }' % (val, a),
+                'else if (__builtin_expect(!e.tia_store_is_nop(ea & 0x3f, %s), 0)) %s' % (val, pend % 'ea'),
                 ('%s e.cyc += %d;' % (dec_s, dc)).strip()
             ]
         # K_RMW
@@ -341,6 +350,8 @@ class Cart(object):
             is_fb = len(body) == 1 and body[0].startswith('{ e.PC')
             native += 0 if is_fb else 1
             out.append('  %s: {  // %s mode %d' % (self.label(a), op, mode))
+            if MARKERS:
+                out.append('    asm volatile("; @@BLK %04x");' % a)
             if is_fb:
                 out.append('    ' + body[0])
             else:

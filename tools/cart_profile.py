@@ -1,0 +1,59 @@
+"""Dev tool (CPU only): static cost model of the translated cartridge code.
+
+Input: the gfx950 assembly of a marker build of atari_env.hip (PARLHIP_CART_MARKERS=1 makes
+gen_cart_native.py emit an asm comment at every block start) and a per-address execution histogram
+of the game produced by an instrumented build of the CPU oracle.  Output: ISA instructions per 6507
+block weighted by how often the block runs = where the translated code spends its issue slots.
+Approximate (instructions are attributed to the last marker above them in layout order), used to
+pick what to optimise before spending GPU time."""
+import collections
+import re
+import sys
+
+
+def main(asm, hist, kernel_index=0, top=30):
+    kernels, cur = [], None
+    for ln in open(asm):
+        if ln.startswith('_ZN7parlhip5atari16atari_env_kernel') and ln.rstrip().endswith(':') or ': ; @_ZN7parlhip5atari16atari_env_kernel' in ln:
+            cur = []
+            kernels.append(cur)
+        elif cur is not None:
+            cur.append(ln)
+            if 's_endpgm' in ln:
+                cur = None
+    lines = kernels[kernel_index]
+    counts, kinds = collections.Counter(), collections.defaultdict(collections.Counter)
+    blk = None
+    for ln in lines:
+        t = ln.strip()
+        m = re.match(r'; @@BLK ([0-9a-f]{4})', t)
+        if m:
+            blk = int(m.group(1), 16)
+            continue
+        if not t or t.startswith((';', '.', '//')) or t.endswith(':'):
+            continue
+        counts[blk] += 1
+        op = t.split()[0]
+        k = 'branch' if op.startswith(('s_cbranch', 's_branch', 's_setpc')) else ('lane' if 'lane' in op else (
+            'valu' if op.startswith('v_') else ('lds' if op.startswith('ds_') else ('wait' if op.startswith(('s_waitcnt', 's_nop')) else 'salu'))))
+        kinds[blk][k] += 1
+    dyn = {}
+    for ln in open(hist):
+        pc, cnt, _ = ln.split()
+        dyn[int(pc, 16)] = float(cnt)
+    tot = sum(counts.get(pc, 0) * c for pc, c in dyn.items())
+    ninstr = sum(dyn.values())
+    print('6507 instructions / frame %.0f; modelled ISA instructions / frame %.0f (%.1f per 6507 instruction); '
+          'prologue+unattributed static %d' % (ninstr, tot, tot / ninstr, counts.get(None, 0)))
+    agg = collections.Counter()
+    for pc, c in dyn.items():
+        for k, v in kinds.get(pc, {}).items():
+            agg[k] += v * c
+    print('mix per frame:', {k: round(v) for k, v in agg.most_common()})
+    rows = sorted(((counts.get(pc, 0) * c, pc, c) for pc, c in dyn.items()), reverse=True)[:top]
+    for w, pc, c in rows:
+        print('  %04x  runs %7.1f  isa %4d  weight %8.0f  %s' % (pc, c, counts.get(pc, 0), w, dict(kinds.get(pc, {}))))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0, int(sys.argv[4]) if len(sys.argv) > 4 else 30)
