@@ -64,7 +64,7 @@ DEVI void load_env(Emu& e, Wrap& v, const uint8_t* blob, int lane) {
   e.ram_hi = blob[kOffRam + 64 + lane];
   e.tia = blob[kOffTia + lane];
   auto L = [&](int i) { return rfl(s[i]); };
-  e.A = L(S_A); e.X = L(S_X); e.Y = L(S_Y); e.S = L(S_S); e.P = L(S_P); e.PC = L(S_PC);
+  e.A = L(S_A); e.X = L(S_X); e.Y = L(S_Y); e.S = L(S_S); e.pset(L(S_P)); e.PC = L(S_PC);
   e.cyc = L(S_CYC); e.cyc0 = L(S_CYC0); e.last_clock = L(S_LAST_CLOCK);
   e.vsync_finish = L(S_VSYNC_FINISH); e.dump_dis_cyc = L(S_DUMP_DIS_CYC); e.dump_en = L(S_DUMP_EN);
   e.timer = L(S_TIMER); e.timer_shift = L(S_TIMER_SHIFT); e.timer_set_cyc = L(S_TIMER_SET_CYC);
@@ -86,7 +86,7 @@ DEVI void store_env(const Emu& e, const Wrap& v, uint8_t* blob, int lane) {
   blob[kOffRam + 64 + lane] = (uint8_t)e.ram_hi;
   blob[kOffTia + lane] = (uint8_t)e.tia;
   if (lane == 0) {
-    s[S_A] = e.A; s[S_X] = e.X; s[S_Y] = e.Y; s[S_S] = e.S; s[S_P] = e.P; s[S_PC] = e.PC;
+    s[S_A] = e.A; s[S_X] = e.X; s[S_Y] = e.Y; s[S_S] = e.S; s[S_P] = e.pfull(); s[S_PC] = e.PC;
     s[S_BUS] = 0;
     s[S_CYC] = e.cyc; s[S_CYC0] = e.cyc0; s[S_LAST_CLOCK] = e.last_clock;
     s[S_VSYNC_FINISH] = e.vsync_finish; s[S_DUMP_DIS_CYC] = e.dump_dis_cyc; s[S_DUMP_EN] = e.dump_en;

@@ -172,13 +172,12 @@ class Cart(object):
         return ['{ e.PC = 0x%04x; return; }' % a]
 
     def emit_read_op(self, op):
-        P = 'e.P'
         return {
             'LDA': 'e.A = m; e.set_nz(e.A);', 'LDX': 'e.X = m; e.set_nz(e.X);', 'LDY': 'e.Y = m; e.set_nz(e.Y);',
             'ORA': 'e.A |= m; e.set_nz(e.A);', 'AND': 'e.A &= m; e.set_nz(e.A);', 'EOR': 'e.A ^= m; e.set_nz(e.A);',
             'ADC': 'e.adc(m);', 'SBC': 'e.sbc(m);', 'CMP': 'e.cmp(e.A, m);', 'CPX': 'e.cmp(e.X, m);',
             'CPY': 'e.cmp(e.Y, m);',
-            'BIT': '%s = (%s & ~(FN | FV | FZ)) | (m & 0xc0) | ((e.A & m) ? 0 : FZ);' % (P, P),
+            'BIT': 'e.bit(m);',
         }[op]
 
     def emit(self, a):
@@ -248,15 +247,15 @@ class Cart(object):
             return L
         if kind == K_NONE:
             simple = {
-                'ASL_A': 'e.P = (e.P & ~FC) | (e.A >> 7); e.A = (e.A << 1) & 0xff; e.set_nz(e.A);',
-                'LSR_A': 'e.P = (e.P & ~FC) | (e.A & 1); e.A = e.A >> 1; e.set_nz(e.A);',
-                'ROL_A': '{ const int c = e.P & FC; e.P = (e.P & ~FC) | (e.A >> 7); e.A = ((e.A << 1) | c) & 0xff; e.set_nz(e.A); }',
-                'ROR_A': '{ const int c = e.P & FC; e.P = (e.P & ~FC) | (e.A & 1); e.A = (e.A >> 1) | (c << 7); e.set_nz(e.A); }',
+                'ASL_A': 'e.cf = e.A >> 7; e.A = (e.A << 1) & 0xff; e.set_nz(e.A);',
+                'LSR_A': 'e.cf = e.A & 1; e.A = e.A >> 1; e.set_nz(e.A);',
+                'ROL_A': '{ const int c = e.cf; e.cf = e.A >> 7; e.A = ((e.A << 1) | c) & 0xff; e.set_nz(e.A); }',
+                'ROR_A': '{ const int c = e.cf; e.cf = e.A & 1; e.A = (e.A >> 1) | (c << 7); e.set_nz(e.A); }',
                 'INX': 'e.X = (e.X + 1) & 0xff; e.set_nz(e.X);', 'INY': 'e.Y = (e.Y + 1) & 0xff; e.set_nz(e.Y);',
                 'DEX': 'e.X = (e.X - 1) & 0xff; e.set_nz(e.X);', 'DEY': 'e.Y = (e.Y - 1) & 0xff; e.set_nz(e.Y);',
                 'TAX': 'e.X = e.A; e.set_nz(e.X);', 'TAY': 'e.Y = e.A; e.set_nz(e.Y);',
                 'TXA': 'e.A = e.X; e.set_nz(e.A);', 'TYA': 'e.A = e.Y; e.set_nz(e.A);',
-                'TSX': 'e.X = e.S; e.set_nz(e.X);', 'TXS': 'e.S = e.X;', 'CLC': 'e.P &= ~FC;', 'SEC': 'e.P |= FC;',
+                'TSX': 'e.X = e.S; e.set_nz(e.X);', 'TXS': 'e.S = e.X;', 'CLC': 'e.cf = 0;', 'SEC': 'e.cf = 1;',
                 'CLI': 'e.P &= ~FI;', 'SEI': 'e.P |= FI;', 'CLV': 'e.P &= ~FV;', 'CLD': 'e.P &= ~FD;',
                 'SED': 'e.P |= FD;', 'NOP': '',
             }
@@ -270,7 +269,8 @@ class Cart(object):
                 npc = (a + 2) & 0xffff
                 tgt = (npc + (b1 - 256 if b1 & 0x80 else b1)) & 0xffff
                 dc = 2 + (2 if ((tgt ^ npc) & 0xff00) else 1)
-                cond = '(e.P & %s)' % flag if want else '!(e.P & %s)' % flag
+                test = {'FN': '(e.nv & 0x80)', 'FZ': '((e.zv & 0xff) == 0)', 'FC': 'e.cf', 'FV': '(e.P & FV)'}[flag]
+                cond = test if want else '!' + test
                 body = 'e.cyc += %d; ' % dc
                 if tgt <= a:  # backward edge: the only place a frame can loop without bound
                     body += 'if (__builtin_expect(n > kNativeInstrLimit, 0)) { e.PC = 0x%04x; return; } ' % tgt
@@ -292,7 +292,7 @@ class Cart(object):
         else:
             return fb
         if kind == K_WRITE:
-            val = {'STA': 'e.A', 'STX': 'e.X', 'STY': 'e.Y', 'PHA': 'e.A', 'PHP': '(e.P | FB | FU)'}[op]
+            val = {'STA': 'e.A', 'STX': 'e.X', 'STY': 'e.Y', 'PHA': 'e.A', 'PHP': '(e.pfull() | FB | FU)'}[op]
             dec_s = ' e.S = (e.S - 1) & 0xff;' if mode == M_PUSH else ''
             # A real TIA register change: the block finishes what step_fast does for the store (S,
             # cycles up to the write cycle, PC) and hands (address, value) to the interpreter's TIA
@@ -314,10 +314,10 @@ class Cart(object):
             ]
         # K_RMW
         rmw = {
-            'ASL': 'e.P = (e.P & ~FC) | (m >> 7); wv = (m << 1) & 0xff;',
-            'LSR': 'e.P = (e.P & ~FC) | (m & 1); wv = m >> 1;',
-            'ROL': '{ const int c = e.P & FC; e.P = (e.P & ~FC) | (m >> 7); wv = ((m << 1) | c) & 0xff; }',
-            'ROR': '{ const int c = e.P & FC; e.P = (e.P & ~FC) | (m & 1); wv = (m >> 1) | (c << 7); }',
+            'ASL': 'e.cf = m >> 7; wv = (m << 1) & 0xff;',
+            'LSR': 'e.cf = m & 1; wv = m >> 1;',
+            'ROL': '{ const int c = e.cf; e.cf = m >> 7; wv = ((m << 1) | c) & 0xff; }',
+            'ROR': '{ const int c = e.cf; e.cf = m & 1; wv = (m >> 1) | (c << 7); }',
             'INC': 'wv = (m + 1) & 0xff;', 'DEC': 'wv = (m - 1) & 0xff;',
         }[op]
         if static is not None and not (static & 0x80):
