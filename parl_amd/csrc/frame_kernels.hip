@@ -18,6 +18,7 @@ namespace atari {
 // Algorithmic bytes per env-step: 2*33,600 read + dim*dim written.
 // ========================================================================================
 struct Tap { int si; float alpha; };
+constexpr int kMaxDim = 210;  // parlhip_frame_post_u8 accepts 1 <= dim <= 210
 
 DEVI uint32_t gray_of_colors(uint32_t c0, uint32_t c1, const uint32_t* pal) {
   const uint32_t a = pal[c0 >> 1], b = pal[c1 >> 1];
@@ -41,6 +42,16 @@ __global__ __launch_bounds__(256) void frame_post_kernel(
   const Tap* yt = (const Tap*)(blob + hdr[6]);
   const uint32_t* pal_g = (const uint32_t*)(blob + hdr[7]) - 128;
   if (threadIdx.x < 128) pal[threadIdx.x] = pal_g[threadIdx.x];
+  // the tap tables are read ~30 times per output pixel in dependent chains: stage them in LDS
+  // (global / L2 latency per tap made this kernel latency-bound at ~0.5 TB/s)
+  __shared__ int s_xstart[kMaxDim + 1], s_ystart[kMaxDim + 1];
+  __shared__ Tap s_xt[kW + 2 * kMaxDim], s_yt[kH + 2 * kMaxDim];  // area_tab: <= src + 2 * dst taps
+  for (int i = threadIdx.x; i <= dim; i += blockDim.x) { s_xstart[i] = xstart[i]; s_ystart[i] = ystart[i]; }
+  {
+    const int nx = xstart[dim], ny = ystart[dim];
+    for (int i = threadIdx.x; i < nx; i += blockDim.x) s_xt[i] = xt[i];
+    for (int i = threadIdx.x; i < ny; i += blockDim.x) s_yt[i] = yt[i];
+  }
   __syncthreads();
   const bool single = (frames1 == nullptr) || (flags && (flags[e] & 1));
   const uint8_t* f0 = frames0 + (size_t)e * in_stride;
@@ -76,14 +87,19 @@ __global__ __launch_bounds__(256) void frame_post_kernel(
   uint8_t* o = out + (size_t)e * out_stride;
   for (int p = threadIdx.x; p < dim * dim; p += blockDim.x) {
     const int dy = p / dim, dx = p - dy * dim;
-    const int x0 = xstart[dx], x1 = xstart[dx + 1];
+    const int x0 = s_xstart[dx], x1 = s_xstart[dx + 1];
+    const int j0 = s_ystart[dy], j1 = s_ystart[dy + 1];
     float sum = 0.f;
-    for (int j = ystart[dy]; j < ystart[dy + 1]; ++j) {
-      const uint8_t* S = gray + yt[j].si * kW;
+    for (int j = j0; j < j1; ++j) {
+      const Tap ty = s_yt[j];
+      const uint8_t* S = gray + ty.si * kW;
       float buf = 0.f;
-      for (int k = x0; k < x1; ++k) buf = __fadd_rn(buf, __fmul_rn((float)S[xt[k].si], xt[k].alpha));
-      const float tmp = __fmul_rn(yt[j].alpha, buf);
-      sum = (j == ystart[dy]) ? tmp : __fadd_rn(sum, tmp);
+      for (int k = x0; k < x1; ++k) {
+        const Tap tx = s_xt[k];
+        buf = __fadd_rn(buf, __fmul_rn((float)S[tx.si], tx.alpha));
+      }
+      const float tmp = __fmul_rn(ty.alpha, buf);
+      sum = (j == j0) ? tmp : __fadd_rn(sum, tmp);
     }
     // cv::saturate_cast<uchar>(float): cvRound (round half to even) then clamp
     int r = (int)__builtin_rintf(sum);
