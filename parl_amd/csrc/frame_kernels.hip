@@ -18,7 +18,6 @@ namespace atari {
 // Algorithmic bytes per env-step: 2*33,600 read + dim*dim written.
 // ========================================================================================
 struct Tap { int si; float alpha; };
-constexpr int kMaxDim = 210;  // parlhip_frame_post_u8 accepts 1 <= dim <= 210
 
 DEVI uint32_t gray_of_colors(uint32_t c0, uint32_t c1, const uint32_t* pal) {
   const uint32_t a = pal[c0 >> 1], b = pal[c1 >> 1];
@@ -28,12 +27,23 @@ DEVI uint32_t gray_of_colors(uint32_t c0, uint32_t c1, const uint32_t* pal) {
   return (r * 4899u + g * 9617u + bb * 1868u + 8192u) >> 14;
 }
 
-__global__ __launch_bounds__(256) void frame_post_kernel(
+// LDS of one workgroup: gray frame + palette + the tap tables, sized by the bound of area_tab
+// (<= src + 2 * dst taps per axis) so that dim <= 84 fits 4 workgroups per CU (<= 40 KB each)
+static inline size_t frame_post_lds_bytes(int dim) {
+  return (size_t)kFrameBytes + 128 * 4 + (size_t)(kW + kH + 4 * dim) * sizeof(Tap) + 2 * (size_t)(dim + 1) * 4;
+}
+
+__global__ __launch_bounds__(512) void frame_post_kernel(
     const uint8_t* __restrict__ frames0, const uint8_t* __restrict__ frames1, int64_t in_stride,
     int fmt, const uint8_t* __restrict__ flags, uint8_t* __restrict__ out, int64_t out_stride,
     int dim, const uint8_t* __restrict__ blob) {
-  __shared__ uint8_t gray[kFrameBytes];
-  __shared__ uint32_t pal[128];
+  extern __shared__ __attribute__((aligned(16))) uint8_t fp_lds[];
+  uint8_t* gray = fp_lds;                                   // [kFrameBytes] (33,600: 16-byte multiple)
+  uint32_t* pal = (uint32_t*)(fp_lds + kFrameBytes);        // [128]
+  Tap* s_xt = (Tap*)(pal + 128);                            // [<= kW + 2 dim]
+  Tap* s_yt = s_xt + (kW + 2 * dim);                        // [<= kH + 2 dim]
+  int* s_xstart = (int*)(s_yt + (kH + 2 * dim));            // [dim + 1]
+  int* s_ystart = s_xstart + (dim + 1);                     // [dim + 1]
   const int e = blockIdx.x;
   const int* hdr = (const int*)blob;
   const int* xstart = (const int*)(blob + hdr[3]);
@@ -44,8 +54,6 @@ __global__ __launch_bounds__(256) void frame_post_kernel(
   if (threadIdx.x < 128) pal[threadIdx.x] = pal_g[threadIdx.x];
   // the tap tables are read ~30 times per output pixel in dependent chains: stage them in LDS
   // (global / L2 latency per tap made this kernel latency-bound at ~0.5 TB/s)
-  __shared__ int s_xstart[kMaxDim + 1], s_ystart[kMaxDim + 1];
-  __shared__ Tap s_xt[kW + 2 * kMaxDim], s_yt[kH + 2 * kMaxDim];  // area_tab: <= src + 2 * dst taps
   for (int i = threadIdx.x; i <= dim; i += blockDim.x) { s_xstart[i] = xstart[i]; s_ystart[i] = ystart[i]; }
   {
     const int nx = xstart[dim], ny = ystart[dim];
@@ -244,8 +252,18 @@ PARLHIP_EXPORT int parlhip_frame_post_u8(const uint8_t* frames0, const uint8_t* 
   if (fmt == 1 && ((reinterpret_cast<uintptr_t>(frames0) | (uintptr_t)in_stride |
                     (frames1 ? reinterpret_cast<uintptr_t>(frames1) : 0)) & 15))
     return PARLHIP_EINVAL;
-  frame_post_kernel<<<E, 256, 0, (hipStream_t)stream>>>(frames0, frames1, in_stride, fmt, flags, out,
-                                                        out_stride, dim, (const uint8_t*)tables_dev);
+  const size_t lds = frame_post_lds_bytes(dim);
+  if (lds > 48 * 1024) {  // dim > ~84: beyond the default dynamic-LDS limit, raise it once
+    static int raised_for = 0;
+    if (raised_for < (int)lds) {
+      int rc = check(hipFuncSetAttribute((const void*)frame_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+      if (rc) return rc;
+      raised_for = (int)lds;
+    }
+  }
+  frame_post_kernel<<<E, 512, lds, (hipStream_t)stream>>>(frames0, frames1, in_stride, fmt, flags, out,
+                                                          out_stride, dim, (const uint8_t*)tables_dev);
   return check_launch();
 }
 

@@ -95,6 +95,14 @@ def main():
         s = timeit(lambda: ops.atari42_conv12(obs, w1, b1, w2, b2, out=out))
         fl = n * 2.0 * (441 * 16 * 64 + 121 * 32 * 256)
         res['conv12_u8_mfma_n%d' % n] = {'us': s * 1e6, 'TFLOPs': fl / s / 1e12, 'GBps': n * (7056 + 15488) / s / 1e9}
+    from parl_amd.env import DeviceVectorEnv
+    for dim in (42, 84):
+        env = DeviceVectorEnv('PongNoFrameskip-v4', 1024, dim=dim, horizon=8, seed=1, device=dev)
+        env.reset()
+        env.step_async(torch.zeros(1024, dtype=torch.int64, device=dev))
+        s = timeit(lambda: env._frame_post(1))
+        by = 1024 * (2 * 33600 + dim * dim)
+        res['frame_post_since_E1024_d%d' % dim] = {'us': s * 1e6, 'GBps': by / s / 1e9, 'bytes': by}
     for k, v in res.items():
         print(k, {a: (round(b, 2) if isinstance(b, float) else b) for a, b in v.items()})
     if args.json:
