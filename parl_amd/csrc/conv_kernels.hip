@@ -9,7 +9,7 @@
 // 115 + 127 MB per step at 1024 envs), no intermediate activations in HBM.
 //
 // One workgroup (4 wavefronts) per observation.  Both convolutions are implicit GEMMs on the
-// f32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32 FMA chains):
+// f32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32 FMA chains), weights held in registers:
 //   conv1: [441 positions x 64] x [64 x 16]   A gathered from the zero-padded input in LDS
 //   conv2: [121 positions x 256] x [256 x 32] A gathered from the zero-padded conv1 output in LDS
 // with k = c*16 + kh*4 + kw (the order of weight.flatten(1)).  Operand maps (guide: A[l&15][l>>4],
@@ -26,31 +26,53 @@ constexpr int kP2 = 25;                   // zero-padded conv1 output (pad 2)
 constexpr int kO2 = 11, kC2 = 32;         // conv2 output size / channels
 constexpr int kM1 = kO1 * kO1, kM2 = kO2 * kO2;
 constexpr int kK1 = 64, kK2 = 256;
-constexpr int kLdsIn = 4 * kP1 * kP1;     // 7744 floats (reused as the output staging area)
+constexpr int kLdsIn = 4 * kP1 * kP1;     // 7744 floats
 constexpr int kLdsC1 = kC1 * kP2 * kP2;   // 10000
-constexpr int kLdsFloats = kLdsIn + kLdsC1 + kK1 * kC1 + kK2 * kC2;  // 26,960 floats = 107,840 B
+constexpr int kLdsFloats = kLdsIn + kLdsC1;  // 17,744 floats = 70,976 B: two workgroups per CU
 
+// Both weight matrices live in registers (B operands: 16 + 128 VGPRs per lane, loaded once per
+// workgroup), so an MFMA needs one LDS gather (conv1) or half of one (conv2: both N-tiles reuse
+// the A value); outputs leave the accumulators straight for HBM; the zero borders of the two LDS
+// tiles are written once and never touched again (only interiors are rewritten per observation).
 __global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
     const uint8_t* __restrict__ obs, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ out, int n_obs) {
   extern __shared__ float lds[];
   float* in_pad = lds;                  // [4][44][44]
   float* c1_pad = in_pad + kLdsIn;      // [16][25][25]
-  float* w1t = c1_pad + kLdsC1;         // [64][16]
-  float* w2t = w1t + kK1 * kC1;         // [256][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // weights -> LDS, transposed to [k][n] (B operand rows); zero the padded buffers once
-  for (int i = tid; i < kK1 * kC1; i += 256) w1t[(i & 63) * kC1 + (i >> 6)] = w1[i];       // w1[n][k]
-  for (int i = tid; i < kK2 * kC2; i += 256) w2t[(i & 255) * kC2 + (i >> 8)] = w2[i];      // w2[n][k]
-  for (int i = tid; i < kLdsIn + kLdsC1; i += 256) lds[i] = 0.0f;
-  __syncthreads();
   const int q = lane >> 4, col = lane & 15;
+  // B[k][n] = w[n][k]: lane (q, col) holds k = 4*ks + q, n = col (+16 for the second N-tile)
+  float bw1[16], bw2[64][2];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) bw1[ks] = w1[col * kK1 + ks * 4 + q];
+#pragma unroll
+  for (int ks = 0; ks < 64; ++ks) {
+    bw2[ks][0] = w2[col * kK2 + ks * 4 + q];
+    bw2[ks][1] = w2[(16 + col) * kK2 + ks * 4 + q];
+  }
+  const float bias1 = b1[col], bias20 = b2[col], bias21 = b2[16 + col];
+  for (int i = tid; i < kLdsFloats; i += 256) lds[i] = 0.0f;
   for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
+    __syncthreads();  // borders zeroed / the previous observation's conv2 gathers are done
     // ---- obs u8 -> padded float input (x / 255, the division as in the reference) ----
     const uint8_t* src = obs + (size_t)n * 4 * kD * kD;
-    for (int i = tid; i < 4 * kD * kD; i += 256) {
-      const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
-      in_pad[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = (float)src[i] / 255.0f;
+    if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {  // wave-uniform: 7056 B per observation
+      const uint32_t* src32 = reinterpret_cast<const uint32_t*>(src);
+      for (int wi = tid; wi < kD * kD; wi += 256) {   // 4 * 1764 bytes = 1764 words
+        const uint32_t v = src32[wi];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = wi * 4 + j;
+          const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
+          in_pad[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = (float)((v >> (8 * j)) & 255u) / 255.0f;
+        }
+      }
+    } else {
+      for (int i = tid; i < 4 * kD * kD; i += 256) {
+        const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
+        in_pad[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = (float)src[i] / 255.0f;
+      }
     }
     __syncthreads();
     // ---- conv1: 28 M-tiles of 16 positions, 7 per wave ----
@@ -59,61 +81,48 @@ __global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
       m = m < kM1 ? m : kM1 - 1;
       const int oy = m / kO1, ox = m - oy * kO1;
       const float* a_base = in_pad + (2 * oy) * kP1 + 2 * ox + q;
-      const float* b_base = w1t + q * kC1 + col;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         const float a = a_base[(ks >> 2) * kP1 * kP1 + (ks & 3) * kP1];
-        const float b = b_base[ks * 4 * kC1];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw1[ks], acc, 0, 0, 0);
       }
-      const float bias = b1[col];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int mo = t * 16 + q * 4 + r;  // D row
         if (mo < kM1) {
           const int y = mo / kO1, x = mo - y * kO1;
-          const float v = acc[r] + bias;
+          const float v = acc[r] + bias1;
           c1_pad[col * kP2 * kP2 + (y + 2) * kP2 + (x + 2)] = v > 0.f ? v : 0.f;
         }
       }
     }
     __syncthreads();
-    // ---- conv2: 8 M-tiles x 2 N-tiles, 4 (tile pairs) per wave ----
-    float* stage = in_pad;  // [32][121] output staging (input no longer needed)
-    for (int t = wave; t < 16; t += 4) {
-      const int mt = t >> 1, nt = t & 1;
+    // ---- conv2: 8 M-tiles, 2 per wave, both N-tiles per A gather; D goes straight to HBM ----
+    float* dst = out + (size_t)n * kC2 * kM2;
+    for (int mt = wave; mt < 8; mt += 4) {
       int m = mt * 16 + col;
       m = m < kM2 ? m : kM2 - 1;
       const int oy = m / kO2, ox = m - oy * kO2;
       const float* a_base = c1_pad + (2 * oy) * kP2 + 2 * ox + q;
-      const float* b_base = w2t + q * kC2 + nt * 16 + col;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
       for (int ks = 0; ks < 64; ++ks) {
         const float a = a_base[(ks >> 2) * kP2 * kP2 + (ks & 3) * kP2];
-        const float b = b_base[ks * 4 * kC2];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw2[ks][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw2[ks][1], acc1, 0, 0, 0);
       }
-      const int ch = nt * 16 + col;
-      const float bias = b2[ch];
+      // D: column = channel, rows 4q..4q+3 = 4 consecutive positions of the [32][121] row
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int mo = mt * 16 + q * 4 + r;
         if (mo < kM2) {
-          const float v = acc[r] + bias;
-          stage[ch * kM2 + mo] = v > 0.f ? v : 0.f;
+          const float v0 = acc0[r] + bias20, v1 = acc1[r] + bias21;
+          dst[col * kM2 + mo] = v0 > 0.f ? v0 : 0.f;
+          dst[(16 + col) * kM2 + mo] = v1 > 0.f ? v1 : 0.f;
         }
       }
     }
-    __syncthreads();
-    // ---- coalesced write of the [32*11*11] activation row (NCHW flatten order) ----
-    float* dst = out + (size_t)n * kC2 * kM2;
-    for (int i = tid; i < kC2 * kM2; i += 256) dst[i] = stage[i];
-    __syncthreads();
-    // re-zero the input padding the staging area overwrote
-    for (int i = tid; i < kLdsIn; i += 256) in_pad[i] = 0.0f;
-    __syncthreads();
   }
 }
 
@@ -227,7 +236,7 @@ PARLHIP_EXPORT int parlhip_atari42_conv12_u8_f32(const uint8_t* obs, const float
     if (rc) return rc;
     attr_set = true;
   }
-  const int grid = n_obs < 4 * kNumCU ? n_obs : 4 * kNumCU;
+  const int grid = n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU;  // 71 KB of LDS: two workgroups per CU
   conv12_u8_mfma_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(obs, w1, b1, w2, b2, out, n_obs);
   return check_launch();
 }

@@ -1,1 +1,1 @@
-from .atari_model import AtariModel42, AtariModel84  # noqa: F401
+from .atari_model import AtariModel42, AtariModel84, GemmConv2d  # noqa: F401

@@ -172,3 +172,14 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     out = json.loads(line[0])
     assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0
     assert out['config']['train_batch'] == 2 * 64 * 10
+
+
+def test_ppo_example_atari_runs():
+    out = _run(['examples/PPO/train.py', '--env_num', '8', '--step_nums', '32', '--train_total_steps', '512'])
+    assert "'value_loss': " in out and "'update': 2" in out
+
+
+def test_ppo_example_continuous_runs():
+    out = _run(['examples/PPO/train.py', '--continuous_action', '--env_num', '64', '--step_nums', '64',
+                '--train_total_steps', '8192'])
+    assert "'action_loss': " in out and "'update': 2" in out
