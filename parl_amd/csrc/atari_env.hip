@@ -70,7 +70,7 @@ DEVI void load_env(Emu& e, Wrap& v, const uint8_t* blob, int lane) {
   e.timer = L(S_TIMER); e.timer_shift = L(S_TIMER_SHIFT); e.timer_set_cyc = L(S_TIMER_SET_CYC);
   e.ddra = L(S_DDRA); e.ddrb = L(S_DDRB); e.swcha_out = L(S_SWCHA_OUT); e.swchb_out = L(S_SWCHB_OUT);
   e.cx = L(S_CX); e.jam = L(S_JAM); e.stop = 0;
-  e.paddle_res0 = e.paddle_res1 = kPaddleDefault; e.fire0 = e.fire1 = e.sw_reset = 0;
+  e.pneed0 = e.pneed1 = Emu::paddle_needed(kPaddleDefault); e.fire0 = e.fire1 = e.sw_reset = 0;
   e.fb = nullptr;
   v.paddle = L(S_PADDLE); v.score = L(S_SCORE); v.terminal = L(S_TERMINAL);
   v.ale_lives = L(S_ALE_LIVES); v.started = L(S_STARTED); v.frame_number = L(S_FRAME_NUMBER);
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
       v.paddle += delta;
       v.paddle = v.paddle < kPaddleMin ? kPaddleMin : (v.paddle > kPaddleMax ? kPaddleMax : v.paddle);
       const bool swap = game == GAME_PONG;  // Stella props: Video Olympics SwapPaddles=YES
-      emu.paddle_res0 = swap ? kPaddleDefault : v.paddle;
-      emu.paddle_res1 = swap ? v.paddle : kPaddleDefault;
+      emu.pneed0 = Emu::paddle_needed(swap ? kPaddleDefault : v.paddle);
+      emu.pneed1 = Emu::paddle_needed(swap ? v.paddle : kPaddleDefault);
       emu.fire0 = swap ? 0 : fire;
       emu.fire1 = swap ? fire : 0;
     }

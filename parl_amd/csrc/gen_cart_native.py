@@ -221,12 +221,21 @@ class Cart(object):
                 if always_rom:
                     pre += ['m = e.rom_byte(ea);']
                 else:
-                    pre += [
-                        'if (ea & 0x1000) m = e.rom_byte(ea);', 'else if ((ea & 0x280) == 0x80) m = e.ram_rd(ea & 0x7f);',
-                        'else if ((ea & 0x280) == 0x280) { e.cyc += dc; dc = 0; m = e.riot_read(ea); }',
-                        'else if ((ea & 0x0f) >= 8) { e.cyc += dc; dc = 0; m = e.tia_read(ea, 0x%02x); }' % b2,
-                        'else { --n; e.PC = 0x%04x; return; }' % a
-                    ]
+                    # only the address classes the 256-byte window base .. base+255 can reach
+                    span = [(base + i) & 0xffff for i in range(256)]
+                    can_rom = any(x & 0x1000 for x in span)
+                    can_ram = any(not (x & 0x1000) and (x & 0x280) == 0x80 for x in span)
+                    can_riot = any(not (x & 0x1000) and (x & 0x280) == 0x280 for x in span)
+                    arms = []
+                    if can_rom:
+                        arms.append('if (ea & 0x1000) m = e.rom_byte(ea);')
+                    if can_ram:
+                        arms.append('if ((ea & 0x%x) == 0x80) m = e.ram_rd(ea & 0x7f);' % (0x1280 if not can_rom else 0x280))
+                    if can_riot:
+                        arms.append('if ((ea & 0x%x) == 0x280) { e.cyc += dc; dc = 0; m = e.riot_read(ea); }' %
+                                    (0x1280 if not can_rom else 0x280))
+                    arms.append('if ((ea & 0x0f) >= 8) { e.cyc += dc; dc = 0; m = e.tia_read(ea, 0x%02x); }' % b2)
+                    pre += [arms[0]] + ['else ' + x for x in arms[1:]] + ['else { --n; e.PC = 0x%04x; return; }' % a]
             elif mode == M_IZY:
                 if b1 < 0x80 or b1 == 0xff:
                     return fb
