@@ -72,12 +72,13 @@ def pmc_traffic(key):
     shape (profiles/r01_scan_hbm_traffic.json, produced by tools/prof_traffic.sh: separate
     FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction).  bench.py cannot run under two
     rocprofv3 passes itself; the source file is named next to the number."""
-    path = os.path.join(ROOT, 'profiles', 'r01_scan_hbm_traffic.json')
-    try:
-        t = json.load(open(path))[key]
-        return {'traffic': t['hbm_traffic_bytes'], 'traffic_source': 'profiles/r01_scan_hbm_traffic.json:' + key}
-    except (OSError, KeyError, ValueError):
-        return {'traffic': None}
+    for name in ('r01e_scan_hbm_traffic.json', 'r01_scan_hbm_traffic.json'):
+        try:
+            t = json.load(open(os.path.join(ROOT, 'profiles', name)))[key]
+            return {'traffic': t['hbm_traffic_bytes'], 'traffic_source': 'profiles/%s:%s' % (name, key)}
+        except (OSError, KeyError, ValueError):
+            continue
+    return {'traffic': None}
 
 
 def cpu_baseline(game, dim, seconds_target=12.0):
@@ -242,13 +243,14 @@ def main():
         vt = vt_timer.mean_seconds()
         by = T * Eg * (2 * A * 4 + 8 + 4 + 1 + 4 + 8)  # 73 B/elt at A=6, fused from logits
         out['roofline'] = {
-            'kernel': 'vtrace_logits_tm_kernel (fused log-prob gather + V-trace, T=%d B=%d A=%d; %d launch(es) per '
+            'kernel': 'vtrace_logits_wave_kernel (fused log-prob gather + V-trace, wave per sequence, T=%d B=%d A=%d; %d launch(es) per '
                       'update, one per actor group)' % (T, Eg, A, G),
             'bound': 'hbm', 'achieved': by / vt / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-            'frac': by / vt / 1e9 / HBM_PEAK_GBPS, 'traffic': None, 'bytes_per_launch': by,
+            'frac': by / vt / 1e9 / HBM_PEAK_GBPS, 'bytes_per_launch': by,
             'note': 'workload shape is %.1f MB: launch-latency-bound by construction (SURVEY §8d); '
                     'see roofline_saturating for the HBM-bound shape' % (by / 1e6),
         }
+        out['roofline'].update(pmc_traffic('vtrace_logits_T%d_B%d_A%d' % (T, Eg, A)))
         # --- the same scan family at the saturating shape (T'=127, B=262,144: 932 MB) ---
         Ts, Bs = 127, 262144
         x = [torch.randn((Ts, Bs), device=dev) for _ in range(5)]

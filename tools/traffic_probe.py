@@ -39,7 +39,7 @@ a = [torch.randn((T, B), device=dev) for _ in range(5)]
 boot = torch.randn(B, device=dev)
 flush_cache()
 ops.vtrace(a[0], a[1], a[2], a[3], a[4], boot)
-out['vtrace_T127_B262144'] = {'kernel': 'vtrace_tm_kernel<1, 8>', 'read': T * B * 20 + 4 * B, 'write': T * B * 8}
+out['vtrace_T127_B262144'] = {'kernel': 'vtrace_tm_kernel<1, 8', 'read': T * B * 20 + 4 * B, 'write': T * B * 8}
 del a
 # --- and at B = 1,048,576 (16 B/lane kernel)
 T, B = 127, 1 << 20
@@ -47,7 +47,7 @@ a = [torch.randn((T, B), device=dev) for _ in range(5)]
 boot = torch.randn(B, device=dev)
 flush_cache()
 ops.vtrace(a[0], a[1], a[2], a[3], a[4], boot)
-out['vtrace_T127_B1048576'] = {'kernel': 'vtrace_tm_kernel<4, 4>', 'read': T * B * 20 + 4 * B, 'write': T * B * 8}
+out['vtrace_T127_B1048576'] = {'kernel': 'vtrace_tm_kernel<4, 4', 'read': T * B * 20 + 4 * B, 'write': T * B * 8}
 del a
 # --- GAE, PPO storage shape (chunk-parallel plan: inputs read twice)
 T, B = 2048, 4096
@@ -56,5 +56,14 @@ d = (torch.rand((T, B), device=dev) < 0.001).float()
 flush_cache()
 ops.gae(rew, val, d, torch.randn(B, device=dev), 0.99, 0.95, last_done=torch.zeros(B, device=dev), done_convention=1)
 out['gae_T2048_B4096_f32'] = {'kernel': 'gae_chunk_kernel', 'read': T * B * 12, 'write': T * B * 8}
+# --- fused V-trace from logits at the BENCH WORKLOAD shape (BASELINE configs[2]: T=50, B=1024, A=6)
+T, B, A = 50, 1024, 6
+bl, tl = torch.randn((T, B, A), device=dev), torch.randn((T, B, A), device=dev)
+act = torch.randint(0, A, (T, B), device=dev)
+rw, dn, vl = torch.randn((T, B), device=dev), torch.rand((T, B), device=dev) < 0.01, torch.randn((T, B), device=dev)
+flush_cache()
+ops.vtrace_from_logits(bl, tl, act, rw, dn, vl, 0.99)
+out['vtrace_logits_T50_B1024_A6'] = {'kernel': 'vtrace_logits_', 'read': T * B * (2 * A * 4 + 8 + 4 + 1 + 4),
+                                     'write': (T - 1) * B * 8}
 torch.cuda.synchronize()
 print(json.dumps(out))
