@@ -114,9 +114,11 @@ int parlhip_gae_f32(const float* rewards, const float* values, const void* dones
                     parlhip_stream_t stream);
 
 /* Same arithmetic with a caller workspace, for long rollouts over few sequences (PPO: T=2048,
- * E=4096, examples/PPO/storage.py:45-64): T is cut into chunks that run in parallel (affine
- * recurrence: chunk aggregates, serial combine over chunks, final pass seeded with the exact-order
- * recurrence inside each chunk).  parlhip_gae_workspace_bytes() returns 0 when the single-pass
+ * E=4096, examples/PPO/storage.py:45-64): T is cut into 32-step chunks that run in parallel in ONE
+ * pass over HBM (affine recurrence: every chunk keeps its steps in registers, publishes its
+ * aggregate, folds the aggregates of the later chunks and finishes with the exact-order recurrence
+ * inside the chunk).  The workspace (8 B per chunk and sequence, 16-byte aligned) is overwritten.
+ * parlhip_gae_workspace_bytes() returns 0 when the single-pass
  * kernel is the better plan for (T, B); parlhip_gae_ws_f32 then forwards to parlhip_gae_f32 and
  * workspace may be NULL.  Results agree with parlhip_gae_f32 to fp32 re-association (<=1e-6 rel). */
 size_t parlhip_gae_workspace_bytes(int T, int B);

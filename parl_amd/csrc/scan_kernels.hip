@@ -487,102 +487,122 @@ __global__ __launch_bounds__(256) void gae_tm_kernel(
 // GAE for long T / small B (PPO config: T=2048, B=4096 -> only 64 lane-per-sequence waves, each
 // a chain of 2048 dependent steps: latency-bound at ~0.8 TB/s).  The recurrence
 //   adv_t = d_t + a_t * adv_{t+1}
-// is affine, so T is cut into C chunks that run in parallel (grid.y = chunk):
-//   pass 0 (MODE_AGG)   per (chunk, b): A = prod a_t, D = chunk-local suffix value at its first step
-//   combine             per b, serial over C chunks: carry_in[c] = adv at the first step of chunk c+1
-//   pass 1 (MODE_FINAL) the ordinary sequential recurrence inside the chunk, seeded with carry_in
-// Traffic: inputs are read twice (12 B/elt; the second read of a <=256 MB working set is served
-// by the Infinity Cache), outputs written once.  Results differ from the single-pass kernel only by
-// fp32 re-association of the carry (<= 1e-6 relative), within the 1e-5 contract.
+// is affine, so T is cut into C chunks of kGaeChunk steps that run in parallel — in ONE pass over
+// HBM: a workgroup (256 sequences x one chunk) loads its chunk once into registers (d_t, a_t, V_t),
+// publishes the chunk's aggregate (A = prod a_t, D = chunk-local suffix value at its first step),
+// folds the aggregates of all LATER chunks (x = D_k + A_k * x, k = C-1 .. c+1: the value of adv at
+// the first step of chunk c+1) and finishes from registers.  20 B / element (f32 dones) instead of
+// the 32 B of an aggregate pass + a final pass; the folded aggregates (8 B per sequence and chunk)
+// come from L2.  Results differ from the single-pass kernel only by fp32 re-association of the
+// carry (<= 1e-6 relative), within the 1e-5 contract.
+// Forward progress: workgroups are numbered so that a chunk only ever waits for LOWER workgroup
+// ids (later chunks are launched first), the usual decoupled look-back argument: the lowest
+// unfinished id never waits for an unscheduled workgroup.
 // ----------------------------------------------------------------------------------------
-enum : int { MODE_AGG = 0, MODE_FINAL = 1 };
+constexpr int kGaeChunk = 32;
 
-template <bool DONE_F32, int CONV, int MODE>
-__global__ __launch_bounds__(256) void gae_chunk_kernel(
+template <bool DONE_F32, int CONV>
+__global__ __launch_bounds__(256) void gae_lookback_kernel(
     const float* __restrict__ rew, const float* __restrict__ val,
     const void* __restrict__ dones_v, const float* __restrict__ next_value,
     const void* __restrict__ last_done_v, float* __restrict__ adv, float* __restrict__ ret,
-    int T, int B, float gamma, float gl, int L, float* __restrict__ wsA,
-    float* __restrict__ wsD, const float* __restrict__ carry_in) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const int c = blockIdx.y;
+    int T, int B, float gamma, float gl, int C, int cols, unsigned long long* __restrict__ ws) {
+  constexpr int L = kGaeChunk;
+  const int col = blockIdx.x % cols;
+  const int c = C - 1 - (int)(blockIdx.x / cols);   // id 0 .. cols-1 = the last chunk in time
+  const int64_t b = (int64_t)col * blockDim.x + threadIdx.x;
+  const bool live = b < B;
   const int t0 = c * L;
   const int t1 = (t0 + L < T) ? t0 + L : T;
-  if (t0 >= T) return;
   const float* dones_f = (const float*)dones_v;
   const uint8_t* dones_u = (const uint8_t*)dones_v;
   auto done_at = [&](int64_t i) -> float { return DONE_F32 ? dones_f[i] : (float)dones_u[i]; };
-  float v_next, nnt_next = 1.f;
-  if (t1 == T) {
-    v_next = next_value[b];
-    if (CONV == PARLHIP_GAE_DONE_STARTS_STEP)
-      nnt_next = 1.0f - (DONE_F32 ? ((const float*)last_done_v)[b] : (float)((const uint8_t*)last_done_v)[b]);
-  } else {
-    v_next = val[(int64_t)t1 * B + b];
-    if (CONV == PARLHIP_GAE_DONE_STARTS_STEP) nnt_next = 1.0f - done_at((int64_t)t1 * B + b);
-  }
-  float carry = (MODE == MODE_FINAL) ? carry_in[(int64_t)c * B + b] : 0.f;
-  float Aprod = 1.f;
-  constexpr int U = 8;
-  for (int t = t1 - 1; t >= t0; t -= U) {
-    float lr[U], lv[U], ld[U];
+  float dd[L], aa[L], vv[L];
+  float carry = 0.f, Aprod = 1.f;
+  if (live) {
+    float v_next, nnt_next = 1.f;
+    if (t1 == T) {
+      v_next = next_value[b];
+      if (CONV == PARLHIP_GAE_DONE_STARTS_STEP)
+        nnt_next = 1.0f - (DONE_F32 ? ((const float*)last_done_v)[b] : (float)((const uint8_t*)last_done_v)[b]);
+    } else {
+      v_next = val[(int64_t)t1 * B + b];
+      if (CONV == PARLHIP_GAE_DONE_STARTS_STEP) nnt_next = 1.0f - done_at((int64_t)t1 * B + b);
+    }
+    float lr[L], ld[L];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (t - u < t0) continue;
-      const int64_t i = (int64_t)(t - u) * B + b;
+    for (int u = 0; u < L; ++u) {  // all loads of the chunk in flight before the dependent chain
+      const int t = t1 - 1 - u;
+      const int64_t i = (int64_t)(t < t0 ? t0 : t) * B + b;
       lr[u] = rew[i];
-      lv[u] = val[i];
+      vv[u] = val[i];
       ld[u] = done_at(i);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (t - u < t0) continue;
-      const int64_t i = (int64_t)(t - u) * B + b;
-      const float r = lr[u], v = lv[u];
-      float a, d;
-      if (CONV == PARLHIP_GAE_DONE_ENDS_STEP) {
-        const bool done = ld[u] != 0.f;
-        const float nv = done ? 0.f : v_next;
-        d = r + gamma * nv - v;
-        a = done ? 0.f : gl;
-      } else {
-        const float nnt = nnt_next;
-        d = r + gamma * v_next * nnt - v;
-        a = gl * nnt;
-        nnt_next = 1.0f - ld[u];
-      }
-      if (MODE == MODE_FINAL) {
-        // same expression shapes as gae_tm_kernel: done ? td : td + gl*carry  /  delta + gl*nnt*carry
-        if (CONV == PARLHIP_GAE_DONE_ENDS_STEP) carry = (a == 0.f) ? d : d + gl * carry;
-        else carry = d + a * carry;
-        if (adv) adv[i] = carry;
-        if (ret) ret[i] = carry + v;
-      } else {
+    for (int u = 0; u < L; ++u) {
+      const int t = t1 - 1 - u;
+      float a = 1.f, d = 0.f;  // identity for steps before t0 (ragged last chunk in launch order)
+      if (t >= t0) {
+        const float r = lr[u], v = vv[u];
+        if (CONV == PARLHIP_GAE_DONE_ENDS_STEP) {
+          const bool done = ld[u] != 0.f;
+          const float nv = done ? 0.f : v_next;
+          d = r + gamma * nv - v;
+          a = done ? 0.f : gl;
+        } else {
+          const float nnt = nnt_next;
+          d = r + gamma * v_next * nnt - v;
+          a = gl * nnt;
+          nnt_next = 1.0f - ld[u];
+        }
         carry = d + a * carry;
         Aprod = a * Aprod;
+        v_next = v;
       }
-      v_next = v;
+      dd[u] = d;
+      aa[u] = a;
     }
+    // publish (A, D) as ONE 64-bit agent-scope atomic store: the workspace is pre-filled with the
+    // all-ones pattern, so "A half != 0xffffffff" doubles as the ready flag — no separate flag, no
+    // device-scope fence (on the 8-XCD part a release fence writes back the whole L2 of the XCD:
+    // measured 290 us for this kernel with flags + __threadfence()).
+    const unsigned long long packed = (unsigned long long)__float_as_uint(Aprod) |
+                                      ((unsigned long long)__float_as_uint(carry) << 32);
+    __hip_atomic_store(ws + (int64_t)c * B + b, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (MODE == MODE_AGG) {
-    wsA[(int64_t)c * B + b] = Aprod;
-    wsD[(int64_t)c * B + b] = carry;
-  }
-}
-
-// carry_in[c] = adv at the first step of chunk c+1 (0 for the last chunk), serial over chunks
-__global__ __launch_bounds__(256) void gae_chunk_combine_kernel(const float* __restrict__ wsA,
-                                                                const float* __restrict__ wsD,
-                                                                float* __restrict__ carry_in, int C,
-                                                                int B) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  if (!live) return;
+  // fold the aggregates of the later chunks (x = adv at the first step of chunk c+1): batches of
+  // independent 64-bit atomic loads; a batch with an unpublished entry is simply read again
   float x = 0.f;
-  for (int c = C - 1; c >= 0; --c) {
-    const int64_t i = (int64_t)c * B + b;
-    carry_in[i] = x;
-    x = wsD[i] + wsA[i] * x;
+  constexpr int KB = 8;
+  for (int k = C - 1; k > c; k -= KB) {
+    unsigned long long w[KB];
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < KB; ++j) {
+        const int kk = (k - j > c) ? k - j : c + 1;   // clamped duplicates are skipped below
+        w[j] = __hip_atomic_load(ws + (int64_t)kk * B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok &= (unsigned)(w[j] & 0xffffffffull) != 0xffffffffu;
+      }
+      if (__ballot(!ok) == 0ull) break;   // wave-uniform retry keeps the wave converged
+      __builtin_amdgcn_s_sleep(8);
+    }
+#pragma unroll
+    for (int j = 0; j < KB; ++j)
+      if (k - j > c) x = __uint_as_float((unsigned)(w[j] >> 32)) + __uint_as_float((unsigned)(w[j] & 0xffffffffull)) * x;
+  }
+  carry = x;
+#pragma unroll
+  for (int u = 0; u < L; ++u) {
+    const int t = t1 - 1 - u;
+    if (t < t0) continue;
+    const int64_t i = (int64_t)t * B + b;
+    // same expression shapes as gae_tm_kernel: done ? td : td + gl*carry  /  delta + gl*nnt*carry
+    if (CONV == PARLHIP_GAE_DONE_ENDS_STEP) carry = (aa[u] == 0.f) ? dd[u] : dd[u] + gl * carry;
+    else carry = dd[u] + aa[u] * carry;
+    if (adv) adv[i] = carry;
+    if (ret) ret[i] = carry + vv[u];
   }
 }
 
@@ -837,42 +857,31 @@ PARLHIP_EXPORT int parlhip_gae_f32(const float* rew, const float* val, const voi
 }
 
 // Chunk plan for the long-T / small-B path: 0 chunks = stay on the single-pass kernel.
-static inline void gae_chunk_plan(int T, int B, int* C_out, int* L_out) {
-  *C_out = 0; *L_out = 0;
+static inline void gae_chunk_plan(int T, int B, int* C_out, int* cols_out) {
+  *C_out = 0; *cols_out = 0;
   const int waves = ceil_div(B, 64);
-  if (T < 256 || waves >= 1024) return;
-  int C = ceil_div(2048, waves);           // aim for >= 2048 waves (8 per CU) in flight
-  const int maxC = T / 32;                 // chunks of at least 32 steps
-  if (C > maxC) C = maxC;
-  if (C < 2) return;
-  int L = ceil_div(T, C);
-  L = (L + 7) & ~7;
-  *C_out = ceil_div(T, L);
-  *L_out = L;
+  if (T < 256 || waves >= 1024) return;   // enough lane-per-sequence waves to fill the chip already
+  *C_out = ceil_div(T, kGaeChunk);
+  *cols_out = ceil_div(B, 256);
 }
 
 PARLHIP_EXPORT size_t parlhip_gae_workspace_bytes(int T, int B) {
-  int C, L;
+  int C, cols;
   if (T <= 0 || B <= 0) return 0;
-  gae_chunk_plan(T, B, &C, &L);
-  return (size_t)3 * (size_t)C * (size_t)B * sizeof(float);
+  gae_chunk_plan(T, B, &C, &cols);
+  return (size_t)C * (size_t)B * sizeof(unsigned long long);   // one (A, D) pair per chunk and sequence
 }
 
 template <bool DONE_F32, int CONV>
 static int launch_gae_chunked(const float* rew, const float* val, const void* dones,
                               const float* next_value, const void* last_done, float* adv, float* ret,
-                              int T, int B, float gamma, float gl, int C, int L, float* ws,
+                              int T, int B, float gamma, float gl, int C, int cols, float* ws,
                               hipStream_t s) {
-  float* wsA = ws;
-  float* wsD = ws + (size_t)C * B;
-  float* carry = ws + (size_t)2 * C * B;
-  const int block = B >= 256 ? 256 : 64;
-  dim3 grid(ceil_div(B, block), C);
-  gae_chunk_kernel<DONE_F32, CONV, MODE_AGG><<<grid, block, 0, s>>>(
-      rew, val, dones, next_value, last_done, nullptr, nullptr, T, B, gamma, gl, L, wsA, wsD, nullptr);
-  gae_chunk_combine_kernel<<<ceil_div(B, block), block, 0, s>>>(wsA, wsD, carry, C, B);
-  gae_chunk_kernel<DONE_F32, CONV, MODE_FINAL><<<grid, block, 0, s>>>(
-      rew, val, dones, next_value, last_done, adv, ret, T, B, gamma, gl, L, nullptr, nullptr, carry);
+  // all-ones = "not published yet" (see gae_lookback_kernel)
+  int rc = check(hipMemsetAsync(ws, 0xff, (size_t)C * B * sizeof(unsigned long long), s));
+  if (rc) return rc;
+  gae_lookback_kernel<DONE_F32, CONV><<<C * cols, 256, 0, s>>>(rew, val, dones, next_value, last_done, adv, ret, T,
+                                                               B, gamma, gl, C, cols, (unsigned long long*)ws);
   return check_launch();
 }
 
@@ -887,7 +896,7 @@ PARLHIP_EXPORT int parlhip_gae_ws_f32(const float* rew, const float* val, const 
     return parlhip_gae_f32(rew, val, dones, next_value, last_done, adv, ret, T, B, gamma, lam,
                            done_convention, dones_are_f32, stream);
   if (!rew || !val || !dones || !next_value || (!adv && !ret)) return PARLHIP_EINVAL;
-  if (!workspace || workspace_bytes < (size_t)3 * C * B * sizeof(float)) return PARLHIP_ENOMEM;
+  if (!workspace || workspace_bytes < parlhip_gae_workspace_bytes(T, B)) return PARLHIP_ENOMEM;
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)workspace;
   if (done_convention == PARLHIP_GAE_DONE_ENDS_STEP) {

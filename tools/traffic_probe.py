@@ -49,13 +49,13 @@ flush_cache()
 ops.vtrace(a[0], a[1], a[2], a[3], a[4], boot)
 out['vtrace_T127_B1048576'] = {'kernel': 'vtrace_tm_kernel<4, 4', 'read': T * B * 20 + 4 * B, 'write': T * B * 8}
 del a
-# --- GAE, PPO storage shape (chunk-parallel plan: inputs read twice)
+# --- GAE, PPO storage shape (single-pass look-back plan)
 T, B = 2048, 4096
 rew, val = torch.randn((T, B), device=dev), torch.randn((T, B), device=dev)
 d = (torch.rand((T, B), device=dev) < 0.001).float()
 flush_cache()
 ops.gae(rew, val, d, torch.randn(B, device=dev), 0.99, 0.95, last_done=torch.zeros(B, device=dev), done_convention=1)
-out['gae_T2048_B4096_f32'] = {'kernel': 'gae_chunk_kernel', 'read': T * B * 12, 'write': T * B * 8}
+out['gae_T2048_B4096_f32'] = {'kernel': 'gae_lookback_kernel', 'read': T * B * 12, 'write': T * B * 8}
 # --- fused V-trace from logits at the BENCH WORKLOAD shape (BASELINE configs[2]: T=50, B=1024, A=6)
 T, B, A = 50, 1024, 6
 bl, tl = torch.randn((T, B, A), device=dev), torch.randn((T, B, A), device=dev)
