@@ -88,6 +88,24 @@ int parlhip_vtrace_from_logits_f32(const float* behaviour_logits,
                                    float clip_pg_rho_threshold,
                                    parlhip_stream_t stream);
 
+/* IMPALA learner loss in one pass (impala.py:25-79 VTraceLoss + impala.py:119-194 of IMPALA.learn):
+ * everything parlhip_vtrace_from_logits_f32 does, plus the Categorical entropy / KL of the two
+ * policies, the three loss sums and the gradient of
+ *     total = pi_loss + vf_coeff * vf_loss + ent_coeff * entropy          (impala.py:78-79)
+ * with respect to target_logits and values (the V-trace targets carry no gradient, vtrace.py:36).
+ * Inputs as parlhip_vtrace_from_logits_f32.  Outputs: vs, pg_advantages [T-1,B] / [B,T-1];
+ * grad_logits f32 in the layout of target_logits, grad_values f32 in the layout of values (rows of
+ * the bootstrap step are zero); sums f64[4], ADDED to (zero them first): pi_loss, vf_loss,
+ * entropy, and the sum over all T*B rows of KL(target || behaviour) (impala.py:161-165 takes
+ * its mean).  Returns PARLHIP_ENOSUP for T > 256 or an action count without a compiled
+ * instantiation (2, 3, 4, 6, 9, 18): callers then use the unfused entry.                          */
+int parlhip_impala_loss_f32(const float* behaviour_logits, const float* target_logits,
+                            const int64_t* actions, const float* rewards, const uint8_t* dones,
+                            const float* values, float* vs, float* pg_advantages, float* grad_logits,
+                            float* grad_values, double* sums, int T, int B, int A, int time_major,
+                            float gamma, float clip_rho_threshold, float clip_pg_rho_threshold,
+                            float vf_coeff, float entropy_coeff, parlhip_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * GAE / n-step returns / discounted sums
  * ------------------------------------------------------------------------------------ */

@@ -65,6 +65,38 @@ class _FusedVTraceLoss(object):
         _finish_loss(self, target_actions_log_probs, values, policy_entropy, entropy_coeff, vf_loss_coeff)
 
 
+class _FusedLossFn(torch.autograd.Function):
+    """total_loss of VTraceLoss computed, together with its gradient w.r.t. (target_logits, values),
+    by ONE kernel (ops.impala_loss); backward is two multiplies by the incoming scalar gradient."""
+
+    @staticmethod
+    def forward(ctx, target_logits, values, behaviour_logits, actions, rewards, dones, cfg):
+        gamma, crho, cpg, vf_c, ent_c, time_major = cfg
+        out = ops.impala_loss(behaviour_logits, target_logits, actions, rewards, dones, values, gamma, crho, cpg,
+                              vf_c, ent_c, time_major=time_major)
+        if out is None:
+            raise NotImplementedError
+        vs, pg, glog, gval, sums = out
+        ctx.save_for_backward(glog, gval)
+        total = (sums[0] + vf_c * sums[1] + ent_c * sums[2]).float()
+        ctx.mark_non_differentiable(sums, vs, pg)
+        return total, sums, vs, pg
+
+    @staticmethod
+    def backward(ctx, g_total, g_sums, g_vs, g_pg):
+        glog, gval = ctx.saved_tensors
+        return g_total * glog, g_total * gval, None, None, None, None, None
+
+
+class _KernelVTraceLoss(object):
+    """VTraceLoss whose terms and gradient came from the fused loss kernel"""
+
+    def __init__(self, total, sums, vs, pg):
+        self.vtrace_returns = vtrace.VTraceReturns(vs=vs, pg_advantages=pg)
+        self.total_loss = total
+        self.pi_loss, self.vf_loss, self.entropy = sums[0].float(), sums[1].float(), sums[2].float()
+
+
 class IMPALA(Algorithm):
     def __init__(self,
                  model,
@@ -89,6 +121,9 @@ class IMPALA(Algorithm):
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=0.001)
         self.grad_clip_norm = 40.0
         self.grad_hook = None  # set by parl_amd.dist for data-parallel learners
+        # one-kernel loss + gradient (ops.impala_loss); False keeps the autograd graph of the
+        # reference formulas on top of the fused V-trace (the parity tests compare the two)
+        self.fused_loss = True
 
     def _heads(self, obs):
         if hasattr(self.model, 'policy_and_value'):
@@ -102,6 +137,15 @@ class IMPALA(Algorithm):
         B = N // T
         target_logits, values = self._heads(obs)
         A = target_logits.shape[-1]
+        if self.fused_loss and T <= 256 and A in (2, 3, 4, 6, 9, 18):
+            # log-softmax gather, entropy, KL, V-trace, the three sums AND their gradient: one kernel
+            shp = (T, B) if time_major else (B, T)
+            total, sums, vs, pg_adv = _FusedLossFn.apply(
+                target_logits.reshape(shp + (A, )), values.reshape(shp), behaviour_logits.reshape(shp + (A, )),
+                actions.reshape(shp), rewards.reshape(shp), dones.reshape(shp),
+                (self.gamma, self.clip_rho_threshold, self.clip_pg_rho_threshold, self.vf_loss_coeff,
+                 float(entropy_coeff), time_major))
+            return _KernelVTraceLoss(total, sums, vs, pg_adv), (sums[3] / N).float()
         logp_all = F.log_softmax(target_logits, dim=-1)
         p_all = logp_all.exp()
         policy_entropy = -(p_all * logp_all).sum(-1)  # Categorical.entropy (impala.py:156)

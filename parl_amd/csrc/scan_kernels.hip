@@ -351,6 +351,130 @@ __global__ __launch_bounds__(256) void vtrace_logits_wave_kernel(
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// IMPALA learner loss in one pass: the fused V-trace above plus everything
+// IMPALA.learn computes around it — log-softmax of both policies, the action log-prob gather,
+// Categorical entropy and KL (impala.py:119-165), pi / vf / entropy sums (impala.py:67-79) — and
+// the gradient of   total = pi_loss + vf_coeff * vf_loss + ent_coeff * entropy   with respect to
+// the target logits and the values (vs / pg_advantages carry no gradient: vtrace.py:36):
+//   d total / d logit_j = -pg_adv * (1[j == a] - p_j) + ent_coeff * (-p_j * (log p_j + H))
+//   d total / d V       = vf_coeff * (V - vs)
+// for the T-1 transitions, zero for the bootstrap row.  ~20 eager launches of the autograd graph
+// become this kernel plus two multiplies in backward.  sums (float64, caller-zeroed):
+// [0] pi_loss [1] vf_loss [2] entropy [3] sum over ALL T rows of KL(target || behaviour).
+// ----------------------------------------------------------------------------------------
+template <int A_CT>
+__device__ __forceinline__ void log_softmax_row(const float* __restrict__ row, float (&lp)[A_CT]) {
+  float x[A_CT];
+#pragma unroll
+  for (int j = 0; j < A_CT; ++j) x[j] = row[j];
+  float m = x[0];
+#pragma unroll
+  for (int j = 1; j < A_CT; ++j) m = fmaxf(m, x[j]);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < A_CT; ++j) sum += expf(x[j] - m);
+  const float lse = logf(sum);
+#pragma unroll
+  for (int j = 0; j < A_CT; ++j) lp[j] = (x[j] - m) - lse;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int A_CT, int K, bool TM>
+__global__ __launch_bounds__(256) void impala_loss_wave_kernel(
+    const float* __restrict__ blog, const float* __restrict__ tlog,
+    const int64_t* __restrict__ actions, const float* __restrict__ rew,
+    const uint8_t* __restrict__ dones, const float* __restrict__ val,
+    float* __restrict__ vs, float* __restrict__ pg, float* __restrict__ glog,
+    float* __restrict__ gval, double* __restrict__ sums, int T, int B, float gamma,
+    float clip_rho, float clip_pg, float vf_coeff, float ent_coeff, int* __restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  const int blk = TM ? xcd_chunk_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int64_t b = ((int64_t)blk * blockDim.x + threadIdx.x) >> 6;
+  if (b >= B) return;  // whole wave exits together
+  const int Tm = T - 1;
+  const int64_t in_t = TM ? B : 1, in_b = TM ? 1 : T, out_b = TM ? 1 : Tm;
+  const float bootstrap = val[(int64_t)Tm * in_t + b * in_b];
+
+  float rho[K], dsc[K], v[K], r[K], vst[K], pgv[K], tlp[K], H[K];
+  float p[K][A_CT], lp[K][A_CT];
+  int act[K];
+  bool valid[K];
+  float kl = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int t = lane * K + k;
+    valid[k] = t < Tm;
+    rho[k] = 1.f; dsc[k] = 0.f; v[k] = 0.f; r[k] = 0.f; tlp[k] = 0.f; H[k] = 0.f; act[k] = 0;
+#pragma unroll
+    for (int j = 0; j < A_CT; ++j) { p[k][j] = 0.f; lp[k][j] = 0.f; }
+    if (t < T) {
+      const int64_t i = (int64_t)t * in_t + b * in_b;
+      float blp[A_CT];
+      log_softmax_row<A_CT>(tlog + i * A_CT, lp[k]);
+      log_softmax_row<A_CT>(blog + i * A_CT, blp);
+      float h = 0.f;
+#pragma unroll
+      for (int j = 0; j < A_CT; ++j) {
+        p[k][j] = expf(lp[k][j]);
+        h -= p[k][j] * lp[k][j];
+        kl += p[k][j] * (lp[k][j] - blp[j]);
+      }
+      H[k] = h;
+      if (valid[k]) {
+        int a = (int)actions[i];
+        if (a < 0 || a >= A_CT) { *err = 1; a = 0; }
+        act[k] = a;
+        float ta = lp[k][0], ba = blp[0];
+#pragma unroll
+        for (int j = 1; j < A_CT; ++j) { ta = (j == a) ? lp[k][j] : ta; ba = (j == a) ? blp[j] : ba; }
+        tlp[k] = ta;
+        dsc[k] = dones[i] ? 0.f : gamma;
+        rho[k] = expf(ta - ba);
+        v[k] = val[i];
+        r[k] = rew[i];
+      }
+    }
+  }
+  vtrace_wave_core<K>(rho, dsc, v, r, valid, lane, Tm, bootstrap, clip_rho, clip_pg, vst, pgv);
+  float pi = 0.f, vf = 0.f, ent = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int t = lane * K + k;
+    if (t >= T) continue;
+    const int64_t i = (int64_t)t * in_t + b * in_b;
+    if (valid[k]) {
+      const int64_t o = (int64_t)t * in_t + b * out_b;
+      pg[o] = pgv[k];
+      vs[o] = vst[k];
+      const float dv = v[k] - vst[k];
+#pragma unroll
+      for (int j = 0; j < A_CT; ++j)
+        glog[i * A_CT + j] = -pgv[k] * ((j == act[k] ? 1.f : 0.f) - p[k][j]) - ent_coeff * (p[k][j] * (lp[k][j] + H[k]));
+      gval[i] = vf_coeff * dv;
+      pi -= tlp[k] * pgv[k];
+      vf += 0.5f * dv * dv;
+      ent += H[k];
+    } else {  // the bootstrap row: no transition, no gradient
+#pragma unroll
+      for (int j = 0; j < A_CT; ++j) glog[i * A_CT + j] = 0.f;
+      gval[i] = 0.f;
+    }
+  }
+  pi = wave_sum(pi); vf = wave_sum(vf); ent = wave_sum(ent); kl = wave_sum(kl);
+  if (lane == 0) {
+    atomicAdd(sums + 0, (double)pi);
+    atomicAdd(sums + 1, (double)vf);
+    atomicAdd(sums + 2, (double)ent);
+    atomicAdd(sums + 3, (double)kl);
+  }
+}
+
 // V-trace from log-probs (the reference function boundary), time-major, wave-per-sequence:
 // the small-B path of parlhip_vtrace_f32 (reference shape T'=49, B=1024 is 1.4 MB).
 template <int K>
@@ -932,4 +1056,56 @@ PARLHIP_EXPORT int parlhip_discount_cumsum_f32(const float* x, const uint8_t* do
     discount_cumsum_kernel<1, 8><<<ceil_div(B, block), block, 0, s>>>(x, dones, out, T, B, gamma);
   }
   return check_launch();
+}
+
+template <int A_CT>
+static int launch_impala_loss(const float* blog, const float* tlog, const int64_t* actions, const float* rew,
+                              const uint8_t* dones, const float* val, float* vs, float* pg, float* glog,
+                              float* gval, double* sums, int T, int B, int time_major, float gamma,
+                              float clip_rho, float clip_pg, float vf_coeff, float ent_coeff, hipStream_t s,
+                              int* err) {
+  const int K = ceil_div(T, 64);   // T rows (the bootstrap row takes part in the KL sum)
+  const int grid = ceil_div((int64_t)B * 64, 256);
+#define LAUNCH_LOSS(KK)                                                                                  \
+  do {                                                                                                   \
+    if (time_major)                                                                                      \
+      impala_loss_wave_kernel<A_CT, KK, true><<<grid, 256, 0, s>>>(blog, tlog, actions, rew, dones, val, \
+          vs, pg, glog, gval, sums, T, B, gamma, clip_rho, clip_pg, vf_coeff, ent_coeff, err);           \
+    else                                                                                                 \
+      impala_loss_wave_kernel<A_CT, KK, false><<<grid, 256, 0, s>>>(blog, tlog, actions, rew, dones, val,\
+          vs, pg, glog, gval, sums, T, B, gamma, clip_rho, clip_pg, vf_coeff, ent_coeff, err);           \
+  } while (0)
+  if (K <= 1) LAUNCH_LOSS(1);
+  else if (K <= 2) LAUNCH_LOSS(2);
+  else if (K <= 4) LAUNCH_LOSS(4);
+  else return PARLHIP_ENOSUP;   // T > 256: use parlhip_vtrace_from_logits_f32 + the framework's loss
+#undef LAUNCH_LOSS
+  return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_impala_loss_f32(const float* blog, const float* tlog, const int64_t* actions,
+                                           const float* rew, const uint8_t* dones, const float* val, float* vs,
+                                           float* pg, float* grad_logits, float* grad_values, double* sums, int T,
+                                           int B, int A, int time_major, float gamma, float clip_rho,
+                                           float clip_pg, float vf_coeff, float ent_coeff,
+                                           parlhip_stream_t stream) {
+  if (T < 2 || B < 0 || A < 1) return PARLHIP_EINVAL;
+  if (B == 0) return PARLHIP_OK;
+  if (!blog || !tlog || !actions || !rew || !dones || !val || !vs || !pg || !grad_logits || !grad_values || !sums)
+    return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int* err = action_err_ptr();
+  if (!err) return PARLHIP_ELAUNCH;
+#define LARGS blog, tlog, actions, rew, dones, val, vs, pg, grad_logits, grad_values, sums, T, B, time_major, \
+              gamma, clip_rho, clip_pg, vf_coeff, ent_coeff, s, err
+  switch (A) {
+    case 2: return launch_impala_loss<2>(LARGS);
+    case 3: return launch_impala_loss<3>(LARGS);
+    case 4: return launch_impala_loss<4>(LARGS);
+    case 6: return launch_impala_loss<6>(LARGS);
+    case 9: return launch_impala_loss<9>(LARGS);
+    case 18: return launch_impala_loss<18>(LARGS);
+    default: return PARLHIP_ENOSUP;   // other action counts: the unfused path
+  }
+#undef LARGS
 }

@@ -88,6 +88,48 @@ def vtrace_from_logits(behaviour_logits, target_logits, actions, rewards, dones,
     return vs, pg
 
 
+ENOSUP = -3  # PARLHIP_ENOSUP (include/parl_hip.h)
+
+
+def impala_loss(behaviour_logits, target_logits, actions, rewards, dones, values, gamma, clip_rho_threshold=1.0,
+                clip_pg_rho_threshold=1.0, vf_coeff=0.5, entropy_coeff=-0.01, time_major=True):
+    """VTraceLoss + the pre-processing of IMPALA.learn (impala.py:25-79,119-194) in one launch,
+    including the gradient of total_loss w.r.t. target_logits and values.  Shapes as
+    vtrace_from_logits.  Returns (vs, pg_advantages, grad_logits, grad_values, sums) with sums =
+    f64[4] device tensor (pi_loss, vf_loss, entropy, KL summed over all rows), or None when the
+    library has no instantiation for this (T, A) (callers use the unfused path)."""
+    bl, tl = _f32(behaviour_logits, 'behaviour_logits'), _f32(target_logits, 'target_logits')
+    if time_major:
+        T, B, A = tl.shape
+        oshape = (T - 1, B)
+    else:
+        B, T, A = tl.shape
+        oshape = (B, T - 1)
+    if actions.dtype != torch.int64:
+        raise N.ParlHipError('actions must be int64')
+    actions = actions.contiguous()
+    rew, val = _f32(rewards, 'rewards'), _f32(values, 'values')
+    if dones.dtype == torch.bool:
+        dones = dones.contiguous().view(torch.uint8)
+    elif dones.dtype != torch.uint8:
+        raise N.ParlHipError('dones must be bool or uint8')
+    dones = dones.contiguous()
+    dev = val.device
+    vs = torch.empty(oshape, dtype=torch.float32, device=dev)
+    pg = torch.empty(oshape, dtype=torch.float32, device=dev)
+    glog = torch.empty_like(tl)
+    gval = torch.empty_like(val)
+    sums = torch.zeros(4, dtype=torch.float64, device=dev)
+    code = N.lib().parlhip_impala_loss_f32(
+        N.ptr(bl), N.ptr(tl), N.ptr(actions), N.ptr(rew), N.ptr(dones), N.ptr(val), N.ptr(vs), N.ptr(pg), N.ptr(glog),
+        N.ptr(gval), N.ptr(sums), T, B, A, 1 if time_major else 0, float(gamma), _thr(clip_rho_threshold),
+        _thr(clip_pg_rho_threshold), float(vf_coeff), float(entropy_coeff), N.stream_ptr())
+    if code == ENOSUP:
+        return None
+    N.check(code, 'parlhip_impala_loss_f32')
+    return vs, pg, glog, gval, sums
+
+
 GAE_DONE_ENDS_STEP = 0
 GAE_DONE_STARTS_STEP = 1
 

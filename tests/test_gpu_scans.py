@@ -271,3 +271,86 @@ def test_policy_sample(dev, oracle, A):
     a = ops.policy_sample(T_(row, dev), 5, 0, 0).cpu().numpy()
     freq = np.bincount(a, minlength=A) / len(a)
     np.testing.assert_allclose(freq, oprobs[0], atol=5e-3)
+
+
+# ---- fused IMPALA loss (parlhip_impala_loss_f32): loss terms + gradient in one kernel ----
+@pytest.mark.parametrize('T,B,A,time_major', [(50, 64, 6, True), (50, 20, 6, False), (7, 3, 4, True),
+                                              (130, 5, 18, False), (200, 9, 2, True)])
+def test_impala_fused_loss_matches_autograd(dev, T, B, A, time_major):
+    """ops.impala_loss == the reference formulas (impala.py:25-79,119-165) evaluated by torch autograd
+    in float64 on top of the same V-trace targets: loss sums to 1e-5 relative, gradients w.r.t.
+    target logits / values to 1e-5 of their scale."""
+    import torch.nn.functional as F
+    from parl_amd import ops
+    g = torch.Generator(device=dev).manual_seed(T * 1000 + B)
+    shp = (T, B) if time_major else (B, T)
+    bl = torch.randn(shp + (A, ), device=dev, generator=g)
+    tl = (bl + 0.3 * torch.randn(shp + (A, ), device=dev, generator=g)).requires_grad_(True)
+    act = torch.randint(0, A, shp, device=dev, generator=g)
+    rew = torch.randint(-1, 2, shp, device=dev, generator=g).float()
+    dones = torch.rand(shp, device=dev, generator=g) < 0.05
+    val = torch.randn(shp, device=dev, generator=g).requires_grad_(True)
+    gamma, crho, cpg, vf_c, ent_c = 0.99, 1.0, 1.0, 0.5, -0.01
+    out = ops.impala_loss(bl, tl.detach(), act, rew, dones, val.detach(), gamma, crho, cpg, vf_c, ent_c,
+                          time_major=time_major)
+    assert out is not None
+    vs, pg, glog, gval, sums = out
+    vs2, pg2 = ops.vtrace_from_logits(bl, tl.detach(), act, rew, dones, val.detach(), gamma, crho, cpg,
+                                      time_major=time_major)
+    np.testing.assert_allclose(vs.cpu().numpy(), vs2.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(pg.cpu().numpy(), pg2.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    cut = (lambda x: x[:-1]) if time_major else (lambda x: x[:, :-1])
+    tl64, val64 = tl.double(), val.double()
+    logp = F.log_softmax(tl64, dim=-1)
+    p = logp.exp()
+    ent = -(p * logp).sum(-1)
+    tlp = logp.gather(-1, act.unsqueeze(-1)).squeeze(-1)
+    pi_loss = -(cut(tlp) * pg2.double()).sum()
+    vf_loss = 0.5 * ((cut(val64) - vs2.double())**2).sum()
+    entropy = cut(ent).sum()
+    total = pi_loss + vf_c * vf_loss + ent_c * entropy
+    total.backward()
+    kl = (p * (logp - F.log_softmax(bl.double(), dim=-1))).sum()
+    ref = np.array([float(pi_loss), float(vf_loss), float(entropy), float(kl)])
+    np.testing.assert_allclose(sums.cpu().numpy(), ref, rtol=1e-5, atol=1e-4)
+    for mine, want in ((glog, tl.grad), (gval, val.grad)):
+        scale = float(want.abs().max()) + 1e-12
+        assert float((mine.double() - want.double()).abs().max()) <= 1e-5 * scale + 1e-7
+    # unsupported shapes are reported, not silently mis-computed
+    assert ops.impala_loss(torch.randn((4, 2, 5), device=dev), torch.randn((4, 2, 5), device=dev),
+                           torch.zeros((4, 2), dtype=torch.int64, device=dev), torch.zeros((4, 2), device=dev),
+                           torch.zeros((4, 2), dtype=torch.bool, device=dev), torch.zeros((4, 2), device=dev),
+                           0.99) is None
+
+
+def test_impala_learn_fused_equals_unfused(dev):
+    """IMPALA.learn with the one-kernel loss == the autograd graph of the reference formulas:
+    same losses, same parameters after the update (both layouts)."""
+    import copy
+    import parl_amd as parl
+    from parl_amd.models import AtariModel42
+    torch.manual_seed(1)
+    T, B, A = 10, 6, 6
+    for time_major in (True, False):
+        m1 = AtariModel42(A).to(dev)
+        m2 = copy.deepcopy(m1)
+        algs = []
+        for m, fused in ((m1, True), (m2, False)):
+            alg = parl.algorithms.IMPALA(m, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
+                                         clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+            alg.fused_loss = fused
+            algs.append(alg)
+        obs = torch.randint(0, 256, (T * B, 4, 42, 42), dtype=torch.uint8, device=dev)
+        act = torch.randint(0, A, (T * B, ), device=dev)
+        bl = torch.randn((T * B, A), device=dev)
+        rew = torch.randint(-1, 2, (T * B, ), device=dev).float()
+        dones = torch.rand(T * B, device=dev) < 0.1
+        res = [alg.learn(obs, act, bl, rew, dones, 1e-3, -0.01, time_major=time_major) for alg in algs]
+        (l1, k1), (l2, k2) = res
+        for name in ('total_loss', 'pi_loss', 'vf_loss', 'entropy'):
+            np.testing.assert_allclose(float(getattr(l1, name)), float(getattr(l2, name)), rtol=2e-5, atol=1e-3)
+        np.testing.assert_allclose(float(k1), float(k2), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(l1.vtrace_returns.vs.cpu().numpy(), l2.vtrace_returns.vs.cpu().numpy(),
+                                   rtol=1e-6, atol=1e-6)
+        for p1, p2 in zip(m1.parameters(), m2.parameters()):
+            np.testing.assert_allclose(p1.detach().cpu().numpy(), p2.detach().cpu().numpy(), rtol=1e-3, atol=2e-5)
