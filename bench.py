@@ -164,7 +164,11 @@ def main():
     ent_s = parl.utils.PiecewiseScheduler(cfg['entropy_coeff_scheduler'])
 
     vt_timer = KernelTimer()
-    ops.vtrace_from_logits = vt_timer.wrap(ops.vtrace_from_logits)
+    # time the C-ABI entry itself (the kernel launch on the learner stream), not the Python wrapper
+    # around it (output allocations, the zero fill of the sums)
+    from parl_amd import _native
+    for name in ('parlhip_impala_loss_f32', 'parlhip_vtrace_from_logits_f32'):
+        setattr(_native.lib(), name, vt_timer.wrap(getattr(_native.lib(), name)))
     env_timer, fp_timer = KernelTimer(), KernelTimer()
     for e in envs:
         e.step_async = env_timer.wrap(e.step_async)
@@ -241,16 +245,22 @@ def main():
         # --- roofline of the V-trace kernel at the workload shape (HBM-bound scan) ---
         A = env.act_dim
         vt = vt_timer.mean_seconds()
-        by = T * Eg * (2 * A * 4 + 8 + 4 + 1 + 4 + 8)  # 73 B/elt at A=6, fused from logits
+        # 73 B/elt at A=6 for the fused V-trace from logits (2 logits rows, action, reward,
+        # done, value in; vs, pg_adv out); the one-kernel loss additionally writes the gradient
+        # w.r.t. logits and values (4A + 4 B/elt)
+        fused = bool(getattr(alg, 'fused_loss', False))
+        by = T * Eg * (2 * A * 4 + 8 + 4 + 1 + 4) + (T - 1) * Eg * 8 + (T * Eg * (4 * A + 4) if fused else 0)
+        kname = ('impala_loss_wave_kernel (V-trace + log-prob gather + entropy + KL + loss sums + gradient, '
+                 if fused else 'vtrace_logits_wave_kernel (fused log-prob gather + V-trace, ')
         out['roofline'] = {
-            'kernel': 'vtrace_logits_wave_kernel (fused log-prob gather + V-trace, wave per sequence, T=%d B=%d A=%d; %d launch(es) per '
-                      'update, one per actor group)' % (T, Eg, A, G),
+            'kernel': kname + 'wave per sequence, T=%d B=%d A=%d; %d launch(es) per update, one per actor group)' %
+            (T, Eg, A, G),
             'bound': 'hbm', 'achieved': by / vt / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
             'frac': by / vt / 1e9 / HBM_PEAK_GBPS, 'bytes_per_launch': by,
             'note': 'workload shape is %.1f MB: launch-latency-bound by construction (SURVEY §8d); '
                     'see roofline_saturating for the HBM-bound shape' % (by / 1e6),
         }
-        out['roofline'].update(pmc_traffic('vtrace_logits_T%d_B%d_A%d' % (T, Eg, A)))
+        out['roofline'].update(pmc_traffic(('impala_loss' if fused else 'vtrace_logits') + '_T%d_B%d_A%d' % (T, Eg, A)))
         # --- the same scan family at the saturating shape (T'=127, B=262,144: 932 MB) ---
         Ts, Bs = 127, 262144
         x = [torch.randn((Ts, Bs), device=dev) for _ in range(5)]

@@ -395,8 +395,11 @@ __global__ __launch_bounds__(256) void impala_loss_wave_kernel(
     float clip_rho, float clip_pg, float vf_coeff, float ent_coeff, int* __restrict__ err) {
   const int lane = threadIdx.x & 63;
   const int blk = TM ? xcd_chunk_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int64_t b = ((int64_t)blk * blockDim.x + threadIdx.x) >> 6;
-  if (b >= B) return;  // whole wave exits together
+  const int64_t b_raw = ((int64_t)blk * blockDim.x + threadIdx.x) >> 6;
+  // a wave past the last sequence recomputes sequence B-1 with its stores and sums masked, so that
+  // the whole workgroup reaches the reduction barrier below
+  const bool live = b_raw < B;
+  const int64_t b = live ? b_raw : (int64_t)B - 1;
   const int Tm = T - 1;
   const int64_t in_t = TM ? B : 1, in_b = TM ? 1 : T, out_b = TM ? 1 : Tm;
   const float bootstrap = val[(int64_t)Tm * in_t + b * in_b];
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(256) void impala_loss_wave_kernel(
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int t = lane * K + k;
-    if (t >= T) continue;
+    if (t >= T || !live) continue;
     const int64_t i = (int64_t)t * in_t + b * in_b;
     if (valid[k]) {
       const int64_t o = (int64_t)t * in_t + b * out_b;
@@ -466,13 +469,18 @@ __global__ __launch_bounds__(256) void impala_loss_wave_kernel(
       gval[i] = 0.f;
     }
   }
-  pi = wave_sum(pi); vf = wave_sum(vf); ent = wave_sum(ent); kl = wave_sum(kl);
+  // wave reduction, then the 4 waves of the workgroup through LDS: one f64 atomic per term and
+  // WORKGROUP (with one per wave, 4 x 1024 atomics on four addresses made this kernel 55 us)
+  pi = wave_sum(pi); vf = wave_sum(vf); ent = wave_sum(ent); kl = wave_sum(live ? kl : 0.f);
+  __shared__ float red[4][4];
   if (lane == 0) {
-    atomicAdd(sums + 0, (double)pi);
-    atomicAdd(sums + 1, (double)vf);
-    atomicAdd(sums + 2, (double)ent);
-    atomicAdd(sums + 3, (double)kl);
+    const int w = threadIdx.x >> 6;
+    red[w][0] = pi; red[w][1] = vf; red[w][2] = ent; red[w][3] = kl;
   }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    atomicAdd(sums + threadIdx.x, (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] +
+                                      (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x]);
 }
 
 // V-trace from log-probs (the reference function boundary), time-major, wave-per-sequence:

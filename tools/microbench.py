@@ -95,6 +95,13 @@ def main():
         s = timeit(lambda: ops.atari42_conv12(obs, w1, b1, w2, b2, out=out))
         fl = n * 2.0 * (441 * 16 * 64 + 121 * 32 * 256)
         res['conv12_u8_mfma_n%d' % n] = {'us': s * 1e6, 'TFLOPs': fl / s / 1e12, 'GBps': n * (7056 + 15488) / s / 1e9}
+    T, B, A = 50, 1024, 6
+    bl, tl = torch.randn((T, B, A), device=dev), torch.randn((T, B, A), device=dev)
+    act = torch.randint(0, A, (T, B), device=dev)
+    rw, dn, vl = torch.randn((T, B), device=dev), torch.rand((T, B), device=dev) < 0.01, torch.randn((T, B), device=dev)
+    s = timeit(lambda: ops.impala_loss(bl, tl, act, rw, dn, vl, 0.99))
+    by = T * B * (2 * A * 4 + 8 + 4 + 1 + 4) + (T - 1) * B * 8 + T * B * (4 * A + 4)
+    res['impala_loss_T50_B1024_A6 (incl. 5 allocations + zero fill)'] = {'us': s * 1e6, 'GBps': by / s / 1e9, 'bytes': by}
     from parl_amd.env import DeviceVectorEnv
     for dim in (42, 84):
         env = DeviceVectorEnv('PongNoFrameskip-v4', 1024, dim=dim, horizon=8, seed=1, device=dev)

@@ -65,5 +65,10 @@ flush_cache()
 ops.vtrace_from_logits(bl, tl, act, rw, dn, vl, 0.99)
 out['vtrace_logits_T50_B1024_A6'] = {'kernel': 'vtrace_logits_', 'read': T * B * (2 * A * 4 + 8 + 4 + 1 + 4),
                                      'write': (T - 1) * B * 8}
+# --- the learner's one-kernel loss at the same shape (adds the gradient writes)
+flush_cache()
+ops.impala_loss(bl, tl, act, rw, dn, vl, 0.99)
+out['impala_loss_T50_B1024_A6'] = {'kernel': 'impala_loss_wave_kernel', 'read': T * B * (2 * A * 4 + 8 + 4 + 1 + 4),
+                                   'write': (T - 1) * B * 8 + T * B * (4 * A + 4)}
 torch.cuda.synchronize()
 print(json.dumps(out))
