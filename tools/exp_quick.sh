@@ -8,8 +8,8 @@ for so in $R/build_exp/*.so; do
   echo "== $n"; PARL_HIP_LIB=$so timeout 300 python $R/tools/emu_bench.py PongNoFrameskip-v4 $ELIST 2>&1 | grep "E="
 done
 for n in $2; do
-  echo "== parity $n"; PARL_HIP_LIB=$R/build_exp/$n.so timeout 300 python $R/tools/emu_parity.py --envs 8 --steps 300 2>&1 | tail -3
-  PARL_HIP_LIB=$R/build_exp/$n.so timeout 300 python $R/tools/emu_parity.py --game BreakoutNoFrameskip-v4 --envs 8 --steps 300 2>&1 | tail -2
+  echo "== parity $n"; PARL_HIP_LIB=$R/build_exp/$n.so timeout 300 python $R/tests/tools/emu_parity.py --envs 8 --steps 300 2>&1 | tail -3
+  PARL_HIP_LIB=$R/build_exp/$n.so timeout 300 python $R/tests/tools/emu_parity.py --game BreakoutNoFrameskip-v4 --envs 8 --steps 300 2>&1 | tail -2
 done
 for n in $3; do
   export PARL_HIP_LIB=$R/build_exp/$n.so
