@@ -2,7 +2,7 @@
 
 Input: the gfx950 assembly of a marker build of atari_env.hip (PARLHIP_CART_MARKERS=1 makes
 gen_cart_native.py emit an asm comment at every block start) and a per-address execution histogram
-of the game produced by an instrumented build of the CPU oracle.  Output: ISA instructions per 6507
+of the game produced by an instrumented build of the CPU oracle (tests/tools/oracle_profile.py).  Output: ISA instructions per 6507
 block weighted by how often the block runs = where the translated code spends its issue slots.
 Approximate (instructions are attributed to the last marker above them in layout order), used to
 pick what to optimise before spending GPU time."""
