@@ -210,3 +210,70 @@ def test_window_and_time_stat():
     with t:
         time.sleep(0.001)
     assert t.mean > 0
+
+
+# ---- PPO surface (parl/algorithms/torch/ppo.py:27-79, examples/PPO/storage.py:18-43) ----
+class TinyPPOModel(parl.Model):
+    def __init__(self):
+        super(TinyPPOModel, self).__init__()
+        self.fc = nn.Linear(4, 8)
+        self.pi = nn.Linear(8, 3)
+        self.v = nn.Linear(8, 1)
+
+    def policy(self, obs):
+        return self.pi(torch.tanh(self.fc(obs)))
+
+    def value(self, obs):
+        return self.v(torch.tanh(self.fc(obs)))
+
+
+def test_ppo_constructor_contract():
+    """the argument checks of ppo.py:54-65 and check_model_method (utils.py:217-243)"""
+    m = TinyPPOModel()
+    alg = parl.algorithms.PPO(m, clip_param=0.2, entropy_coef=0.0, initial_lr=3e-4, continuous_action=False)
+    assert alg.clip_param == 0.2 and alg.value_loss_coef == 0.5 and alg.max_grad_norm == 0.5
+    assert alg.optimizer.defaults['eps'] == 1e-5 and alg.norm_adv and alg.use_clipped_value_loss
+    with pytest.raises(AssertionError):
+        parl.algorithms.PPO(m, clip_param=1)              # must be float
+    with pytest.raises(AssertionError):
+        parl.algorithms.PPO(m, continuous_action=0)       # must be bool
+    with pytest.raises(AssertionError):
+        parl.algorithms.PPO(TinyModelNoValue())           # model needs value / policy
+
+
+class TinyModelNoValue(parl.Model):
+    def policy(self, obs):
+        return obs
+
+
+def test_rollout_storage_ring_and_loud_failure_without_gpu():
+    """append is the reference's ring (cur_step wraps, storage.py:35-43); the arithmetic has no CPU
+    path: compute_returns / sample_batch on host tensors raise instead of falling back"""
+    import collections
+    from parl_amd import _native
+    Space = collections.namedtuple('Space', ['shape'])
+    rs = parl.RolloutStorage(3, 2, Space((4, )), Space(()), device='cpu')
+    assert rs.obs.shape == (3, 2, 4) and rs.actions.shape == (3, 2) and rs.obs.dtype == torch.float32
+    for t in range(5):
+        rs.append(np.full((2, 4), t, np.float32), np.full(2, t), np.zeros(2), np.ones(2), np.zeros(2), np.zeros(2))
+    assert rs.cur_step == 5 % 3
+    assert float(rs.obs[0, 0, 0]) == 3.0 and float(rs.obs[1, 0, 0]) == 4.0 and float(rs.obs[2, 0, 0]) == 2.0
+    with pytest.raises(_native.ParlHipError):
+        rs.compute_returns(np.zeros(2, np.float32), np.zeros(2, np.float32))
+    rs.advantages = rs.returns = torch.zeros(3, 2)
+    with pytest.raises(_native.ParlHipError):
+        rs.sample_batch(np.array([0, 1]))
+
+
+def test_device_ops_refuse_host_tensors():
+    """every new entry fails loudly on CPU tensors (no fallback): conv1-84, vecnorm, fused loss"""
+    from parl_amd import _native, ops
+    E = _native.ParlHipError
+    with pytest.raises(E):
+        ops.atari84_conv1(torch.zeros((1, 4, 84, 84), dtype=torch.uint8), torch.zeros(32, 4, 8, 8), torch.zeros(32))
+    with pytest.raises(E):
+        ops.vecnorm_obs(torch.zeros((2, 3), dtype=torch.float64), torch.zeros((2, 3), dtype=torch.float64),
+                        torch.ones((2, 3), dtype=torch.float64), torch.ones(2, dtype=torch.float64))
+    with pytest.raises(E):
+        ops.impala_loss(torch.zeros(4, 2, 6), torch.zeros(4, 2, 6), torch.zeros((4, 2), dtype=torch.int64),
+                        torch.zeros(4, 2), torch.zeros((4, 2), dtype=torch.bool), torch.zeros(4, 2), 0.99)
