@@ -1,0 +1,76 @@
+"""CPU checks of the static cartridge translator (parl_amd/csrc/gen_cart_native.py): structural
+properties of the dispatch-entry set, and — by replaying an instruction trace of the CPU oracle —
+that restricting the dispatch switch to those entries keeps execution inside translated code
+(a PC outside the set is always safe but interpreted).  Needs the cartridges
+(roms/, provisioned by __graft_entry__.build()); skipped without them."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, 'parl_amd', 'csrc'))
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'tools'))
+
+
+def _cart(name):
+    import gen_cart_native as g
+    path = os.path.join(ROOT, 'roms', name + '.bin')
+    if not os.path.exists(path):
+        pytest.skip('cartridge %s not provisioned' % name)
+    return g, g.Cart(name, open(path, 'rb').read())
+
+
+@pytest.mark.parametrize('name', ['pong', 'breakout'])
+def test_entry_set_structure(name):
+    g, c = _cart(name)
+    ent = c.entries()
+    assert ent <= set(c.code)                       # every case label has a block
+    assert c.word(0xfffc) in ent                    # reset vector
+    assert len(ent) < len(c.code) // 2              # the point: most blocks are NOT dispatch targets
+    for a, (mode, kind, op, b1, b2) in c.code.items():
+        body = c.emit(a)
+        if op == 'JSR':
+            assert (b1 | (b2 << 8)) in ent or (b1 | (b2 << 8)) not in c.code
+            assert ((a + 3) & 0xffff) in ent or ((a + 3) & 0xffff) not in c.code
+        elif mode != g.M_REL and op not in ('JMP', 'BRK', 'RTS', 'RTI', 'JMPI', 'JAM') and \
+                any('return' in ln for ln in body):
+            nxt = (a + g.length(mode)) & 0xffff     # execution resumes here after the deferral
+            assert nxt in ent or nxt not in c.code, hex(a)
+    src = c.source('GAME_PONG' if name == 'pong' else 'GAME_BREAKOUT')
+    assert src.count('case 0x') == len(ent)
+    assert 'e.pend = ' in src                        # real TIA stores are handed over, not re-decoded
+
+
+@pytest.mark.parametrize('name,max_wait', [('pong', 10.0), ('breakout', 10.0)])
+def test_restricted_dispatch_keeps_execution_translated(tmp_path, name, max_wait):
+    """replay 1600 frames of the oracle's instruction trace against the entry set: instructions that
+    would be interpreted only because the PC is not an entry must stay negligible"""
+    g, c = _cart(name)
+    import oracle_profile
+    oracle_profile.main(str(tmp_path))
+    tr = np.fromfile(os.path.join(str(tmp_path), name + '.trace'), dtype=np.uint16).reshape(-1, 2)
+    frames = 1600
+    bodies = {a: c.emit(a) for a in c.code}
+    static_fb = {a for a, b in bodies.items() if len(b) == 1 and b[0].startswith('{ e.PC')}
+    dyn = {a for a, b in bodies.items() if a not in static_fb and c.code[a][0] != g.M_REL and c.code[a][2] != 'JMP'
+           and any('return' in ln for ln in b)}
+    ent = c.entries()
+    native, deferrals, waiting, translated = False, 0, 0, 0
+    for pc, real in tr.tolist():
+        if not native:
+            if pc in ent:
+                native = True
+            else:
+                waiting += 1
+                continue
+        if pc in static_fb or (real and pc in dyn):
+            deferrals += 1
+            native = False
+            continue
+        translated += 1
+    total = len(tr)
+    assert waiting / frames <= max_wait, (waiting / frames, deferrals / frames)
+    assert translated / total > 0.9, translated / total
