@@ -151,3 +151,83 @@ def test_device_env_sharding_keeps_rng_streams(dev):
         o, r, d, _ = full.step(a)
         o2, r2, d2, _ = shard.step(a[2:].contiguous())
         assert torch.equal(o[2:], o2) and torch.equal(r[2:], r2) and torch.equal(d[2:], d2)
+
+
+# ---- PPO: mean-reduced losses => the data-parallel gradient is the MEAN over ranks ----
+def _ppo_model():
+    import torch.nn as nn
+    import parl_amd as parl
+
+    class M(parl.Model):
+        def __init__(self):
+            super(M, self).__init__()
+            self.fc = nn.Linear(4, 8)
+            self.pi = nn.Linear(8, 2)
+            self.v = nn.Linear(8, 1)
+            self.logstd = nn.Parameter(torch.zeros(1, 2))
+
+        def policy(self, o):
+            return self.pi(torch.tanh(self.fc(o))), torch.exp(self.logstd)
+
+        def value(self, o):
+            return self.v(torch.tanh(self.fc(o)))
+
+    return M()
+
+
+def _ppo_batch():
+    g = torch.Generator().manual_seed(11)
+    n = 16
+    return dict(obs=torch.randn(n, 4, generator=g), act=torch.randn(n, 2, generator=g),
+                val=torch.randn(n, generator=g), ret=torch.randn(n, generator=g),
+                logp=torch.randn(n, generator=g) * 0.1 - 2.0, adv=torch.randn(n, generator=g))
+
+
+def _ppo_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import parl_amd as parl
+    from parl_amd import dist as pdist
+    pdist.init(backend='gloo')
+    torch.manual_seed(200 + rank)
+    m = _ppo_model()
+    pdist.broadcast_model(m)
+    # norm_adv=False: the per-minibatch normalisation is the HIP kernel (no CPU path); the exchange
+    # logic under test is independent of it
+    alg = parl.algorithms.PPO(m, clip_param=0.2, entropy_coef=0.01, initial_lr=1e-2, norm_adv=False,
+                              continuous_action=True)
+    alg.grad_hook = pdist.FlatGradAllReduce(alg.model, average=True)
+    b = _ppo_batch()
+    sl = slice(rank * 8, rank * 8 + 8)
+    for _ in range(3):
+        alg.learn(b['obs'][sl], b['act'][sl], b['val'][sl], b['ret'][sl], b['logp'][sl], b['adv'][sl])
+    pdist.barrier()
+    q.put((rank, {k: v.numpy().copy() for k, v in alg.model.state_dict().items()}))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='PPO moves its model to the GPU when one is present (ppo.py:75-76)')
+def test_ppo_data_parallel_mean_gradient(tmp_path):
+    import parl_amd as parl
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ppo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sd0, sd1 = res[0][1], res[1][1]
+    for k in sd0:
+        assert np.array_equal(sd0[k], sd1[k]), k
+    torch.manual_seed(200)
+    m = _ppo_model()
+    alg = parl.algorithms.PPO(m, clip_param=0.2, entropy_coef=0.01, initial_lr=1e-2, norm_adv=False,
+                              continuous_action=True)
+    b = _ppo_batch()
+    for _ in range(3):  # equal shards: the mean over the union = the mean of the per-rank means
+        alg.learn(b['obs'], b['act'], b['val'], b['ret'], b['logp'], b['adv'])
+    for k, v in alg.model.state_dict().items():
+        np.testing.assert_allclose(sd0[k], v.numpy(), rtol=2e-5, atol=2e-6)
