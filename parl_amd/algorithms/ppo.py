@@ -59,39 +59,34 @@ class PPO(Algorithm):
             return Normal(mean, std)
         return Categorical(logits=self.model.policy(obs))
 
-    def learn(self, batch_obs, batch_action, batch_value, batch_return, batch_logprob, batch_adv, lr=None):
-        """ppo.py:81-158.  Returns (value_loss, action_loss, entropy_loss) as python floats."""
-        values = self.model.value(batch_obs)
-        dist = self._dist(batch_obs)
-        if self.continuous_action:
-            action_log_probs = dist.log_prob(batch_action).sum(1)
-            dist_entropy = dist.entropy().sum(1)
-        else:
-            action_log_probs = dist.log_prob(batch_action)
-            dist_entropy = dist.entropy()
-        entropy_loss = dist_entropy.mean()
-
-        if self.norm_adv:  # ppo.py:124-127 on the device kernel (unbiased std, + 1e-8)
-            batch_adv = ops.adv_normalize(batch_adv.detach(), eps=1e-8).view_as(batch_adv)
-
-        ratio = torch.exp(action_log_probs - batch_logprob)
-        surr1 = ratio * batch_adv
-        surr2 = torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param) * batch_adv
-        action_loss = -torch.min(surr1, surr2).mean()
-
-        values = values.view(-1)
+    def _losses(self, obs, action, old_value, ret, old_logp, adv):
+        """the three terms of the PPO objective for one minibatch (ppo.py:104-148)"""
+        dist = self._dist(obs)
+        logp, entropy = dist.log_prob(action), dist.entropy()
+        if self.continuous_action:  # independent Normal per action dimension
+            logp, entropy = logp.sum(1), entropy.sum(1)
+        if self.norm_adv:  # ppo.py:124-127 on the device kernel (unbiased std, + 1e-8); no gradient
+            adv = ops.adv_normalize(adv.detach(), eps=1e-8).view_as(adv)
+        eps = self.clip_param
+        ratio = torch.exp(logp - old_logp)
+        policy_loss = -torch.minimum(ratio * adv, ratio.clamp(1.0 - eps, 1.0 + eps) * adv).mean()
+        value = self.model.value(obs).view(-1)
         if self.use_clipped_value_loss:
-            value_pred_clipped = batch_value + torch.clamp(values - batch_value, -self.clip_param, self.clip_param)
-            value_losses = (values - batch_return).pow(2)
-            value_losses_clipped = (value_pred_clipped - batch_return).pow(2)
-            value_loss = 0.5 * torch.max(value_losses, value_losses_clipped).mean()
+            clipped = old_value + (value - old_value).clamp(-eps, eps)
+            value_loss = 0.5 * torch.maximum((value - ret)**2, (clipped - ret)**2).mean()
         else:
-            value_loss = 0.5 * (batch_return - values).pow(2).mean()
-        loss = value_loss * self.value_loss_coef + action_loss - entropy_loss * self.entropy_coef
+            value_loss = 0.5 * ((ret - value)**2).mean()
+        return value_loss, policy_loss, entropy.mean()
 
+    def learn(self, batch_obs, batch_action, batch_value, batch_return, batch_logprob, batch_adv, lr=None):
+        """ppo.py:81-158: one clipped-surrogate update on a minibatch.  Returns
+        (value_loss, action_loss, entropy_loss) as python floats."""
+        value_loss, action_loss, entropy_loss = self._losses(batch_obs, batch_action, batch_value, batch_return,
+                                                             batch_logprob, batch_adv)
+        loss = value_loss * self.value_loss_coef + action_loss - entropy_loss * self.entropy_coef
         if lr:
-            for param_group in self.optimizer.param_groups:
-                param_group['lr'] = lr
+            for group in self.optimizer.param_groups:
+                group['lr'] = lr
         self.optimizer.zero_grad()
         loss.backward()
         if self.grad_hook is not None:

@@ -277,3 +277,58 @@ def test_device_ops_refuse_host_tensors():
     with pytest.raises(E):
         ops.impala_loss(torch.zeros(4, 2, 6), torch.zeros(4, 2, 6), torch.zeros((4, 2), dtype=torch.int64),
                         torch.zeros(4, 2), torch.zeros((4, 2), dtype=torch.bool), torch.zeros(4, 2), 0.99)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='PPO moves its model to the GPU when one is present')
+@pytest.mark.parametrize('case', ['continuous', 'discrete', 'continuous_noclipv_nonorm'])
+def test_ppo_learn_host_logic_matches_reference_fixture(case, monkeypatch):
+    """parl_amd.algorithms.PPO.learn on CPU against the losses / weights the reference's torch PPO
+    produced (tests/golden/ppo_learn.npz).  The advantage normalisation is a HIP kernel with no CPU
+    path; for this HOST-LOGIC test it is replaced by the formula it implements (ppo.py:124-127) —
+    the kernel itself is checked on the GPU (tests/test_gpu_ppo.py)."""
+    from conftest import load_golden
+    from parl_amd import ops
+    monkeypatch.setattr(ops, 'adv_normalize', lambda adv, eps=1e-8, **k: (adv - adv.mean()) / (adv.std() + eps))
+    z = load_golden('ppo_learn.npz')
+    obs_dim, act_dim, nb = [int(x) for x in z[case + '/dims']]
+    clip, ent, lr0, clipv, norm = [float(x) for x in z[case + '/kw']]
+    cont = case.startswith('continuous')
+
+    class MujocoModel(parl.Model):
+        def __init__(self):
+            super().__init__()
+            self.fc1, self.fc2 = nn.Linear(obs_dim, 64), nn.Linear(64, 64)
+            self.fc_value, self.fc_policy = nn.Linear(64, 1), nn.Linear(64, act_dim)
+            self.fc_pi_std = nn.Parameter(torch.zeros(1, act_dim))
+
+        def value(self, obs):
+            return self.fc_value(torch.tanh(self.fc2(torch.tanh(self.fc1(obs)))))
+
+        def policy(self, obs):
+            return self.fc_policy(torch.tanh(self.fc2(torch.tanh(self.fc1(obs))))), torch.exp(self.fc_pi_std)
+
+    class DiscreteModel(parl.Model):
+        def __init__(self):
+            super().__init__()
+            self.fc1, self.fc_value, self.fc_policy = nn.Linear(obs_dim, 64), nn.Linear(64, 1), nn.Linear(64, act_dim)
+
+        def value(self, obs):
+            return self.fc_value(torch.tanh(self.fc1(obs)))
+
+        def policy(self, obs):
+            return self.fc_policy(torch.tanh(self.fc1(obs)))
+
+    model = (MujocoModel if cont else DiscreteModel)()
+    prefix = case + '/init/'
+    model.load_state_dict({k[len(prefix):]: torch.from_numpy(v) for k, v in z.items() if k.startswith(prefix)})
+    alg = parl.algorithms.PPO(model, clip_param=clip, entropy_coef=ent, initial_lr=lr0,
+                              use_clipped_value_loss=bool(clipv), norm_adv=bool(norm), continuous_action=cont)
+    losses = []
+    for it in range(3):
+        b = {k: torch.from_numpy(z['%s/batch%d/%s' % (case, it, k)]) for k in ('obs', 'act', 'val', 'ret', 'logp', 'adv')}
+        lr = float(z['%s/batch%d/lr' % (case, it)])
+        losses.append(alg.learn(b['obs'], b['act'], b['val'], b['ret'], b['logp'], b['adv'], None if np.isnan(lr) else lr))
+    np.testing.assert_allclose(np.array(losses), z[case + '/losses'], rtol=1e-5, atol=1e-7)
+    prefix = case + '/final/'
+    for k, v in alg.model.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), z[prefix + k], rtol=1e-4, atol=1e-6, err_msg=k)
