@@ -1,0 +1,21 @@
+/* Test infrastructure: exposes the CPU oracle's bus / frame primitives (static in atari_oracle.c)
+ * to the host build of the translated cartridge code (main.cpp).  Nothing here is product code. */
+#include "../../../oracle/atari_oracle.c"
+
+/* the bookkeeping of atari_frame() before its instruction loop (Stella TIA::startFrame) */
+void host_frame_begin(Atari* a, uint8_t* fb) {
+  const int32_t into = (a->cyc - a->cyc0) % 76;
+  const int32_t old = a->cyc;
+  a->cyc = 0;
+  a->cyc0 = -into;
+  a->timer_set_cyc -= old;
+  a->dump_disabled_cyc -= old;
+  if (a->vsync_finish_clock != 0x7fffffff) a->vsync_finish_clock -= old * 3;
+  a->last_clock = frame_clock0(a) + CLOCKS_PER_LINE * ATARI_YSTART;
+  a->fb = fb;
+  a->stop = 0;
+}
+void host_cpu_step(Atari* a) { cpu_step(a); }
+void host_wr(Atari* a, uint16_t addr, uint8_t v) { wr(a, addr, v); }
+uint8_t host_tia_read(Atari* a, uint16_t addr, uint8_t noise) { a->bus = noise; return tia_read(a, (uint8_t)addr); }
+uint8_t host_riot_read(Atari* a, uint16_t addr) { return riot_read(a, addr); }
