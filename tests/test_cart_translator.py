@@ -104,3 +104,45 @@ def test_translated_cartridge_on_host_equals_oracle(tmp_path, name, game):
     assert 'frames identical' in p.stdout
     translated = float(p.stdout.split('identical;')[1].split()[0])
     assert translated > 3000          # execution really goes through the translated blocks
+
+
+def _fn_body(text, signature):
+    """source of the function starting at `signature` (brace matched), normalised"""
+    import re
+    i = text.index(signature)
+    j = text.index('{', i)
+    depth, k = 0, j
+    while True:
+        depth += text[k] == '{'
+        depth -= text[k] == '}'
+        k += 1
+        if depth == 0:
+            break
+    body = text[j:k]
+    body = re.sub(r'//[^\n]*', '', body)
+    body = re.sub(r'__builtin_expect\((.*?), 0\)', r'\1', body)
+    return re.sub(r'\s+', '', body)
+
+
+def test_host_harness_alu_is_the_device_text_and_matches_oracle(tmp_path):
+    """(1) the flag arithmetic of tests/tools/cart_host/main.cpp is textually the device's
+    (atari_core.hpp adc / sbc / cmp / bit / set_nz / pfull / pset) — the harness cannot drift;
+    (2) that arithmetic equals the oracle's ADC / SBC / CMP for every accumulator, operand, carry and
+    decimal-mode combination (3 x 2 x 2 x 65,536 cases)."""
+    import subprocess
+    dev = open(os.path.join(ROOT, 'parl_amd', 'csrc', 'atari_core.hpp')).read()
+    host = open(os.path.join(ROOT, 'tests', 'tools', 'cart_host', 'main.cpp')).read()
+    for sig in ('void adc(int m)', 'void sbc(int m)', 'void cmp(int r, int m)', 'void bit(int m)', 'void set_nz(int v)',
+                'int pfull() const', 'void pset(int v)'):
+        assert _fn_body(dev, sig) == _fn_body(host, sig), sig
+    d = str(tmp_path)
+    src = os.path.join(ROOT, 'tests', 'tools', 'cart_host')
+    open(os.path.join(d, 'cart_native.gen.hpp'), 'w').write('// no cartridge needed for the ALU check\n')
+    subprocess.check_call(['gcc', '-O1', '-std=c11', '-ffp-contract=off', '-c', os.path.join(src, 'shim.c'), '-o',
+                           os.path.join(d, 'shim.o')])
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-I', d, '-c', os.path.join(src, 'main.cpp'), '-o',
+                           os.path.join(d, 'main.o')])
+    subprocess.check_call(['g++', os.path.join(d, 'shim.o'), os.path.join(d, 'main.o'), '-lm', '-o',
+                           os.path.join(d, 'cart_host')])
+    p = subprocess.run([os.path.join(d, 'cart_host'), '--alu'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0 and 'identical to the oracle' in p.stdout, p.stdout[-1500:]

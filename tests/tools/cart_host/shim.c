@@ -19,3 +19,12 @@ void host_cpu_step(Atari* a) { cpu_step(a); }
 void host_wr(Atari* a, uint16_t addr, uint8_t v) { wr(a, addr, v); }
 uint8_t host_tia_read(Atari* a, uint16_t addr, uint8_t noise) { a->bus = noise; return tia_read(a, (uint8_t)addr); }
 uint8_t host_riot_read(Atari* a, uint16_t addr) { return riot_read(a, addr); }
+
+/* ALU ops of the oracle on a scratch machine, for the exhaustive flag-arithmetic check */
+uint16_t host_alu(int op, uint8_t A, uint8_t m, uint8_t P) {   /* returns (P << 8) | A */
+  Atari t;
+  memset(&t, 0, sizeof(t));
+  t.A = A; t.P = P;
+  if (op == 0) op_adc(&t, m); else if (op == 1) op_sbc(&t, m); else op_cmp(&t, A, m);
+  return (uint16_t)((t.P << 8) | t.A);
+}
