@@ -22,3 +22,5 @@ int oracle_ale_jam(void* p) { return ((AleBox*)p)->ale.emu.jam; }
 void oracle_ale_ram(void* p, uint8_t* out) { memcpy(out, ((AleBox*)p)->ale.emu.ram, 128); }
 int32_t oracle_ale_cycles(void* p) { return ((AleBox*)p)->ale.emu.cyc - ((AleBox*)p)->ale.emu.cyc0; }
 void oracle_palette(uint32_t* out) { memcpy(out, atari_ntsc_palette, sizeof(atari_ntsc_palette)); }
+/* state surgery for the reference-GIF pin (tests/test_breakout_gif_pin.py): overwrite the 128 RAM bytes */
+void oracle_ale_set_ram(void* p, const uint8_t* in) { memcpy(((AleBox*)p)->ale.emu.ram, in, 128); }

@@ -55,6 +55,11 @@ static int player_pixel(int x, int pos, uint8_t nusiz, uint8_t refl, uint8_t grp
   const int scale_shift = mode == 5 ? 1 : (mode == 7 ? 2 : 0);
   int d = x - pos;
   if (d < 0) d += 160;
+  /* Stella 2.x computePlayerMaskTable: "in double [quad] size mode the player's output is delayed
+   * by one pixel" (mask set for 0 < x <= 16 [32], bit (x-1)/2 [/4]).  Pinned by the reference's own
+   * ALE recording (.github/Breakout.gif, tests/test_breakout_gif_pin.py): the 16-pixel paddle of
+   * Breakout is a double-size player and sits one pixel right of the undelayed position. */
+  if (scale_shift) d -= 1;
   for (int c = 0; c < 3 && k_copies[mode][c] >= 0; ++c) {
     if (c == 0 && suppress) continue;
     int off = d - k_copies[mode][c];

@@ -1,0 +1,118 @@
+"""Pins oracle/frame_oracle.c (the WarpFrame restatement, parl/env/atari_wrappers.py:263-267) on
+INDEPENDENT arithmetic, because cv2 itself is absent from this image:
+
+* INTER_AREA is by definition the exact box (area) average.  `exact_area` below computes it in
+  pure integer arithmetic (overlap lengths in units of 1/21 source pixel in x and 1/2 in y, so
+  every weight is an integer and the sum is exact), rounds half-to-even like cv::saturate_cast,
+  and must equal the oracle's float32 tap-table path everywhere except on outputs whose exact
+  value lies within 1e-4 of a .5 tie (there float32 summation order decides; +-1 allowed).
+* cv2.cvtColor(RGB2GRAY) is the published fixed-point formula; checked against a rational
+  evaluation of 0.299 R + 0.587 G + 0.114 B (|diff| < 1 LSB, equal after rounding except near
+  ties) and for the grey / primary identities.
+* PIL's BOX filter agrees with the area average whenever the scale is an integer: frames that are
+  constant along x are resized 210 -> 42 rows (factor 5) by PIL and by the oracle: <= 1 LSB
+  (PIL accumulates in 22-bit fixed point).
+"""
+import os
+import sys
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import c_oracle  # noqa: E402
+
+SRC_H, SRC_W = 210, 160
+
+
+def overlap_matrix(ssize, dsize):
+    """W[d, s] = length of [d*scale, (d+1)*scale) ∩ [s, s+1) in units of 1/dsize source pixels."""
+    W = np.zeros((dsize, ssize), np.int64)
+    for d in range(dsize):
+        lo, hi = d * ssize, (d + 1) * ssize  # in units of 1/dsize
+        for s in range(lo // dsize, min(ssize, -(-hi // dsize))):
+            W[d, s] = max(0, min(hi, (s + 1) * dsize) - max(lo, s * dsize))
+    assert (W.sum(1) == ssize).all()
+    return W
+
+
+def exact_area(gray, dim):
+    Wy, Wx = overlap_matrix(SRC_H, dim), overlap_matrix(SRC_W, dim)
+    num = Wy @ gray.astype(np.int64) @ Wx.T  # exact
+    den = SRC_H * SRC_W
+    q, r = np.divmod(num, den)
+    up = (2 * r > den) | ((2 * r == den) & (q % 2 == 1))  # round half to even
+    frac = r.astype(np.float64) / den
+    return (q + up).astype(np.int64), frac
+
+
+def gray_ref(rgb):
+    return ((rgb[..., 0].astype(np.int64) * 4899 + rgb[..., 1].astype(np.int64) * 9617 +
+             rgb[..., 2].astype(np.int64) * 1868 + 8192) >> 14).astype(np.uint8)
+
+
+@pytest.mark.parametrize('dim', [84, 42])
+def test_inter_area_equals_exact_rational_box_average(dim):
+    rng = np.random.default_rng(dim)
+    frames = rng.integers(0, 256, (20, SRC_H, SRC_W, 3), dtype=np.uint8)
+    # a few structured frames: blocks, single bright pixels, gradients
+    frames[0] = 0
+    frames[0, ::7, ::5] = 255
+    frames[1] = (np.arange(SRC_W)[None, :, None] * 255 // (SRC_W - 1)).astype(np.uint8)
+    frames[2] = (np.arange(SRC_H)[:, None, None] * 255 // (SRC_H - 1)).astype(np.uint8)
+    frames[3] = np.repeat(np.repeat(rng.integers(0, 256, (27, 20, 3), dtype=np.uint8), 8, 0), 8, 1)[:SRC_H]
+    out = c_oracle.frame_post(frames, None, dim, 0).astype(np.int64)
+    n_tie = 0
+    for e in range(frames.shape[0]):
+        ex, frac = exact_area(gray_ref(frames[e]), dim)
+        near_tie = np.abs(frac - 0.5) < 1e-4
+        n_tie += int(near_tie.sum()) if e >= 4 else 0  # structured frames tie by construction
+        assert np.array_equal(out[e][~near_tie], ex[~near_tie]), 'frame %d' % e
+        assert np.abs(out[e] - ex).max() <= 1
+    assert n_tie < 0.01 * out.size
+
+
+def test_inter_area_on_tia_colour_frames_with_max():
+    """fmt 1 (TIA colour bytes through the NTSC palette) + the MaxAndSkip max of two frames."""
+    import ctypes
+    rng = np.random.default_rng(5)
+    f0 = (rng.integers(0, 128, (6, SRC_H, SRC_W)) * 2).astype(np.uint8)
+    f1 = (rng.integers(0, 128, (6, SRC_H, SRC_W)) * 2).astype(np.uint8)
+    pal = (ctypes.c_uint32 * 128)()
+    c_oracle.lib().oracle_palette(pal)
+    p = np.array(pal, dtype=np.uint32)
+    rgbpal = np.stack([(p >> 16) & 255, (p >> 8) & 255, p & 255], 1).astype(np.uint8)
+    rgb = np.maximum(rgbpal[f0 >> 1], rgbpal[f1 >> 1])  # obs_buffer.max(axis=0), atari_wrappers.py:239
+    for dim in (84, 42):
+        out = c_oracle.frame_post(f0, f1, dim, 1).astype(np.int64)
+        for e in range(f0.shape[0]):
+            ex, frac = exact_area(gray_ref(rgb[e]), dim)
+            ok = np.abs(frac - 0.5) >= 1e-4
+            assert np.array_equal(out[e][ok], ex[ok])
+
+
+def test_rgb2gray_fixed_point_against_rational_luma():
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, (4096, 3), dtype=np.uint8)
+    g = gray_ref(rgb[None])[0]
+    for (r, gg, b), v in zip(rgb[:512].tolist(), g[:512].tolist()):
+        y = Fraction(299, 1000) * r + Fraction(587, 1000) * gg + Fraction(114, 1000) * b
+        assert abs(y - v) < Fraction(51, 100)  # rounded luma, fixed-point coefficient error < 0.01
+    grey = np.arange(256, dtype=np.uint8)
+    assert np.array_equal(gray_ref(np.stack([grey] * 3, -1)[None])[0], grey)  # R=G=B=v -> v
+    assert gray_ref(np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255]]], np.uint8)).tolist() == [[76, 150, 29]]
+
+
+def test_integer_factor_rows_agree_with_pil_box():
+    from PIL import Image
+    rng = np.random.default_rng(2)
+    for _ in range(5):
+        col = rng.integers(0, 256, (SRC_H, 1), dtype=np.uint8)
+        gray = np.repeat(col, SRC_W, 1)
+        rgb = np.stack([gray] * 3, -1)
+        out = c_oracle.frame_post(rgb[None], None, 42, 0)[0]
+        pil = np.asarray(Image.fromarray(gray).resize((42, 42), Image.BOX)).astype(np.int64)
+        assert np.abs(out.astype(np.int64) - pil).max() <= 1
+        assert (out == out[:, :1]).all()
