@@ -117,6 +117,27 @@ def cpu_baseline(game, dim, seconds_target=12.0):
     }
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without torchrun: start the N ranks ourselves, exactly as the
+    driver would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py ...`).  Rank 0 prints the one JSON line.  With fewer
+    visible GPUs than ranks the ranks share devices and talk over gloo (RCCL cannot put two ranks
+    on one device); the JSON line says so."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    if torch.cuda.device_count() < args.gpus:
+        env['PARL_AMD_SHARE_GPU'] = '1'
+        env['PARL_AMD_DIST_BACKEND'] = 'gloo'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -128,13 +149,20 @@ def main():
     ap.add_argument('--game', default='PongNoFrameskip-v4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--actor-groups', type=int, default=1, help='env groups (actor streams) per GPU')
+    ap.add_argument('--quick', action='store_true',
+                    help='headline workload only: skip the saturating-shape roofline and the extra config legs')
     ap.add_argument('--no-overlap', action='store_true',
                     help='run rollout and learner update back to back on one stream instead of overlapped')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args)
     rank, local, world = pdist.init()
-    assert world == args.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
-    if os.environ.get('PARL_AMD_SHARE_GPU'):  # test hook: several ranks on the one GPU of a test box
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or run without torchrun and '
+                 'let bench.py start the ranks itself)' % (args.gpus, world))
+    shared = bool(os.environ.get('PARL_AMD_SHARE_GPU'))
+    if shared:  # fewer GPUs than ranks (a 1-GPU test box): ranks share devices, gloo instead of RCCL
         local = local % torch.cuda.device_count()
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
@@ -193,12 +221,10 @@ def main():
         rollout = pipe.rollout
         pipe.prime()  # untimed: every timed step = one rollout + one learner update
 
+        pipe.gather_small = world > 1  # small-tensor trajectory all-gather on the learner stream
+
         def step():
             loss, kl = pipe.step(lr_s.step(), ent_s.step())
-            if world > 1:
-                for st, ro in zip(pipe.actor_streams, pipe.rollouts):
-                    with torch.cuda.stream(st):
-                        pdist.all_gather_small({'rewards': ro.rewards, 'dones': ro.dones, 'actions': ro.actions})
             return loss
 
     for _ in range(args.warmup):
@@ -237,6 +263,9 @@ def main():
             'envs_per_gpu': E, 'sample_batch_steps': T, 'obs_dim': dim, 'train_batch': T * E * world,
             'frame_skip': 4, 'parallelism': 'dp%d (envs sharded by rank, grad all-reduce)' % world,
             'actor_learner_overlap': not args.no_overlap, 'actor_groups': G,
+            'collectives': ('none (single process)' if world == 1 else
+                            ('gloo, ranks SHARE GPUs (fewer devices than ranks: functional run, not a scaling number)'
+                             if shared else 'RCCL: flat-gradient all-reduce + small-tensor all-gather per update')),
         },
         'learner_updates_per_sec': K / dt,
         'agent_steps_per_sec': K * T * E * world / dt,

@@ -68,7 +68,7 @@ class Learner(object):
         seqs = max(1, self.config['train_batch_size'] // T)
         while not self.stop:
             try:
-                batch = self.sample_data_queue.get(timeout=0.5)
+                batch, consumed = self.sample_data_queue.get(timeout=0.5)
             except queue.Empty:
                 continue
             E = batch['actions'].numel() // T
@@ -90,13 +90,16 @@ class Learner(object):
                 self.entropy_stat.add(entropy)
                 self.kl_stat.add(kl)
             self.sample_total_steps += T * E
-            self.consumed.set()
+            consumed.set()  # this actor's rollout buffers may be overwritten now
 
     # ------------------------------------------------------------------ actor side
     def create_actors(self):
         parl.connect(self.config['master_address'])
-        self.consumed = threading.Event()
-        self.consumed.set()
+        # one event PER ACTOR: an actor's rollout buffers are reused, and the queued batch aliases
+        # them, so only the learner's "done with YOUR batch" may release that actor
+        self.consumed = [threading.Event() for _ in range(self.config['actor_num'])]
+        for e in self.consumed:
+            e.set()
         self.actors = []
         for i in range(self.config['actor_num']):
             if self.start_time is None:
@@ -108,7 +111,8 @@ class Learner(object):
     def shutdown(self):
         """stop the actor / learner threads and wait for in-flight GPU work"""
         self.stop = True
-        self.consumed.set()
+        for e in self.consumed:
+            e.set()
         for t in self.actors + [self.learn_thread]:
             t.join(timeout=30)
         torch.cuda.synchronize()
@@ -118,10 +122,11 @@ class Learner(object):
         cnt = 0
         while not self.stop:
             # the rollout buffers are reused: wait until the learner has consumed the previous batch
-            self.consumed.wait()
-            self.consumed.clear()
+            consumed = self.consumed[actor_id]
+            consumed.wait()
+            consumed.clear()
             batch = remote_actor.sample().get()
-            self.sample_data_queue.put(batch)
+            self.sample_data_queue.put((batch, consumed))
             cnt += 1
             if cnt % self.config['get_remote_metrics_interval'] == 0:
                 metrics = remote_actor.get_metrics().get()

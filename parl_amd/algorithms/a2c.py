@@ -40,7 +40,7 @@ class A2C(Algorithm):
         total_loss = pi_loss + vf_loss * self.vf_loss_coeff + entropy * entropy_coeff
         for g in self.optimizer.param_groups:
             g['lr'] = lr
-        self.optimizer.zero_grad(set_to_none=True)
+        self._zero_grad()
         total_loss.backward()
         if self.grad_hook is not None:
             self.grad_hook(self.model)

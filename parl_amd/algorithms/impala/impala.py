@@ -184,7 +184,7 @@ class IMPALA(Algorithm):
         obs [N,C,H,W] (uint8 or float32), actions int64 [N], behaviour_logits f32 [N,A],
         rewards f32 [N], dones bool [N].  Returns (vtrace_loss, kl)."""
         vtrace_loss, kl = self._vtrace_loss(obs, actions, behaviour_logits, rewards, dones, entropy_coeff, time_major)
-        self.optimizer.zero_grad(set_to_none=True)
+        self._zero_grad()
         vtrace_loss.total_loss.backward()
         self._apply_gradients(learning_rate)
         return vtrace_loss, kl
@@ -195,7 +195,7 @@ class IMPALA(Algorithm):
         the sum of the per-batch gradients: each batch is forwarded / backpropagated on its own
         (accumulating into .grad), then clip + Adam run once.  Used by the multi-group actor
         pipeline, whose groups deliver their trajectories in separate buffers."""
-        self.optimizer.zero_grad(set_to_none=True)
+        self._zero_grad()
         out, kls = None, []
         for b in batches:
             loss, kl = self._vtrace_loss(b['obs'], b['actions'], b['behaviour_logits'], b['rewards'], b['dones'],

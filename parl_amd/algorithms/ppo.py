@@ -87,7 +87,7 @@ class PPO(Algorithm):
         if lr:
             for group in self.optimizer.param_groups:
                 group['lr'] = lr
-        self.optimizer.zero_grad()
+        self._zero_grad()
         loss.backward()
         if self.grad_hook is not None:
             self.grad_hook(self.model)

@@ -54,6 +54,16 @@ class Algorithm(object):
                     for k, m in ms.items():
                         m.set_weights(weights[key][k])
 
+    def _zero_grad(self):
+        """reset gradients before backward.  With a data-parallel grad_hook (parl_amd.dist.
+        FlatGradAllReduce) the gradients are views of its flat bucket: zero the bucket in place
+        instead of dropping the views."""
+        hook = getattr(self, 'grad_hook', None)
+        if hook is not None and hasattr(hook, 'zero_grad'):
+            hook.zero_grad()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+
     def learn(self, *args, **kwargs):
         raise NotImplementedError
 

@@ -698,7 +698,11 @@ __global__ __launch_bounds__(256) void gae_lookback_kernel(
     // all-ones pattern, so "A half != 0xffffffff" doubles as the ready flag — no separate flag, no
     // device-scope fence (on the 8-XCD part a release fence writes back the whole L2 of the XCD:
     // measured 290 us for this kernel with flags + __threadfence()).
-    const unsigned long long packed = (unsigned long long)__float_as_uint(Aprod) |
+    // a NaN whose bits are all ones (reachable from garbage float dones) would read as "never
+    // published" and hang the dependent workgroups: publish the canonical quiet NaN instead
+    unsigned abits = __float_as_uint(Aprod);
+    abits = abits == 0xffffffffu ? 0x7fc00000u : abits;
+    const unsigned long long packed = (unsigned long long)abits |
                                       ((unsigned long long)__float_as_uint(carry) << 32);
     __hip_atomic_store(ws + (int64_t)c * B + b, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }

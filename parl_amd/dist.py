@@ -14,12 +14,14 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend=None):
-    """Initialise from the torchrun env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+def init(backend=None, force=False):
+    """Initialise from the torchrun env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  A single
+    process creates no group unless force=True (one-rank RCCL group: tests, PARL_AMD_FORCE_DIST=1)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    force = force or bool(os.environ.get('PARL_AMD_FORCE_DIST'))
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             # PARL_AMD_DIST_BACKEND=gloo: test hook (e.g. two ranks sharing the one GPU of a test box)
             backend = os.environ.get('PARL_AMD_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
@@ -28,6 +30,7 @@ def init(backend=None):
         elif torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
@@ -36,18 +39,28 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def active():
+    """collectives run whenever a process group exists — also a one-rank group (a 1-GPU box
+    exercising RCCL itself); a plain single process never creates one"""
+    return dist.is_available() and dist.is_initialized()
+
+
 def broadcast_model(model, src=0):
     """init-time weight broadcast so every rank starts from rank 0's parameters"""
-    if world_size() == 1:
+    if not active():
         return
     for p in list(model.parameters()) + list(model.buffers()):
         dist.broadcast(p.data, src=src)
 
 
 class FlatGradAllReduce(object):
-    """grad_hook for IMPALA/A2C: one bucket = the whole model (4.0 MB / 10.9 MB fp32), one
-    all-reduce per update.  The flat buffer is allocated once; grads are views into it after the
-    first call, so no pack/unpack copies in steady state."""
+    """grad_hook for IMPALA/A2C/PPO: one bucket = the whole model (4.0 MB / 10.9 MB fp32), one
+    all-reduce per update.  The flat buffer is allocated once.  The algorithms call
+    `hook.zero_grad()` instead of `optimizer.zero_grad(set_to_none=True)` when a hook is installed:
+    it zeroes the flat buffer and makes every `p.grad` a view into it, so backward accumulates
+    straight into the bucket and there is no pack / unpack copy.  A gradient that is not a view
+    (someone reset `.grad`) is packed; a parameter without gradient on this rank contributes
+    zeros AND receives the reduced value, so every replica takes the same Adam step."""
 
     def __init__(self, model, average=False):
         # average=True: divide by the world size after the sum (PPO / any mean-reduced loss: the
@@ -62,12 +75,18 @@ class FlatGradAllReduce(object):
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
+    def zero_grad(self):
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
     def __call__(self, model=None):
-        if world_size() == 1:
+        if not active():
             return
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 v.zero_()
+                p.grad = v
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
                 p.grad = v
@@ -79,7 +98,7 @@ class FlatGradAllReduce(object):
 def all_gather_small(tensors):
     """All-gather a dict of small per-step tensors along a new leading rank dim."""
     w = world_size()
-    if w == 1:
+    if not active():
         return {k: v.unsqueeze(0) for k, v in tensors.items()}
     out = {}
     for k, v in tensors.items():
@@ -97,7 +116,7 @@ def all_gather_small(tensors):
 
 def all_reduce_max_scalar(x):
     """max over ranks of a python float (bench timing)"""
-    if world_size() == 1:
+    if not active():
         return x
     dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
     t = torch.tensor([x], dtype=torch.float64, device=dev)
@@ -106,5 +125,5 @@ def all_reduce_max_scalar(x):
 
 
 def barrier():
-    if world_size() > 1:
+    if active():
         dist.barrier()

@@ -197,6 +197,12 @@ class AsyncActorLearner(object):
         self.batch_ready = [[torch.cuda.Event(), torch.cuda.Event()] for _ in range(G)]
         self.batch_free = [torch.cuda.Event(), torch.cuda.Event()]
         self.pending = None  # ([batch per group], buffer index) collected but not yet learned
+        # data-parallel runs: all-gather the small per-step tensors of every learned batch on the
+        # LEARNER stream, right after the gradient all-reduce (one stream, one fixed order of
+        # collectives on every rank)
+        self.gather_small = False
+        self.gathered = None
+        self.step_done = torch.cuda.Event()  # recorded after every update on the learner stream
         self._src = [p for p in alg.model.parameters()] + [b for b in alg.model.buffers()]
         self._dst = [p for p in self.actor_model.parameters()] + [b for b in self.actor_model.buffers()]
         cur = torch.cuda.current_stream(dev)
@@ -247,7 +253,9 @@ class AsyncActorLearner(object):
 
     def step(self, learning_rate, entropy_coeff):
         """Enqueue one learner update on the previously collected batches and, concurrently, the
-        collection of the next ones.  Returns (vtrace_loss, kl) of the update (device tensors)."""
+        collection of the next ones.  Returns (vtrace_loss, kl) of the update: device tensors
+        produced on the LEARNER stream — before reading them from another stream call
+        `wait_outputs()` (or `synchronize()`)."""
         self.prime()
         batches, k = self.pending
         # the snapshot for the next rollout is taken first; the learner may not touch the
@@ -264,8 +272,13 @@ class AsyncActorLearner(object):
                                      learning_rate, entropy_coeff, time_major=True)
             else:
                 out = self.alg.learn_batches(batches, learning_rate, entropy_coeff, time_major=True)
+            if self.gather_small:  # per-step scalars of the batch just learned, for global statistics
+                from . import dist as pdist
+                self.gathered = [pdist.all_gather_small({'rewards': b['rewards'], 'dones': b['dones'].to(torch.uint8),
+                                                         'actions': b['actions']}) for b in batches]
             self.weights_ready.record(ls)
             self.batch_free[k].record(ls)
+            self.step_done.record(ls)
         for b in batches:
             for v in b.values():  # tensors made on an actor stream (e.g. dones.bool()), read on the learner's
                 v.record_stream(ls)
@@ -273,13 +286,25 @@ class AsyncActorLearner(object):
         return out
 
     def pop_episode_stats(self):
-        """(episodes closed, mean unclipped return, mean length) over all groups; syncs."""
+        """(episodes closed, mean unclipped return, mean length) over all groups.  The statistics
+        are accumulated on the actor streams: the caller's stream first waits for everything
+        enqueued there (so the counts are complete and the reset cannot race with an accumulation
+        in flight), and the actor streams wait for the reset before they accumulate again."""
+        cur = torch.cuda.current_stream(self.env.device)
+        for st in self.actor_streams:
+            cur.wait_stream(st)
         n = r = l = 0.0
         for ro in self.rollouts:
             gn, gr, gl = ro.pop_episode_stats()
             if gn:
                 n, r, l = n + gn, r + gr * gn, l + gl * gn
+        for st in self.actor_streams:
+            st.wait_stream(cur)
         return n, (r / n if n else None), (l / n if n else None)
+
+    def wait_outputs(self):
+        """make the caller's current stream wait for the last update's outputs (loss, kl, gathered)"""
+        torch.cuda.current_stream(self.env.device).wait_event(self.step_done)
 
     def synchronize(self):
         for st in self.actor_streams:

@@ -5,6 +5,9 @@ The reference functions take one (env, segment) at a time as Python lists on the
 drop-ins keep that contract (host in, float64 numpy out) by staging the segment as a [T,1] batch
 on the GPU — correct but latency-bound.  The batched device API is parl_amd.ops.gae /
 ops.discount_cumsum ([T,B] tensors), which is what the on-device A2C/PPO paths use.
+Precision: the kernels compute in float32 and the result is widened to float64; the reference is
+float64 end to end (rl_utils.py:49-50).  The two agree to 1e-5 (tests/test_gpu_scans.py, fixtures
+produced by the reference function) — nothing hot calls these shims.
 There is no CPU fallback: without the HIP library or a GPU these raise."""
 import numpy as np
 import torch
