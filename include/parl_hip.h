@@ -281,6 +281,20 @@ int parlhip_atari42_conv12_u8_f32(const uint8_t* obs, const float* w1, const flo
                                   const float* w2, const float* b2, float* out, int n_obs,
                                   parlhip_stream_t stream);
 
+/* The LEARNER's gradient of the same two layers (IMPALA.learn, parl/algorithms/paddle/impala/
+ * impala.py:148-149,205-215 backpropagates through AtariModel.policy / .value; the reference leaves
+ * it to the framework's conv backward): d loss / d (w1, b1, w2, b2) given the forward output
+ * a2 = relu(conv2(relu(conv1(obs/255)))) [n,3872] and dy = d loss / d a2 [n,3872].  conv1 is
+ * recomputed on the fly (bit-identical to the forward kernel), so no activation other than a2 is
+ * stored; per-workgroup partial sums go to `workspace` (parlhip_atari42_conv12_bwd_workspace_bytes)
+ * and are added in a fixed order: the result is deterministic.  Outputs are OVERWRITTEN:
+ * dw1 [16,64], db1 [16], dw2 [32,256], db2 [32].  The observations get no gradient.           */
+size_t parlhip_atari42_conv12_bwd_workspace_bytes(int n_obs);
+int parlhip_atari42_conv12_bwd_f32(const uint8_t* obs, const float* w1, const float* b1,
+                                   const float* w2, const float* a2, const float* dy, int n_obs,
+                                   float* workspace, float* dw1, float* db1, float* dw2, float* db2,
+                                   parlhip_stream_t stream);
+
 /* examples/A2C/atari_model.py:21-104 (AtariModel trunk), first layer — the 84x84 -> 20x20
  * contraction: x = obs / 255; conv1 4->32 k8 s4 p1 + ReLU.  obs u8 [n,4,84,84], w1 f32
  * [32,4,8,8], b1 [32] (nn.Conv2d layout), out f32 [n,32,20,20] (NCHW, the input of conv2).

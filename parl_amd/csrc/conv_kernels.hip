@@ -128,6 +128,215 @@ __global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
 
 
 // ----------------------------------------------------------------------------------------
+// Backward of the fused conv1 + conv2 for the LEARNER (IMPALA.learn, impala.py:148-215 runs
+// AtariModel.policy / .value under autograd; the gradient of the two convolutions w.r.t. their
+// weights and biases is what this kernel produces — the observations need no gradient).
+//
+// Inputs per observation: the uint8 stack (7,056 B), the forward output a2 = relu(conv2) and the
+// incoming gradient dY w.r.t. a2 (15,488 B each).  Nothing else crosses HBM: conv1 is recomputed
+// into LDS exactly as the forward kernel computes it (same operand order, bit-identical), so the
+// 28 KB / observation conv1 activation is never stored (1.44 GB per 51,200-observation update),
+// and no im2col / col2im matrix exists (the GEMM-lowered convolutions moved ~30 GB per update and
+// spent 19 ms in two split-K-less dW GEMMs with 16x64 / 32x256 outputs).
+//
+// One workgroup (4 waves) per observation, grid-stride; four implicit GEMMs on the f32 matrix
+// cores per observation, gradients accumulated in registers over all observations of the workgroup:
+//   (1) conv1 forward (recompute)                [441 x 64] x [64 x 16]
+//   (2) dW2[o][k] += sum_p dz2[o][p] patch2[p][k]   [32 x 121] x [121 x 256], dz2 = dY * (a2 > 0)
+//   (3) dA1 = transposed conv of dz2 with w2, as a GATHER per output parity class (stride 2,
+//       kernel 4: a conv1 output (y, x) receives from the 2 x 2 conv2 outputs (iy+1-a, ix+1-b)
+//       through taps (py+2a, px+2b)); one class per wave: [<=121 x 128] x [128 x 16];
+//       dz1 = dA1 * (a1 > 0) overwrites a1 in place in LDS
+//   (4) dW1[c][k] += sum_p dz1[c][p] patch1[p][k]   [16 x 441] x [441 x 64]
+// Bias gradients are the row sums of dz2 / dz1, accumulated per lane on the way.  Every workgroup
+// writes its partial sums; conv12_bwd_reduce_kernel adds them in a fixed order (deterministic).
+// ----------------------------------------------------------------------------------------
+constexpr int kZ2W = 13, kZ2H = 12, kZ2 = kZ2H * kZ2W;   // dz2, zero-padded: row 11 / columns 11-12 stay zero
+constexpr int kBwdDW1 = 0, kBwdDB1 = 1024, kBwdDW2 = 1040, kBwdDB2 = 1040 + 8192;
+constexpr int kBwdPartial = 1040 + 8192 + 32;            // 9264 floats per workgroup
+constexpr int kLdsBwdFloats = kLdsIn + kLdsC1 + 32 * kZ2 + 384;  // 23,120 floats = 92,480 B
+
+__global__ __launch_bounds__(256) void conv12_bwd_u8_mfma_kernel(
+    const uint8_t* __restrict__ obs, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ a2, const float* __restrict__ dy,
+    float* __restrict__ partial, int n_obs) {
+  extern __shared__ float lds[];
+  float* in_pad = lds;                  // [4][44][44]
+  float* c1_pad = in_pad + kLdsIn;      // [16][25][25]: a1, then dz1 in place
+  float* dz2p = c1_pad + kLdsC1;        // [32][12][13]
+  float* red = dz2p + 32 * kZ2;         // [384] bias-gradient staging
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, col = lane & 15;
+  float bw1[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) bw1[ks] = w1[col * kK1 + ks * 4 + q];
+  const float bias1 = b1[col];
+  // (3): this wave's parity class and its B operand  B[k = (o, a, b)][n = c] = w2[o][c][py+2a][px+2b]
+  const int py = wave >> 1, px = wave & 1, ta = q >> 1, tb = q & 1;
+  float bt[32];
+#pragma unroll
+  for (int o = 0; o < 32; ++o) bt[o] = w2[o * kK2 + col * 16 + (py + 2 * ta) * 4 + (px + 2 * tb)];
+  f32x4 acc2[2][4], acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc2[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float db2a0 = 0.f, db2a1 = 0.f, db1a = 0.f;
+  for (int i = tid; i < kLdsBwdFloats; i += 256) lds[i] = 0.0f;
+  const int kh = col >> 2, kw = col & 3;   // tap of this lane's k column in (2) and (4)
+  for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
+    __syncthreads();
+    // ---- obs u8 -> padded float input, exactly as the forward kernel ----
+    const uint8_t* src = obs + (size_t)n * 4 * kD * kD;
+    if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+      const uint32_t* src32 = reinterpret_cast<const uint32_t*>(src);
+      for (int wi = tid; wi < kD * kD; wi += 256) {
+        const uint32_t v = src32[wi];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = wi * 4 + j;
+          const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
+          in_pad[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = (float)((v >> (8 * j)) & 255u) / 255.0f;
+        }
+      }
+    } else {
+      for (int i = tid; i < 4 * kD * kD; i += 256) {
+        const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
+        in_pad[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = (float)src[i] / 255.0f;
+      }
+    }
+    // ---- dz2 = dY * (a2 > 0) -> zero-padded LDS tile ----
+    const float* a2n = a2 + (size_t)n * kC2 * kM2;
+    const float* dyn = dy + (size_t)n * kC2 * kM2;
+    for (int i = tid; i < kC2 * kM2; i += 256) {
+      const int o = i / kM2, p = i - o * kM2, oy = p / kO2, ox = p - oy * kO2;
+      dz2p[o * kZ2 + oy * kZ2W + ox] = a2n[i] > 0.f ? dyn[i] : 0.f;
+    }
+    __syncthreads();
+    // ---- (1) conv1 forward into c1_pad (identical to conv12_u8_mfma_kernel) ----
+    for (int t = wave; t < 28; t += 4) {
+      int m = t * 16 + col;
+      m = m < kM1 ? m : kM1 - 1;
+      const int oy = m / kO1, ox = m - oy * kO1;
+      const float* a_base = in_pad + (2 * oy) * kP1 + 2 * ox + q;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const float a = a_base[(ks >> 2) * kP1 * kP1 + (ks & 3) * kP1];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw1[ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mo = t * 16 + q * 4 + r;
+        if (mo < kM1) {
+          const int y = mo / kO1, x = mo - y * kO1;
+          const float v = acc[r] + bias1;
+          c1_pad[col * kP2 * kP2 + (y + 2) * kP2 + (x + 2)] = v > 0.f ? v : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (2) dW2: this wave owns input channels 4*wave .. 4*wave+3 (k tiles), both o tiles ----
+    for (int ps = 0; ps < 31; ++ps) {
+      const int p = ps * 4 + q;
+      const bool valid = p < kM2;
+      const int pc = valid ? p : kM2 - 1;
+      const int oy = pc / kO2, ox = pc - oy * kO2;
+      const int zoff = valid ? oy * kZ2W + ox : 11 * kZ2W;   // row 11 of the padded tile is zero
+      const float a0 = dz2p[col * kZ2 + zoff], a1v = dz2p[(16 + col) * kZ2 + zoff];
+      db2a0 += a0;
+      db2a1 += a1v;
+      const float* bb = c1_pad + (4 * wave) * kP2 * kP2 + (2 * oy + kh) * kP2 + 2 * ox + kw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float b = bb[j * kP2 * kP2];
+        acc2[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc2[0][j], 0, 0, 0);
+        acc2[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, b, acc2[1][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();   // all patch2 gathers done before dz1 overwrites a1
+    // ---- (3) dz1 for this wave's parity class, in place over a1 ----
+    {
+      const int ny = kO2 - py, nx = kO2 - px, M = ny * nx;   // y = 2*iy + py < 21, x = 2*ix + px < 21
+      for (int t = 0; t * 16 < M; ++t) {
+        int m = t * 16 + col;
+        m = m < M ? m : M - 1;
+        const int iy = m / nx, ix = m - iy * nx;
+        const float* ab = dz2p + (iy + 1 - ta) * kZ2W + (ix + 1 - tb);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 32; ++o) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[o * kZ2], bt[o], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mo = t * 16 + q * 4 + r;
+          if (mo < M) {
+            const int jy = mo / nx, jx = mo - jy * nx;
+            float* pz = c1_pad + col * kP2 * kP2 + (2 * jy + py + 2) * kP2 + (2 * jx + px + 2);
+            const float v = *pz > 0.f ? acc[r] : 0.f;
+            *pz = v;
+            db1a += v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (4) dW1: this wave owns input channel `wave` (16 taps = one k tile) ----
+    for (int ps = 0; ps < 111; ++ps) {
+      const int p = ps * 4 + q;
+      const bool valid = p < kM1;
+      const int pc = valid ? p : kM1 - 1;
+      const int y = pc / kO1, x = pc - y * kO1;
+      const float a = c1_pad[col * kP2 * kP2 + (valid ? (y + 2) * kP2 + (x + 2) : 0)];   // [0][0] is border: 0
+      const float b = in_pad[wave * kP1 * kP1 + (2 * y + kh) * kP1 + 2 * x + kw];
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc1, 0, 0, 0);
+    }
+  }
+  // ---- this workgroup's partial sums ----
+  float* P = partial + (size_t)blockIdx.x * kBwdPartial;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) P[kBwdDW1 + (4 * q + r) * kK1 + 16 * wave + col] = acc1[r];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        P[kBwdDW2 + (16 * t + 4 * q + r) * kK2 + 16 * (4 * wave + j) + col] = acc2[t][j][r];
+  // bias gradients: per-lane partial row sums -> LDS -> fixed-order sums (deterministic)
+  __syncthreads();
+  red[tid] = db1a;                         // [wave][q][col]: db1[c = col] = sum over (wave, q)
+  if (wave == 0) {                         // every wave saw the same dz2 rows; take wave 0's sums
+    red[256 + q * 16 + col] = db2a0;       // [q][col]: db2[o = col]      = sum over q
+    red[256 + 64 + q * 16 + col] = db2a1;  //           db2[o = 16 + col]
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += red[i * 16 + tid];
+    P[kBwdDB1 + tid] = s;
+  } else if (tid < 48) {
+    const int o = tid - 16;                // 0..31
+    const float* r = red + 256 + (o >> 4) * 64 + (o & 15);
+    P[kBwdDB2 + o] = r[0] + r[16] + r[32] + r[48];
+  }
+}
+
+// fixed-order sum of the per-workgroup partials -> dW1 [16,64], db1 [16], dW2 [32,256], db2 [32]
+__global__ __launch_bounds__(256) void conv12_bwd_reduce_kernel(const float* __restrict__ partial, int n_parts,
+                                                                float* __restrict__ dw1, float* __restrict__ db1,
+                                                                float* __restrict__ dw2, float* __restrict__ db2) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= kBwdPartial) return;
+  float s = 0.f;
+  for (int g = 0; g < n_parts; ++g) s += partial[(size_t)g * kBwdPartial + j];
+  if (j < kBwdDB1) dw1[j] = s;
+  else if (j < kBwdDW2) db1[j - kBwdDB1] = s;
+  else if (j < kBwdDB2) dw2[j - kBwdDW2] = s;
+  else db2[j - kBwdDB2] = s;
+}
+
+
+// ----------------------------------------------------------------------------------------
 // conv1 of the A2C Atari network (the 84x84 -> 20x20 contraction) on the f32 matrix cores.
 //
 // Reference: examples/A2C/atari_model.py:21-104 (AtariModel): obs / 255, conv1 4->32 k8 s4 p1
@@ -259,5 +468,42 @@ PARLHIP_EXPORT int parlhip_atari84_conv1_u8_f32(const uint8_t* obs, const float*
   }
   const int grid = n_obs < kNumCU ? n_obs : kNumCU;  // 113 KB of LDS: one workgroup per CU
   conv1_84_u8_mfma_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(obs, w1, b1, out, n_obs);
+  return check_launch();
+}
+
+static int conv12_bwd_grid(int n_obs) { return n_obs < kNumCU ? n_obs : kNumCU; }  // 92 KB of LDS: one per CU
+
+PARLHIP_EXPORT size_t parlhip_atari42_conv12_bwd_workspace_bytes(int n_obs) {
+  return n_obs <= 0 ? 0 : (size_t)conv12_bwd_grid(n_obs) * kBwdPartial * sizeof(float);
+}
+
+PARLHIP_EXPORT int parlhip_atari42_conv12_bwd_f32(const uint8_t* obs, const float* w1, const float* b1,
+                                                  const float* w2, const float* a2, const float* dy, int n_obs,
+                                                  float* workspace, float* dw1, float* db1, float* dw2, float* db2,
+                                                  parlhip_stream_t stream) {
+  if (n_obs < 0) return PARLHIP_EINVAL;
+  if (!dw1 || !db1 || !dw2 || !db2) return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (n_obs == 0) {
+    int rc = check(hipMemsetAsync(dw1, 0, 1024 * 4, s));
+    if (!rc) rc = check(hipMemsetAsync(db1, 0, 16 * 4, s));
+    if (!rc) rc = check(hipMemsetAsync(dw2, 0, 8192 * 4, s));
+    if (!rc) rc = check(hipMemsetAsync(db2, 0, 32 * 4, s));
+    return rc;
+  }
+  if (!obs || !w1 || !b1 || !w2 || !a2 || !dy || !workspace) return PARLHIP_EINVAL;
+  static bool attr_set = false;
+  const size_t lds_bytes = kLdsBwdFloats * sizeof(float);
+  if (!attr_set) {
+    int rc = check(hipFuncSetAttribute((const void*)conv12_bwd_u8_mfma_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int grid = conv12_bwd_grid(n_obs);
+  conv12_bwd_u8_mfma_kernel<<<grid, 256, lds_bytes, s>>>(obs, w1, b1, w2, a2, dy, workspace, n_obs);
+  int rc = check_launch();
+  if (rc) return rc;
+  conv12_bwd_reduce_kernel<<<(kBwdPartial + 255) / 256, 256, 0, s>>>(workspace, grid, dw1, db1, dw2, db2);
   return check_launch();
 }

@@ -65,6 +65,12 @@ class AtariModel42(Model):
             # observations (ops.atari42_conv12), conv3 is a 3872 -> 256 linear layer
             h = ops.atari42_conv12(obs, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
             return F.relu(F.linear(h, self.conv3.weight.flatten(1), self.conv3.bias))
+        if obs.dtype == torch.uint8 and obs.is_cuda and obs.shape[0] > 0:
+            # the learner's path: the same fused forward kernel under autograd, its backward is ONE
+            # kernel that recomputes conv1 and produces the four parameter gradients (no im2col, no
+            # stored conv1 activation); conv3 = a 3872 -> 256 linear layer = plain rocBLAS GEMMs
+            h = ops.Atari42Conv12Fn.apply(obs, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
+            return F.relu(F.linear(h, self.conv3.weight.flatten(1), self.conv3.bias))
         x = obs.float() / 255.0
         x = F.relu(self.conv1(x))
         x = F.relu(self.conv2(x))

@@ -288,6 +288,50 @@ def atari42_conv12(obs, conv1_weight, conv1_bias, conv2_weight, conv2_bias, out=
     return out
 
 
+def atari42_conv12_backward(obs, conv1_weight, conv1_bias, conv2_weight, a2, grad_a2):
+    """Gradient of atari42_conv12 w.r.t. its four parameters given its output a2 [n,3872] and
+    d loss / d a2 (the learner side of examples/IMPALA/atari_model.py:59-71; the observations get
+    no gradient).  conv1 is recomputed inside the kernel; deterministic.  Returns
+    (d conv1_weight [16,4,4,4], d conv1_bias [16], d conv2_weight [32,16,4,4], d conv2_bias [32])."""
+    if obs.dtype != torch.uint8 or obs.dim() != 4 or tuple(obs.shape[1:]) != (4, 42, 42):
+        raise N.ParlHipError('atari42_conv12_backward: obs must be uint8 [n,4,42,42]')
+    n = obs.shape[0]
+    a2, grad_a2 = _f32(a2, 'a2'), _f32(grad_a2.contiguous(), 'grad_a2')
+    if a2.numel() != n * 3872 or grad_a2.numel() != n * 3872:
+        raise N.ParlHipError('atari42_conv12_backward: a2 / grad_a2 must be [n,3872]')
+    dev = obs.device
+    dw1 = torch.empty((16, 4, 4, 4), dtype=torch.float32, device=dev)
+    db1 = torch.empty(16, dtype=torch.float32, device=dev)
+    dw2 = torch.empty((32, 16, 4, 4), dtype=torch.float32, device=dev)
+    db2 = torch.empty(32, dtype=torch.float32, device=dev)
+    nb = N.lib().parlhip_atari42_conv12_bwd_workspace_bytes(n)
+    ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=dev)
+    w1, b1 = _f32(conv1_weight.detach(), 'conv1_weight'), _f32(conv1_bias.detach(), 'conv1_bias')
+    w2 = _f32(conv2_weight.detach(), 'conv2_weight')
+    N.check(
+        N.lib().parlhip_atari42_conv12_bwd_f32(N.ptr(obs.contiguous()), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(a2),
+                                              N.ptr(grad_a2), n, N.ptr(ws), N.ptr(dw1), N.ptr(db1), N.ptr(dw2),
+                                              N.ptr(db2), N.stream_ptr()), 'parlhip_atari42_conv12_bwd_f32')
+    return dw1, db1, dw2, db2
+
+
+class Atari42Conv12Fn(torch.autograd.Function):
+    """autograd node: forward = the fused conv1 + conv2 MFMA kernel on uint8 observations,
+    backward = atari42_conv12_backward (one kernel + a fixed-order reduction)."""
+
+    @staticmethod
+    def forward(ctx, obs, w1, b1, w2, b2):
+        a2 = atari42_conv12(obs, w1, b1, w2, b2)
+        ctx.save_for_backward(obs, w1, b1, w2, a2)
+        return a2
+
+    @staticmethod
+    def backward(ctx, grad_a2):
+        obs, w1, b1, w2, a2 = ctx.saved_tensors
+        dw1, db1, dw2, db2 = atari42_conv12_backward(obs, w1, b1, w2, a2, grad_a2)
+        return None, dw1, db1, dw2, db2
+
+
 def atari84_conv1(obs, conv1_weight, conv1_bias, out=None):
     """conv1 + ReLU of the A2C Atari network (examples/A2C/atari_model.py:21-104: 4->32 k8 s4 p1,
     84x84 -> 20x20) for uint8 observations [n,4,84,84] as one MFMA kernel with the /255 fused
