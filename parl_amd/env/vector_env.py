@@ -1,0 +1,63 @@
+"""parl.env.vector_env.VectorEnv with the reference's contract (parl/env/vector_env.py:26-63):
+`VectorEnv(envs)`, `reset() -> [obs]`, `step(actions) -> ([obs], [reward], [done], [info])` with
+auto-reset, lists of numpy arrays / Python scalars on the HOST — for scripts written against the
+reference (benchmark/torch/a2c/actor.py:30-101, examples/IMPALA/actor.py:29-91).  The envs are the
+handles `wrap_deepmind(gym.make(id), dim, obs_format)` returns; they all run in ONE DeviceVectorEnv
+(one kernel launch per step for the whole list).  Every step costs a device-to-host copy of the
+observations; the device-native loop (parl_amd.rollout) has none — this class is the drop-in
+boundary, not the fast path."""
+import itertools
+
+import numpy as np
+import torch
+
+from .atari_wrappers import WrappedDeviceAtariEnv
+from .device_vector_env import DeviceVectorEnv
+
+__all__ = ['VectorEnv']
+
+_next_env_id = itertools.count()  # distinct RNG streams (noop counts) for every env of the process
+
+
+class VectorEnv(object):
+    def __init__(self, envs, seed=0, device=None):
+        if not envs or not all(isinstance(e, WrappedDeviceAtariEnv) for e in envs):
+            raise TypeError('VectorEnv: expected a list of envs made by wrap_deepmind(gym.make(...)) of the device path')
+        first = envs[0]
+        if any((e.env_id, e.dim, e.obs_format) != (first.env_id, first.dim, first.obs_format) for e in envs):
+            raise ValueError('VectorEnv: all envs must share env id, dim and obs_format')
+        self.envs = envs
+        self.envs_num = len(envs)
+        id0 = next(_next_env_id)
+        for _ in range(self.envs_num - 1):
+            next(_next_env_id)
+        self.dev_env = DeviceVectorEnv(first.env_id, self.envs_num, dim=first.dim, horizon=64, seed=seed,
+                                       env_id0=id0, device=device)
+        self._nhwc = first.obs_format == 'NHWC'
+
+    def _obs_list(self, obs):
+        a = obs.cpu().numpy()
+        if self._nhwc:
+            a = a.transpose(0, 2, 3, 1)
+        return list(a)
+
+    def reset(self):
+        """vector_env.py:34-39"""
+        return self._obs_list(self.dev_env.reset())
+
+    def step(self, actions):
+        """vector_env.py:41-63 (the obs returned for a done env is its reset obs)"""
+        a = torch.as_tensor(np.asarray(actions).reshape(-1), dtype=torch.int64, device=self.dev_env.device)
+        obs, rew, done, info = self.dev_env.step(a)
+        ret = info['episode_returns'].cpu().numpy()
+        ln = info['episode_lengths'].cpu().numpy()
+        infos = []
+        for i, e in enumerate(self.envs):
+            if ln[i] > 0:  # MonitorEnv closed an episode of env i in this step
+                e.monitor._push(ret[i], ln[i])
+                infos.append({'episode': {'r': float(ret[i]), 'l': int(ln[i])}})
+            else:
+                infos.append({})
+        self.dev_env.check_faults()
+        return (self._obs_list(obs), [float(x) for x in rew.cpu().numpy()], [bool(x) for x in done.cpu().numpy()],
+                infos)

@@ -1,9 +1,13 @@
 """Device Atari env (HIP emulator + wrapper state machine + frame_post + frame-stack ring, through
 the C ABI) against the CPU oracle: bit-exact RAM, raw frames, observations, rewards, dones and
 MonitorEnv episode records.  Needs a real MI355X: -m gpu."""
+import os
+
 import numpy as np
 import pytest
 import torch
+
+from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -144,3 +148,50 @@ def test_translated_cartridge_equals_interpreter(dev, game):
         assert torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(oa, ob), 'step %d' % i
     a_env.check_faults()
     b_env.check_faults()
+
+
+def test_reference_style_vector_env_on_device(dev, oracle):
+    """The drop-in host API of the reference scripts on the real kernels:
+    gym.make -> wrap_deepmind(dim, obs_format) -> VectorEnv(envs).reset()/step() with the
+    reference's return types (lists of numpy obs / floats / bools / info dicts,
+    parl/env/vector_env.py:34-63), bit-exact against the oracle's chain, and MonitorEnv statistics
+    through get_wrapper_by_cls (benchmark/torch/a2c/actor.py:110-119)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'compat'))
+    try:
+        for m in ('gym', 'parl'):
+            sys.modules.pop(m, None)
+        import gym
+        import parl
+        from parl.env.atari_wrappers import wrap_deepmind, MonitorEnv, get_wrapper_by_cls
+        from parl.env.vector_env import VectorEnv
+        import parl_amd
+        assert parl is parl_amd
+        E = 3
+        envs = [wrap_deepmind(gym.make('BreakoutNoFrameskip-v4'), dim=84, obs_format='NCHW') for _ in range(E)]
+        assert envs[0].observation_space.shape == (4, 84, 84) and envs[0].action_space.n == 4
+        with pytest.raises(RuntimeError):
+            envs[0].reset()
+        vec = VectorEnv(envs)
+        id0 = vec.dev_env.env_id0
+        orc = oracle.VecEnv(_rom('breakout'), 'breakout', E, 84, seed=0, env_id0=id0)
+        obs = vec.reset()
+        assert isinstance(obs, list) and len(obs) == E and obs[0].shape == (4, 84, 84) and obs[0].dtype == np.uint8
+        assert np.array_equal(np.stack(obs), orc.reset())
+        rng = np.random.default_rng(0)
+        n_eps = 0
+        for t in range(400):
+            a = rng.integers(0, 4, E)
+            obs, rew, done, info = vec.step(a)
+            oo, orr, od = orc.step(a)
+            assert np.array_equal(np.stack(obs), oo) and rew == [float(x) for x in orr] and done == [bool(x) for x in od]
+            assert all(isinstance(r, float) for r in rew) and all(isinstance(d, bool) for d in done)
+            for e in range(E):
+                exp = orc.pop_episodes(e)
+                got = list(get_wrapper_by_cls(envs[e], MonitorEnv).next_episode_results())
+                assert got == [(float(r), int(n)) for r, n in exp]
+                n_eps += len(got)
+                assert ('episode' in info[e]) == bool(exp)
+        assert n_eps >= 1
+    finally:
+        sys.path.remove(os.path.join(ROOT, 'compat'))
