@@ -117,6 +117,152 @@ def cpu_baseline(game, dim, seconds_target=12.0):
     }
 
 
+def _event_time(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2] * 1e-3
+
+
+def extra_legs(dev):
+    """Short runs of the other BASELINE.json configs on ONE GPU (each leg: its own envs / model,
+    1 warm-up + a few timed iterations, wall-clock with synchronize on both sides; frames = emulated
+    2600 frames of agent steps).  They ride on the headline's JSON line under their own keys and
+    never touch `value`."""
+    from parl_amd.rollout import DeviceA2CRollout
+    out = {}
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:  # a leg must never take the headline down
+            out[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    # ---- configs[1]: Pong A2C, 256 on-GPU envs, 84x84, T=20, lambda=1 (examples/A2C/a2c_config.py) ----
+    def a2c_c2():
+        E, T, K = 256, 20, 5
+        env = DeviceVectorEnv('PongNoFrameskip-v4', E, dim=84, horizon=T, seed=7, device=dev)
+        model = AtariModel84(env.act_dim).to(dev)
+        alg = parl.algorithms.A2C(model, vf_loss_coeff=0.5)
+        ro = DeviceA2CRollout(env, T, gamma=0.99, lam=1.0, seed=3)
+        lr_s = parl.utils.LinearDecayScheduler(0.001, int(1e7))
+
+        def step():
+            b = ro.collect(model)
+            return alg.learn(b['obs'], b['actions'], b['advantages'], b['target_values'], lr_s.step(T * E), -0.01)
+
+        step()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(K):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        assert np.isfinite(float(loss[0]))
+        env.check_faults()
+        rew, val = torch.randn((T, E), device=dev), torch.randn((T, E), device=dev)
+        dn = torch.rand((T, E), device=dev) < 1 / 800
+        nv = torch.randn(E, device=dev)
+        g = _event_time(lambda: ops.gae(rew, val, dn, nv, 0.99, 1.0))
+        by = T * E * 17
+        return {'workload': 'BASELINE configs[1]: PongNoFrameskip-v4 A2C, 256 on-GPU envs, 84x84, T=20, lambda=1.0; '
+                            'rollout then update (synchronous A2C), learner convs GEMM-lowered',
+                'env_frames_per_s': K * T * E * 4 / dt, 'updates_per_s': K / dt, 'ms_per_step': dt / K * 1e3, 'steps': K,
+                'gae_kernel': {'shape': 'T=20 B=256 u8 dones', 'us': g * 1e6, 'bytes': by, 'GBps': by / g / 1e9,
+                               'frac_of_hbm_peak': by / g / 1e9 / HBM_PEAK_GBPS,
+                               'note': '87 KB: launch-latency-bound by construction (SURVEY 8d)'}}
+
+    # ---- IMPALA at 84x84 (the north-star frame size), 1024 envs, T=50 ----
+    def impala_84():
+        E, T, K, CH = 1024, 50, 2, 8
+        env = DeviceVectorEnv('PongNoFrameskip-v4', E, dim=84, horizon=T, seed=8, device=dev)
+        model = AtariModel84(env.act_dim).to(dev)
+        alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
+                                     clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+        ro = DeviceRollout(env, T, seed=4)
+        Ec = E // CH
+
+        def step():
+            b = ro.collect(model)
+            chunks = []
+            for c in range(CH):  # the learner batch in env chunks: the GEMM-lowered 84x84 convs need ~2 MB per row
+                sl = slice(c * Ec, (c + 1) * Ec)
+                v = lambda t: t.reshape((T, E) + tuple(t.shape[1:]))[:, sl].reshape((T * Ec, ) + tuple(t.shape[1:]))  # noqa: E731
+                chunks.append({k: v(b[k]) for k in ('obs', 'actions', 'behaviour_logits', 'rewards', 'dones')})
+            return alg.learn_batches(chunks, 0.001, -0.01, time_major=True)
+
+        step()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(K):
+            loss, kl = step()
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        assert np.isfinite(float(loss.total_loss))
+        env.check_faults()
+        return {'workload': 'PongNoFrameskip-v4 IMPALA V-trace at 84x84, 1024 actors, T=50; rollout then ONE update on '
+                            'the 51,200-row batch (8 env chunks accumulated), no actor/learner overlap, learner convs '
+                            'GEMM-lowered (the fused MFMA learner path exists for the 42x42 model only)',
+                'env_frames_per_s': K * T * E * 4 / dt, 'updates_per_s': K / dt, 'ms_per_step': dt / K * 1e3, 'steps': K}
+
+    # ---- configs[3] per GPU: Breakout IMPALA, 1024 of the 8192 actors, A=4 ----
+    def breakout_c4():
+        E, T, K = 1024, 50, 3
+        env = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=42, horizon=T, seed=9, device=dev)
+        model = AtariModel42(env.act_dim).to(dev)
+        alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
+                                     clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+        pipe = AsyncActorLearner(alg, [env], T, seed=5)
+        pipe.prime()
+        pipe.step(0.001, -0.01)
+        pipe.synchronize()
+        t0 = time.time()
+        for _ in range(K):
+            loss, kl = pipe.step(0.001, -0.01)
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        assert np.isfinite(float(loss.total_loss))
+        env.check_faults()
+        return {'workload': 'BASELINE configs[3], one GPU\'s share: BreakoutNoFrameskip-v4 IMPALA, 1024 of 8192 actors, '
+                            'A=4, 42x42, T=50, actor/learner overlapped',
+                'env_frames_per_s': K * T * E * 4 / dt, 'updates_per_s': K / dt, 'ms_per_step': dt / K * 1e3, 'steps': K}
+
+    # ---- configs[4]: the PPO scans at HalfCheetah shapes (T=2048, E=4096; minibatch 262,144) ----
+    def ppo_c5_scans():
+        T, E = 2048, 4096
+        rew, val = torch.randn((T, E), device=dev).clamp_(-10, 10), torch.randn((T, E), device=dev)
+        dn = (torch.rand((T, E), device=dev) < 1e-3).float()
+        nv, ld = torch.randn(E, device=dev), torch.zeros(E, device=dev)
+        g = _event_time(lambda: ops.gae(rew, val, dn, nv, 0.99, 0.95, last_done=ld, done_convention=1))
+        by = T * E * 20
+        adv = torch.randn(T * E, device=dev)
+        idx = torch.randperm(T * E, device=dev)[:262144]
+        a = _event_time(lambda: ops.adv_normalize(adv, idx))
+        aby = 262144 * (8 + 4 + 4 + 4)  # index read, gathered read (twice), write
+        return {'workload': 'BASELINE configs[4] shapes: RolloutStorage.compute_returns at T=2048 x E=4096 (f32 dones, '
+                            '20 B/elt) and the per-minibatch advantage normalisation on 262,144 gathered elements',
+                'gae_kernel': {'kernel': 'gae_lookback_kernel (single pass, 32-step chunks)', 'us': g * 1e6, 'bytes': by,
+                               'GBps': by / g / 1e9, 'frac_of_hbm_peak': by / g / 1e9 / HBM_PEAK_GBPS,
+                               'traffic_key': 'profiles/r01e_scan_hbm_traffic.json:gae_T2048_B4096_f32'},
+                'adv_normalize_kernel': {'us': a * 1e6, 'bytes': aby, 'GBps': aby / a / 1e9}}
+
+    guarded('a2c_c2', a2c_c2)
+    guarded('impala_84', impala_84)
+    guarded('breakout_c4_per_gpu', breakout_c4)
+    guarded('ppo_c5_scans', ppo_c5_scans)
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without torchrun: start the N ranks ourselves, exactly as the
     driver would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
@@ -291,7 +437,7 @@ def main():
         }
         out['roofline'].update(pmc_traffic(('impala_loss' if fused else 'vtrace_logits') + '_T%d_B%d_A%d' % (T, Eg, A)))
         # --- the same scan family at the saturating shape (T'=127, B=262,144: 932 MB) ---
-        Ts, Bs = 127, 262144
+        Ts, Bs = (127, 262144) if not args.quick else (127, 8192)
         x = [torch.randn((Ts, Bs), device=dev) for _ in range(5)]
         boot = torch.randn(Bs, device=dev)
         sat = KernelTimer()
@@ -304,8 +450,9 @@ def main():
         torch.cuda.synchronize()
         bys = Ts * Bs * 28 + 4 * Bs
         out['roofline_saturating'] = {
-            'kernel': 'vtrace_tm_kernel (from log-probs, lane per sequence, T=127 B=262144: the saturating shape '
-                      'of SURVEY 8d)', 'bound': 'hbm',
+            'kernel': 'vtrace_tm_kernel (from log-probs, lane per sequence, T=%d B=%d%s)' %
+                      (Ts, Bs, ': the saturating shape of SURVEY 8d' if not args.quick else ' (--quick: reduced shape)'),
+            'bound': 'hbm',
             'achieved': bys / sat.mean_seconds() / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
             'frac': bys / sat.mean_seconds() / 1e9 / HBM_PEAK_GBPS, 'bytes_per_launch': bys,
         }
@@ -339,6 +486,12 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.game, dim)
+            from oracle import py_baselines  # measurement infrastructure (numpy ports pinned on reference fixtures)
+            out['cpu_baseline']['scan_kernels'] = py_baselines.time_scan_baselines()
+        if world == 1 and not args.quick:
+            del pipe, rollout, envs, env, model, alg  # free the headline's buffers before the extra legs
+            torch.cuda.empty_cache()
+            out.update(extra_legs(dev))
         print(json.dumps(out))
 
 

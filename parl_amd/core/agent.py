@@ -29,19 +29,43 @@ class Agent(object):
     def sample(self, *args, **kwargs):
         raise NotImplementedError
 
+    def attach(self, **stateful):
+        """Register objects with state_dict() / load_state_dict() (DeviceVectorEnv, DeviceRollout,
+        DeviceA2CRollout, ...) whose state is checkpointed next to the model: with actors resident
+        on the GPU the envs and the sampling RNG live in this process, and a model-only
+        checkpoint (all the reference needs, its actors being separate processes) could not
+        resume a run.  SURVEY 8 f4."""
+        if not hasattr(self, '_stateful'):
+            self._stateful = {}
+        for k, v in stateful.items():
+            assert hasattr(v, 'state_dict') and hasattr(v, 'load_state_dict'), k
+            self._stateful[k] = v
+
     def save(self, save_path, model=None):
-        """torch.save(model.state_dict()) (core/torch/agent.py:100-124)"""
+        """torch.save(model.state_dict()) exactly as core/torch/agent.py:100-124 (the file is
+        interchangeable with the reference's); attached env / sampler state goes to
+        `save_path + '.env'`."""
         if model is None:
             model = self.alg.model
         dirname = os.sep.join(save_path.split(os.sep)[:-1])
         if dirname != '' and not os.path.exists(dirname):
             os.makedirs(dirname)
         torch.save(model.state_dict(), save_path)
+        extra = getattr(self, '_stateful', None)
+        if extra:
+            torch.save({k: v.state_dict() for k, v in extra.items()}, save_path + '.env')
 
     def restore(self, save_path, model=None, map_location=None):
         if model is None:
             model = self.alg.model
         model.load_state_dict(torch.load(save_path, map_location=map_location))
+        extra = getattr(self, '_stateful', None)
+        if extra and os.path.exists(save_path + '.env'):
+            blob = torch.load(save_path + '.env', map_location='cpu', weights_only=False)
+            for k, v in extra.items():
+                if k not in blob:
+                    raise KeyError('%s.env holds no state for %r' % (save_path, k))
+                v.load_state_dict(blob[k])
 
     def train(self):
         self.alg.model.train()

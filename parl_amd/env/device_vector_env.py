@@ -190,6 +190,33 @@ class DeviceVectorEnv(object):
         info = {'episode_returns': self.ep_returns, 'episode_lengths': self.ep_lengths}
         return self.current_obs(), self.rewards, self.dones.bool(), info
 
+    # ---------------------------------------------------------------- checkpoint
+    _STATE_TENSORS = ('states', 'raw_frames', 'ring', 'since', 'rewards', 'dones', 'obs_flags', 'ep_returns',
+                      'ep_lengths', 'jam')
+
+    def state_dict(self):
+        """Everything that determines the future of the envs: the per-env machine + wrapper state
+        blobs (6507 / TIA / RIOT, ALE paddle, lives, noop / reset counters = the Philox offsets of
+        the reset stream), the raw frame pair MaxAndSkip still needs, the frame-stack ring with its
+        `since` counters and the ring position.  Host tensors; pairs with Agent.save
+        (parl/core/torch/agent.py:100-124 saves the model only — a GPU-resident env has no other
+        way to survive a restart)."""
+        d = {k: getattr(self, k).detach().cpu().clone() for k in self._STATE_TENSORS}
+        d['meta'] = {'env_name': self.env_name, 'envs_num': self.envs_num, 'dim': self.dim, 'horizon': self.horizon,
+                     'seed': self.seed, 'env_id0': self.env_id0, 'max_episode_steps': self.max_episode_steps,
+                     't': self.t}
+        return d
+
+    def load_state_dict(self, d):
+        m = d['meta']
+        for k in ('env_name', 'envs_num', 'dim', 'horizon', 'seed', 'env_id0', 'max_episode_steps'):
+            if m[k] != getattr(self, k):
+                raise ValueError('DeviceVectorEnv.load_state_dict: %s is %r here but %r in the checkpoint' %
+                                 (k, getattr(self, k), m[k]))
+        for k in self._STATE_TENSORS:
+            getattr(self, k).copy_(d[k].to(self.device))
+        self.t = int(m['t'])
+
     def check_faults(self):
         """Raise if any env hit an emulator fault (undocumented opcode, ...). Synchronises."""
         j = int(self.jam.item())

@@ -93,6 +93,20 @@ class DeviceRollout(object):
             self.collect_step(model, t)
         return self.collect_end()
 
+    def state_dict(self):
+        """the sampler's own state: the Philox offset (one uniform per global step and env), the
+        buffer cursor, the episode statistics not yet popped.  The env is saved separately."""
+        return {'step_count': self.step_count, 'started': self.started, 'cur': self._cur, 'seed': self.seed,
+                'ep_stats': self.ep_stats.detach().cpu().clone()}
+
+    def load_state_dict(self, d):
+        if d['seed'] != self.seed:
+            raise ValueError('rollout seed %r differs from the checkpoint (%r)' % (self.seed, d['seed']))
+        self.step_count, self.started, self._cur = int(d['step_count']), bool(d['started']), int(d['cur'])
+        if self._cur >= 0:
+            self._select(self._cur)
+        self.ep_stats.copy_(d['ep_stats'].to(self.ep_stats.device))
+
     def pop_episode_stats(self):
         """(episodes closed, mean unclipped return, mean length in emulated frames); syncs."""
         n, r, l = (float(x) for x in self.ep_stats.tolist())
@@ -153,6 +167,16 @@ class DeviceA2CRollout(object):
                 'target_values': target.reshape(n)}
 
     pop_episode_stats = DeviceRollout.pop_episode_stats
+
+    def state_dict(self):
+        return {'step_count': self.step_count, 'started': self.started, 'seed': self.seed,
+                'ep_stats': self.ep_stats.detach().cpu().clone()}
+
+    def load_state_dict(self, d):
+        if d['seed'] != self.seed:
+            raise ValueError('rollout seed %r differs from the checkpoint (%r)' % (self.seed, d['seed']))
+        self.step_count, self.started = int(d['step_count']), bool(d['started'])
+        self.ep_stats.copy_(d['ep_stats'].to(self.ep_stats.device))
 
 
 class AsyncActorLearner(object):

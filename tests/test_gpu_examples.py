@@ -183,3 +183,49 @@ def test_ppo_example_continuous_runs():
     out = _run(['examples/PPO/train.py', '--continuous_action', '--env_num', '64', '--step_nums', '64',
                 '--train_total_steps', '8192'])
     assert "'action_loss': " in out and "'update': 2" in out
+
+
+def test_env_and_sampler_checkpoint_resumes_bit_identically(dev, tmp_path):
+    """Agent.save with the env and the sampler attached, 20 more steps, Agent.restore,
+    the same 20 steps again: observations, actions, rewards, dones identical — env state blobs,
+    frame ring, `since`, reset counters and the Philox offsets all come back.  Breakout, so that
+    life losses / FIRE resets / noop draws happen inside the window."""
+    import parl_amd as parl
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel42
+    from parl_amd.rollout import DeviceRollout
+    torch.manual_seed(0)
+    E, T = 24, 20
+    env = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=42, horizon=T, seed=11, device=dev)
+    model = AtariModel42(env.act_dim).to(dev)
+    alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
+                                 clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+
+    class A(parl.Agent):
+        pass
+
+    agent = A(alg)
+    ro = DeviceRollout(env, T, seed=5)
+    agent.attach(env=env, rollout=ro)
+    for _ in range(4):  # get into the game
+        ro.collect(model)
+    path = str(tmp_path / 'ckpt' / 'model.ckpt')
+    agent.save(path)
+    assert os.path.exists(path) and os.path.exists(path + '.env')
+
+    def run():
+        b = ro.collect(model)
+        return [b[k].clone() for k in ('obs', 'actions', 'rewards', 'dones', 'behaviour_logits')]
+
+    first = run()
+    second_without_restore = run()
+    assert not torch.equal(first[0], second_without_restore[0])
+    agent.restore(path)
+    again = run()
+    for a, b in zip(first, again):
+        assert torch.equal(a, b)
+    assert int(first[3].sum()) > 0  # dones (life losses) inside the window
+    # a different env cannot swallow the checkpoint
+    other = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=42, horizon=T, seed=12, device=dev)
+    with pytest.raises(ValueError):
+        other.load_state_dict(env.state_dict())

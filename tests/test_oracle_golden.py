@@ -185,3 +185,28 @@ def test_ppo_sample_batch_oracle(oracle, case):
     out = oracle.ppo_sample_batch(ring['obs'], ring['actions'], ring['logprobs'], adv, ret, ring['values'], g['idx'])
     for o, k in zip(out, ['obs', 'actions', 'logprobs', 'advantages', 'returns', 'values']):
         assert np.array_equal(o.reshape(g['batch_' + k].shape), g['batch_' + k]), k
+
+
+# ---- the numpy CPU baselines bench.py times (oracle/py_baselines.py) are pinned on the same fixtures ----
+def test_py_baselines_match_reference_fixtures():
+    from oracle import py_baselines as pb
+    z = load_golden('calc_gae.npz')
+    for case in ('a2c_T20_B6_lam1', 'a2c_T20_B6_lam95'):
+        c = {k.split('/', 1)[1]: v for k, v in z.items() if k.startswith(case + '/')}
+        adv = pb.calc_gae_segments(c['rewards'], c['values'], c['dones'].astype(bool), c['next_value'], 0.99,
+                                   float(c['lam']))
+        np.testing.assert_allclose(adv, c['advantages'], rtol=1e-6, atol=1e-6)
+    z = load_golden('ppo_compute_returns.npz')
+    for case in ('T16_E8', 'T64_E5'):
+        c = {k.split('/', 1)[1]: v for k, v in z.items() if k.startswith(case + '/')}
+        g, lam = c['gamma_lam']
+        adv, ret = pb.compute_returns(c['rewards'], c['values'], c['dones'], c['value'], c['done'], float(g), float(lam))
+        assert np.array_equal(adv, c['advantages']) and np.array_equal(ret, c['returns'])
+    z = load_golden('vtrace_known_answer.npz')
+    for case in ('ref_B1', 'ref_B4'):
+        c = {k.split('/', 1)[1]: v for k, v in z.items() if k.startswith(case + '/')}
+        vs, pg = pb.vtrace_numpy(c['behaviour_actions_log_probs'], c['target_actions_log_probs'], c['discounts'],
+                                 c['rewards'], c['values'], c['bootstrap_value'], float(c['clip_rho_threshold']),
+                                 float(c['clip_pg_rho_threshold']))
+        np.testing.assert_allclose(vs, c['vs'], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(pg, c['pg_advantages'], rtol=1e-5, atol=1e-5)
