@@ -196,9 +196,13 @@ class Cart(object):
                 pre, dc = ['const int m = e.ram_rd(0x%02x);' % (b1 & 0x7f)], 3
             elif mode in (M_ZPX, M_ZPY):
                 idx = 'e.X' if mode == M_ZPX else 'e.Y'
-                pre = ['const int ea = (0x%02x + %s) & 0xff;' % (b1, idx),
-                       'if (!(ea & 0x80)) { --n; e.PC = 0x%04x; return; }' % a, 'const int m = e.ram_rd(ea & 0x7f);']
-                dc = 4
+                # RAM, or an input port (INPTx: does not depend on the picture; Breakout polls `LDA $38,X`
+                # on every line of its kernel); collision latches go to the interpreter
+                pre = ['const int ea = (0x%02x + %s) & 0xff;' % (b1, idx), 'int dc = 4, m;',
+                       'if (ea & 0x80) m = e.ram_rd(ea & 0x7f);',
+                       'else if ((ea & 0x0f) >= 8) { e.cyc += 4; dc = 0; m = e.tia_read(ea, 0x%02x); }' % b1,
+                       'else { --n; e.PC = 0x%04x; return; }' % a]
+                dc = None
             elif mode == M_ABS:
                 ea = b1 | (b2 << 8)
                 dc = 4
@@ -245,8 +249,18 @@ class Cart(object):
                     'int m;', 'if (ea & 0x1000) m = e.rom_byte(ea);',
                     'else if ((ea & 0x280) == 0x80) m = e.ram_rd(ea & 0x7f);', 'else { --n; e.PC = 0x%04x; return; }' % a
                 ]
+            elif mode == M_PULL and op == 'PLA':
+                # pull from a stack in RAM (a pull from TIA space reads collision latches: interpreter)
+                # ... or from an input-port address in TIA space (Breakout pulls from $1F inside its
+                # kernel: the read returns the bus noise = the next opcode byte and needs no picture)
+                pre = ['const int s1 = (e.S + 1) & 0xff;', 'int dc = 4, m;',
+                       'if (s1 & 0x80) m = e.ram_rd(s1 & 0x7f);',
+                       'else if ((s1 & 0x0f) >= 8) { e.cyc += 4; dc = 0; m = e.tia_read(s1, 0x%02x); }' % b1,
+                       'else { --n; e.PC = 0x%04x; return; }' % a, 'e.S = s1;']
+                dc = None
+                op = 'LDA'
             else:
-                return fb  # (zp,X), PLA / PLP
+                return fb  # (zp,X), PLP
             L += pre
             L.append(self.emit_read_op(op))
             if dc is None:
@@ -288,7 +302,34 @@ class Cart(object):
             if op == 'JMP':
                 tgt = b1 | (b2 << 8)
                 return ['e.cyc += 3;', 'if (__builtin_expect(n > kNativeInstrLimit, 0)) { e.PC = 0x%04x; return; }' % tgt, self.goto(tgt)]
-            return fb  # JSR / RTS / RTI / BRK / JMP () / JAM
+            # ---- subroutine linkage with the stack in RAM (cycle totals as in Emu::step; no bus access
+            # in between that could observe the intermediate cycles).  RTS / RTI have a run-time target:
+            # they set PC and return with pend = -2 ("dispatch again, nothing to interpret"); an
+            # in-function `goto` back to the dispatch switch made the object 4.5x larger and the
+            # compile 20x slower (the switch becomes a loop header inside a 2000-block function).  With the stack pointer in TIA
+            # space (Breakout's `LDX #$1F; TXS` kernel trick) the interpreter does it.
+            if op == 'JSR':
+                tgt, ret = b1 | (b2 << 8), (a + 2) & 0xffff
+                return ['if (__builtin_expect(e.S < 0x81, 0)) { --n; e.PC = 0x%04x; return; }' % a,
+                        'e.ram_wr(e.S & 0x7f, 0x%02x); e.ram_wr((e.S - 1) & 0x7f, 0x%02x); e.S = (e.S - 2) & 0xff;' %
+                        (ret >> 8, ret & 0xff), 'e.cyc += 6;',
+                        'if (__builtin_expect(n > kNativeInstrLimit, 0)) { e.PC = 0x%04x; return; }' % tgt, self.goto(tgt)]
+            if op == 'RTS':
+                return ['if (__builtin_expect(e.S < 0x7f || e.S > 0xfd, 0)) { --n; e.PC = 0x%04x; return; }' % a,
+                        'e.PC = ((e.ram_rd((e.S + 1) & 0x7f) | (e.ram_rd((e.S + 2) & 0x7f) << 8)) + 1) & 0xffff;',
+                        'e.S = (e.S + 2) & 0xff; e.cyc += 6;', 'e.pend = -2; return;']
+            if op == 'RTI':
+                return ['if (__builtin_expect(e.S < 0x7f || e.S > 0xfc, 0)) { --n; e.PC = 0x%04x; return; }' % a,
+                        'e.pset((e.ram_rd((e.S + 1) & 0x7f) & ~FB) | FU);',
+                        'e.PC = e.ram_rd((e.S + 2) & 0x7f) | (e.ram_rd((e.S + 3) & 0x7f) << 8);',
+                        'e.S = (e.S + 3) & 0xff; e.cyc += 6;', 'e.pend = -2; return;']
+            if op == 'BRK':
+                ret, vec = (a + 2) & 0xffff, self.word(0xfffe)
+                return ['if (__builtin_expect(e.S < 0x82, 0)) { --n; e.PC = 0x%04x; return; }' % a,
+                        'e.ram_wr(e.S & 0x7f, 0x%02x); e.ram_wr((e.S - 1) & 0x7f, 0x%02x);' % (ret >> 8, ret & 0xff),
+                        'e.ram_wr((e.S - 2) & 0x7f, e.pfull() | FB | FU); e.S = (e.S - 3) & 0xff; e.P |= FI; e.cyc += 7;',
+                        'if (__builtin_expect(n > kNativeInstrLimit, 0)) { e.PC = 0x%04x; return; }' % vec, self.goto(vec)]
+            return fb  # JMP () / JAM
         # ---- stores and read-modify-writes (zero-page class only, as in step_fast) ----
         if mode == M_ZP:
             ea, dc, static = '0x%02x' % b1, 3, b1
@@ -313,6 +354,10 @@ class Cart(object):
                 reg = static & 0x3f
                 if reg == 0x02:  # WSYNC
                     return ['e.wsync(e.cyc + %d);' % dc]
+                # (measured: handling playfield changes INSIDE the translated code — Emu::pf_store_fast, a
+                # per-lane select on the `tia` / `pfe` VGPRs — made those VGPRs live across all ~2000
+                # blocks: compile 1 -> 14 min, Pong 1.2 -> 9.0 ms per step.  The translated code stays
+                # scalar-only; real playfield changes go through `pend` like every other real change.)
                 return ['if (__builtin_expect(!e.tia_store_is_nop(0x%02x, %s), 0)) %s' % (reg, val, pend % ('0x%02x' % static)),
                         'e.cyc += %d;' % dc]
             return [

@@ -135,6 +135,7 @@ static void frame_translated(Atari* a, uint8_t* fb, long* native_instr, long* de
     native_run<GAME>(e, n);
     e.store();
     *native_instr += n - n0;
+    if (e.pend == -2) continue;   // translated RTS / RTI: PC set, dispatch again (Emu::frame)
     if (e.pend < 0 && n >= kMaxInstrPerFrame) break;
     if (e.pend >= 0) host_wr(a, (uint16_t)(e.pend & 0xff), (uint8_t)(e.pend >> 8));   // Emu::step, pending path
     else host_cpu_step(a);
