@@ -154,17 +154,22 @@ __global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
 constexpr int kZ2W = 13, kZ2H = 12, kZ2 = kZ2H * kZ2W;   // dz2, zero-padded: row 11 / columns 11-12 stay zero
 constexpr int kBwdDW1 = 0, kBwdDB1 = 1024, kBwdDW2 = 1040, kBwdDB2 = 1040 + 8192;
 constexpr int kBwdPartial = 1040 + 8192 + 32;            // 9264 floats per workgroup
-constexpr int kLdsBwdFloats = kLdsIn + kLdsC1 + 32 * kZ2 + 384;  // 23,120 floats = 92,480 B
+// LDS: the observation stays uint8 (zero-padded [4][44][44] = 7,744 B) next to a 256-entry table of
+// (float)u / 255.0f — the forward kernel's exact operand values — so the workgroup needs 69 KB instead
+// of 92: two workgroups per CU, and the actors' conv12 kernel (71 KB) can share the CU.
+constexpr int kLdsBwdU8 = 4 * kP1 * kP1;                                   // 7,744 bytes = 1,936 floats
+constexpr int kLdsBwdFloats = kLdsBwdU8 / 4 + 256 + kLdsC1 + 32 * kZ2 + 384;  // 17,568 floats = 70,272 B
 
-__global__ __launch_bounds__(256) void conv12_bwd_u8_mfma_kernel(
+__global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
     const uint8_t* __restrict__ obs, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ a2, const float* __restrict__ dy,
     float* __restrict__ partial, int n_obs) {
   extern __shared__ float lds[];
-  float* in_pad = lds;                  // [4][44][44]
-  float* c1_pad = in_pad + kLdsIn;      // [16][25][25]: a1, then dz1 in place
-  float* dz2p = c1_pad + kLdsC1;        // [32][12][13]
-  float* red = dz2p + 32 * kZ2;         // [384] bias-gradient staging
+  uint8_t* in_u8 = reinterpret_cast<uint8_t*>(lds);   // [4][44][44] uint8, zero-padded
+  float* lut = lds + kLdsBwdU8 / 4;                   // [256] (float)u / 255.0f
+  float* c1_pad = lut + 256;                          // [16][25][25]: a1, then dz1 in place
+  float* dz2p = c1_pad + kLdsC1;                      // [32][12][13]
+  float* red = dz2p + 32 * kZ2;                       // [384] bias-gradient staging
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, col = lane & 15;
   float bw1[16];
@@ -183,10 +188,13 @@ __global__ __launch_bounds__(256) void conv12_bwd_u8_mfma_kernel(
     for (int j = 0; j < 4; ++j) acc2[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float db2a0 = 0.f, db2a1 = 0.f, db1a = 0.f;
   for (int i = tid; i < kLdsBwdFloats; i += 256) lds[i] = 0.0f;
+  __syncthreads();
+  lut[tid] = (float)tid / 255.0f;
   const int kh = col >> 2, kw = col & 3;   // tap of this lane's k column in (2) and (4)
+#pragma unroll 1
   for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
     __syncthreads();
-    // ---- obs u8 -> padded float input, exactly as the forward kernel ----
+    // ---- obs u8 -> zero-padded u8 tile ----
     const uint8_t* src = obs + (size_t)n * 4 * kD * kD;
     if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {
       const uint32_t* src32 = reinterpret_cast<const uint32_t*>(src);
@@ -196,13 +204,13 @@ __global__ __launch_bounds__(256) void conv12_bwd_u8_mfma_kernel(
         for (int j = 0; j < 4; ++j) {
           const int i = wi * 4 + j;
           const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
-          in_pad[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = (float)((v >> (8 * j)) & 255u) / 255.0f;
+          in_u8[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = (uint8_t)(v >> (8 * j));
         }
       }
     } else {
       for (int i = tid; i < 4 * kD * kD; i += 256) {
         const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
-        in_pad[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = (float)src[i] / 255.0f;
+        in_u8[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = src[i];
       }
     }
     // ---- dz2 = dY * (a2 > 0) -> zero-padded LDS tile ----
@@ -213,16 +221,17 @@ __global__ __launch_bounds__(256) void conv12_bwd_u8_mfma_kernel(
       dz2p[o * kZ2 + oy * kZ2W + ox] = a2n[i] > 0.f ? dyn[i] : 0.f;
     }
     __syncthreads();
-    // ---- (1) conv1 forward into c1_pad (identical to conv12_u8_mfma_kernel) ----
+    // ---- (1) conv1 forward into c1_pad (operand values and order of conv12_u8_mfma_kernel) ----
+#pragma unroll 1
     for (int t = wave; t < 28; t += 4) {
       int m = t * 16 + col;
       m = m < kM1 ? m : kM1 - 1;
       const int oy = m / kO1, ox = m - oy * kO1;
-      const float* a_base = in_pad + (2 * oy) * kP1 + 2 * ox + q;
+      const uint8_t* a_base = in_u8 + (2 * oy) * kP1 + 2 * ox + q;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        const float a = a_base[(ks >> 2) * kP1 * kP1 + (ks & 3) * kP1];
+        const float a = lut[a_base[(ks >> 2) * kP1 * kP1 + (ks & 3) * kP1]];
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw1[ks], acc, 0, 0, 0);
       }
 #pragma unroll
@@ -237,27 +246,38 @@ __global__ __launch_bounds__(256) void conv12_bwd_u8_mfma_kernel(
     }
     __syncthreads();
     // ---- (2) dW2: this wave owns input channels 4*wave .. 4*wave+3 (k tiles), both o tiles ----
-    for (int ps = 0; ps < 31; ++ps) {
-      const int p = ps * 4 + q;
-      const bool valid = p < kM2;
-      const int pc = valid ? p : kM2 - 1;
-      const int oy = pc / kO2, ox = pc - oy * kO2;
-      const int zoff = valid ? oy * kZ2W + ox : 11 * kZ2W;   // row 11 of the padded tile is zero
-      const float a0 = dz2p[col * kZ2 + zoff], a1v = dz2p[(16 + col) * kZ2 + zoff];
-      db2a0 += a0;
-      db2a1 += a1v;
-      const float* bb = c1_pad + (4 * wave) * kP2 * kP2 + (2 * oy + kh) * kP2 + 2 * ox + kw;
+    // position p = 4*ps + q walks the 11 x 11 outputs; offsets advance incrementally (no divides).
+    // The loop stays ROLLED: unrolled (even by 2) the scheduler hoists the LDS gathers of all
+    // iterations, needs > 256 VGPRs + scratch and the kernel runs 8.0 instead of 5.4 ms.
+    {
+      int ox = q, zoff = q;                                   // oy = 0
+      int boff = (4 * wave) * kP2 * kP2 + kh * kP2 + 2 * q + kw;   // c1_pad[(4w)][2*oy + kh][2*ox + kw]
+#pragma clang loop unroll(disable)
+      for (int ps = 0; ps < 31; ++ps) {
+        const bool valid = (ps < 30) | (q == 0);              // p < 121
+        const int zo = valid ? zoff : 11 * kZ2W;              // row 11 of the padded tile is zero
+        const float a0 = dz2p[col * kZ2 + zo], a1v = dz2p[(16 + col) * kZ2 + zo];
+        db2a0 += a0;
+        db2a1 += a1v;
+        const float* bb = c1_pad + (valid ? boff : 0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float b = bb[j * kP2 * kP2];
-        acc2[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc2[0][j], 0, 0, 0);
-        acc2[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, b, acc2[1][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          const float b = bb[j * kP2 * kP2];
+          acc2[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc2[0][j], 0, 0, 0);
+          acc2[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, b, acc2[1][j], 0, 0, 0);
+        }
+        ox += 4;
+        const bool wrap = ox >= kO2;
+        ox -= wrap ? kO2 : 0;
+        zoff += wrap ? 4 + (kZ2W - kO2) : 4;                  // next row of the 13-wide tile
+        boff += wrap ? 8 + (2 * kP2 - 2 * kO2) : 8;           // two rows down, 22 columns back
       }
     }
     __syncthreads();   // all patch2 gathers done before dz1 overwrites a1
     // ---- (3) dz1 for this wave's parity class, in place over a1 ----
     {
       const int ny = kO2 - py, nx = kO2 - px, M = ny * nx;   // y = 2*iy + py < 21, x = 2*ix + px < 21
+#pragma unroll 1
       for (int t = 0; t * 16 < M; ++t) {
         int m = t * 16 + col;
         m = m < M ? m : M - 1;
@@ -281,14 +301,22 @@ __global__ __launch_bounds__(256) void conv12_bwd_u8_mfma_kernel(
     }
     __syncthreads();
     // ---- (4) dW1: this wave owns input channel `wave` (16 taps = one k tile) ----
-    for (int ps = 0; ps < 111; ++ps) {
-      const int p = ps * 4 + q;
-      const bool valid = p < kM1;
-      const int pc = valid ? p : kM1 - 1;
-      const int y = pc / kO1, x = pc - y * kO1;
-      const float a = c1_pad[col * kP2 * kP2 + (valid ? (y + 2) * kP2 + (x + 2) : 0)];   // [0][0] is border: 0
-      const float b = in_pad[wave * kP1 * kP1 + (2 * y + kh) * kP1 + 2 * x + kw];
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc1, 0, 0, 0);
+    {
+      int x = q;                                              // y = 0
+      int aoff = col * kP2 * kP2 + 2 * kP2 + 2 + q;           // c1_pad[col][y + 2][x + 2]
+      int boff = wave * kP1 * kP1 + kh * kP1 + 2 * q + kw;    // in_u8[wave][2*y + kh][2*x + kw]
+#pragma clang loop unroll(disable)
+      for (int ps = 0; ps < 111; ++ps) {
+        const bool valid = (ps < 110) | (q == 0);             // p < 441
+        const float a = c1_pad[valid ? aoff : col * kP2 * kP2];   // [col][0][0] is border: 0
+        const float b = lut[in_u8[valid ? boff : 0]];
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc1, 0, 0, 0);
+        x += 4;
+        const bool wrap = x >= kO1;
+        x -= wrap ? kO1 : 0;
+        aoff += wrap ? 4 + (kP2 - kO1) : 4;
+        boff += wrap ? 8 + (2 * kP1 - 2 * kO1) : 8;
+      }
     }
   }
   // ---- this workgroup's partial sums ----
@@ -471,7 +499,7 @@ PARLHIP_EXPORT int parlhip_atari84_conv1_u8_f32(const uint8_t* obs, const float*
   return check_launch();
 }
 
-static int conv12_bwd_grid(int n_obs) { return n_obs < kNumCU ? n_obs : kNumCU; }  // 92 KB of LDS: one per CU
+static int conv12_bwd_grid(int n_obs) { return n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU; }  // 69 KB of LDS: two per CU
 
 PARLHIP_EXPORT size_t parlhip_atari42_conv12_bwd_workspace_bytes(int n_obs) {
   return n_obs <= 0 ? 0 : (size_t)conv12_bwd_grid(n_obs) * kBwdPartial * sizeof(float);
