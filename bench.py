@@ -183,34 +183,26 @@ def extra_legs(dev):
 
     # ---- IMPALA at 84x84 (the north-star frame size), 1024 envs, T=50 ----
     def impala_84():
-        E, T, K, CH = 1024, 50, 2, 8
+        E, T, K = 1024, 50, 2
         env = DeviceVectorEnv('PongNoFrameskip-v4', E, dim=84, horizon=T, seed=8, device=dev)
         model = AtariModel84(env.act_dim).to(dev)
         alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
                                      clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
-        ro = DeviceRollout(env, T, seed=4)
-        Ec = E // CH
-
-        def step():
-            b = ro.collect(model)
-            chunks = []
-            for c in range(CH):  # the learner batch in env chunks: the GEMM-lowered 84x84 convs need ~2 MB per row
-                sl = slice(c * Ec, (c + 1) * Ec)
-                v = lambda t: t.reshape((T, E) + tuple(t.shape[1:]))[:, sl].reshape((T * Ec, ) + tuple(t.shape[1:]))  # noqa: E731
-                chunks.append({k: v(b[k]) for k in ('obs', 'actions', 'behaviour_logits', 'rewards', 'dones')})
-            return alg.learn_batches(chunks, 0.001, -0.01, time_major=True)
-
-        step()
-        torch.cuda.synchronize()
+        alg.max_learn_rows = 6400  # the GEMM-lowered 84x84 convs need ~2 MB of im2col per row
+        pipe = AsyncActorLearner(alg, [env], T, seed=4)
+        pipe.prime()
+        pipe.step(0.001, -0.01)
+        pipe.synchronize()
         t0 = time.time()
         for _ in range(K):
-            loss, kl = step()
+            loss, kl = pipe.step(0.001, -0.01)
+        pipe.synchronize()
         torch.cuda.synchronize()
         dt = time.time() - t0
         assert np.isfinite(float(loss.total_loss))
         env.check_faults()
-        return {'workload': 'PongNoFrameskip-v4 IMPALA V-trace at 84x84, 1024 actors, T=50; rollout then ONE update on '
-                            'the 51,200-row batch (8 env chunks accumulated), no actor/learner overlap, learner convs '
+        return {'workload': 'PongNoFrameskip-v4 IMPALA V-trace at 84x84, 1024 actors, T=50, actor/learner overlapped; ONE '
+                            'update per step on the 51,200-row batch (8 chunks of 128 sequences accumulated), learner convs '
                             'GEMM-lowered (the fused MFMA learner path exists for the 42x42 model only)',
                 'env_frames_per_s': K * T * E * 4 / dt, 'updates_per_s': K / dt, 'ms_per_step': dt / K * 1e3, 'steps': K}
 

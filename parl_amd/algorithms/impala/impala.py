@@ -124,6 +124,9 @@ class IMPALA(Algorithm):
         # one-kernel loss + gradient (ops.impala_loss); False keeps the autograd graph of the
         # reference formulas on top of the fused V-trace (the parity tests compare the two)
         self.fused_loss = True
+        # rows per forward / backward pass of learn() (None: the whole batch at once).  Models whose
+        # convolutions are GEMM-lowered (the 84x84 network) need ~2 MB of im2col per row.
+        self.max_learn_rows = None
 
     def _heads(self, obs):
         if hasattr(self.model, 'policy_and_value'):
@@ -183,6 +186,23 @@ class IMPALA(Algorithm):
 
         obs [N,C,H,W] (uint8 or float32), actions int64 [N], behaviour_logits f32 [N,A],
         rewards f32 [N], dones bool [N].  Returns (vtrace_loss, kl)."""
+        T = self.sample_batch_steps
+        N = obs.shape[0]
+        if self.max_learn_rows and N > self.max_learn_rows and N // T > 1:
+            # bounded-memory update: the batch in chunks of whole sequences, gradients accumulated
+            # (the losses are sums over rows, impala.py:67-79), ONE clip + Adam step
+            B = N // T
+            per = max(1, self.max_learn_rows // T)
+            chunks = []
+            for b0 in range(0, B, per):
+                b1 = min(B, b0 + per)
+                if time_major:
+                    cut = lambda t: t.reshape((T, B) + tuple(t.shape[1:]))[:, b0:b1].reshape((T * (b1 - b0), ) + tuple(t.shape[1:]))  # noqa: E731
+                else:
+                    cut = lambda t: t[b0 * T:b1 * T]  # noqa: E731
+                chunks.append({'obs': cut(obs), 'actions': cut(actions), 'behaviour_logits': cut(behaviour_logits),
+                               'rewards': cut(rewards), 'dones': cut(dones)})
+            return self.learn_batches(chunks, learning_rate, entropy_coeff, time_major=time_major)
         vtrace_loss, kl = self._vtrace_loss(obs, actions, behaviour_logits, rewards, dones, entropy_coeff, time_major)
         self._zero_grad()
         vtrace_loss.total_loss.backward()

@@ -354,3 +354,33 @@ def test_impala_learn_fused_equals_unfused(dev):
                                    rtol=1e-6, atol=1e-6)
         for p1, p2 in zip(m1.parameters(), m2.parameters()):
             np.testing.assert_allclose(p1.detach().cpu().numpy(), p2.detach().cpu().numpy(), rtol=1e-3, atol=2e-5)
+
+
+def test_impala_learn_in_row_chunks_equals_one_pass(dev):
+    """IMPALA.max_learn_rows: the update accumulated over chunks of whole sequences == the one-pass
+    update (losses are sums, impala.py:67-79), both layouts."""
+    import copy
+    import parl_amd as parl
+    from parl_amd.models import AtariModel42
+    torch.manual_seed(0)
+    T, B, A = 10, 12, 6
+    base = AtariModel42(A).to(dev)
+    obs = torch.randint(0, 256, (T * B, 4, 42, 42), dtype=torch.uint8, device=dev)
+    act = torch.randint(0, A, (T * B, ), device=dev)
+    bl = torch.randn((T * B, A), device=dev)
+    rew = torch.randn(T * B, device=dev)
+    dn = torch.rand(T * B, device=dev) < 0.05
+    for tm in (True, False):
+        outs = []
+        for rows in (None, 3 * T):
+            m = copy.deepcopy(base)
+            alg = parl.algorithms.IMPALA(m, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
+                                         clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+            alg.max_learn_rows = rows
+            loss, kl = alg.learn(obs, act, bl, rew, dn, 1e-3, -0.01, time_major=tm)
+            # the (clipped) gradients the Adam step consumed; Adam's first step is lr * sign-like, so the
+            # parameters themselves amplify rounding differences of tiny gradients
+            outs.append((float(loss.total_loss.detach()), [p.grad.detach().clone() for p in m.parameters()]))
+        assert abs(outs[0][0] - outs[1][0]) <= 1e-4 * abs(outs[0][0])
+        for a, b in zip(outs[0][1], outs[1][1]):
+            assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-7
