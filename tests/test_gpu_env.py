@@ -195,3 +195,34 @@ def test_reference_style_vector_env_on_device(dev, oracle):
         assert n_eps >= 1
     finally:
         sys.path.remove(os.path.join(ROOT, 'compat'))
+
+
+@pytest.mark.parametrize('game,steps', [('pong', 80), ('breakout', 260)])
+def test_full_size_vector_matches_oracle_on_a_subset_of_envs(dev, oracle, game, steps):
+    """BASELINE configs[2] / [3] size: 1024 envs per GPU at 42x42.  The oracle cannot step 1024 envs
+    in seconds, but envs are independent (state, actions, Philox stream keyed by the global env id),
+    so single-env oracles for a spread of ids — first / last wave of a workgroup, workgroup and XCD
+    boundaries, the last env — fed that env's actions must reproduce its observations, rewards and
+    dones bit for bit, including Breakout's life-loss reset chains."""
+    from parl_amd.env import DeviceVectorEnv
+    rom = _rom(game)
+    E, dim, seed = 1024, 42, 21
+    ids = [0, 1, 3, 4, 255, 256, 511, 512, 777, 1023]
+    env = DeviceVectorEnv(GAMES[game], E, dim=dim, horizon=8, seed=seed, device=dev, rom_bytes=rom)
+    orcs = [oracle.VecEnv(rom, game, 1, dim, seed=seed, env_id0=i) for i in ids]
+    obs = env.reset().cpu().numpy()
+    for i, o in zip(ids, orcs):
+        assert np.array_equal(obs[i], o.reset()[0]), 'reset env %d' % i
+    g = torch.Generator().manual_seed(1)
+    ndone = 0
+    for t in range(steps):
+        a = torch.randint(0, env.act_dim, (E, ), generator=g)
+        ob, rew, done, _ = env.step(a.to(dev))
+        ob, rew, done = ob.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        for i, o in zip(ids, orcs):
+            oo, orr, od = o.step(a[i:i + 1].numpy())
+            assert np.array_equal(ob[i], oo[0]) and rew[i] == orr[0] and bool(done[i]) == bool(od[0]), (t, i)
+            ndone += int(od[0])
+    env.check_faults()
+    if game == 'breakout':
+        assert ndone >= 3  # life losses inside the window
