@@ -30,6 +30,12 @@ import zlib
 # tools/cart_profile.py maps the compiled ISA back to 6507 addresses)
 MARKERS = bool(os.environ.get('PARLHIP_CART_MARKERS'))
 
+# Cartridges whose real playfield changes are queued by the translated code (Emu::pf_enqueue) instead
+# of handed over one by one.  Measured on MI355X, E=1024: Breakout (211 playfield changes per frame,
+# six per line in the brick band) 2.69 -> 2.11 ms per agent step; Pong (49 per frame) 1.25 -> 1.33 ms —
+# the enqueue code in the blocks of its scanline loop costs more than the hand-overs it saves.
+PF_QUEUE_GAMES = ('breakout', )
+
 # ---- mirrors atari_defs.hpp (decode_opcode) ------------------------------------------------------
 M_IMP, M_IMM, M_ZP, M_ZPX, M_ZPY, M_ABS, M_ABX, M_ABY, M_IZX, M_IZY, M_REL, M_PUSH, M_PULL = range(13)
 K_NONE, K_READ, K_WRITE, K_RMW = range(4)
@@ -354,10 +360,15 @@ class Cart(object):
                 reg = static & 0x3f
                 if reg == 0x02:  # WSYNC
                     return ['e.wsync(e.cyc + %d);' % dc]
-                # (measured: handling playfield changes INSIDE the translated code — Emu::pf_store_fast, a
-                # per-lane select on the `tia` / `pfe` VGPRs — made those VGPRs live across all ~2000
-                # blocks: compile 1 -> 14 min, Pong 1.2 -> 9.0 ms per step.  The translated code stays
-                # scalar-only; real playfield changes go through `pend` like every other real change.)
+                if 0x0d <= reg <= 0x0f and self.name in PF_QUEUE_GAMES:
+                    # playfield registers: a real change that needs no rendering first is QUEUED in
+                    # scalar registers (Emu::pf_enqueue; applied by the next step() / at frame end).
+                    # (Measured: applying it here — a per-lane select on the `tia` / `pfe` VGPRs — made
+                    # those VGPRs live across all ~2000 blocks: compile 1 -> 14 min, Pong 1.2 -> 9.0 ms
+                    # per step.  The translated code stays scalar-only.)
+                    return ['if (e.tia_store_is_nop(0x%02x, %s)) e.cyc += %d;' % (reg, val, dc),
+                            'else { e.cyc += %d; if (!e.pf_enqueue(0x%02x, %s)) { --n; e.pend = 0x%02x | ((%s) << 8); '
+                            'e.PC = 0x%04x; return; } }' % (dc - 1, reg, val, static, val, nxt)]
                 return ['if (__builtin_expect(!e.tia_store_is_nop(0x%02x, %s), 0)) %s' % (reg, val, pend % ('0x%02x' % static)),
                         'e.cyc += %d;' % dc]
             return [

@@ -87,6 +87,15 @@ struct Emu {
   int rom_byte(int ea) const { return a->rom[ea & a->rom_mask]; }
   int tia_read(int ea, int noise) { return host_tia_read(a, (uint16_t)ea, (uint8_t)noise); }
   int riot_read(int ea) { return host_riot_read(a, (uint16_t)ea); }
+  // Emu::pf_enqueue: the device queues the change for its lazy per-lane playfield; the oracle renders
+  // eagerly, so here the store simply happens (host_wr performs the write cycle) — every other time
+  // declined, so that both the queued and the hand-over path of the generated block are exercised
+  int pf_toggle = 0;
+  bool pf_enqueue(int reg, int v) {
+    if ((pf_toggle++ & 1) == 0) return false;
+    host_wr(a, (uint16_t)reg, (uint8_t)v);
+    return true;
+  }
   void wsync(int cw) {
     const int into = (cw - a->cyc0) % kCyclesPerLine;
     cyc = cw + (into ? kCyclesPerLine - into : 0);
