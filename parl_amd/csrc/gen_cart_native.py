@@ -103,6 +103,7 @@ class Cart(object):
         self.name, self.rom, self.mask = name, rom, len(rom) - 1
         self.code = {}  # 16-bit address -> (mode, kind, op, b1, b2)
         self.discover()
+        self.s_hint = self.stack_hints()
 
     def byte(self, a):
         return self.rom[a & self.mask]
@@ -136,6 +137,69 @@ class Cart(object):
                 if op in ('JAM', 'BRK', 'RTS', 'RTI', 'JMPI', 'JMP'):
                     break
                 a = (a + length(mode)) & 0xffff
+
+    def stack_hints(self):
+        """Likely value of the stack pointer BEFORE each instruction, by an optimistic forward dataflow
+        (`LDX #imm; TXS` makes it known, pushes / pulls / JSR move it; at a join the unique known value
+        wins, two different ones cancel).  Only a HINT: the emitted fast path is guarded by
+        `e.S == hint` and the generic code stays behind it, so a wrong hint costs a compare.  Both
+        cartridges point S into TIA space inside their display kernels (`LDX #$1F; TXS`) and `PHP` the
+        result of a compare onto ENABL / ENAMx — 273 (Pong) / 95 (Breakout) pushes per frame whose
+        address class, register number and no-op test fold to constants once S is known."""
+        UNK, CONFLICT = None, -1
+        s_in, x_in = {}, {}
+
+        def meet(old, new):
+            if new is UNK or old == new:
+                return old
+            if old is UNK:
+                return new
+            return CONFLICT
+
+        work = list(self.code)
+        for a in work:
+            s_in[a], x_in[a] = UNK, UNK
+        work = sorted(self.code)  # every address is a block: facts arise wherever `TXS` follows `LDX #imm`
+        seen_iter = 0
+        while work and seen_iter < 2000000:
+            seen_iter += 1
+            a = work.pop()
+            if a not in self.code:
+                continue
+            mode, kind, op, b1, b2 = self.code[a]
+            S, X = s_in[a], x_in[a]
+            if op == 'LDX':
+                X = b1 if mode == M_IMM else UNK
+            elif op in ('TAX', 'TSX'):
+                X = UNK if op == 'TAX' else S
+            elif op in ('INX', 'DEX') and X not in (UNK, CONFLICT):
+                X = (X + (1 if op == 'INX' else -1)) & 0xff
+            elif op == 'TXS':
+                S = X
+            elif op in ('PHA', 'PHP') and S not in (UNK, CONFLICT):
+                S = (S - 1) & 0xff
+            elif op in ('PLA', 'PLP') and S not in (UNK, CONFLICT):
+                S = (S + 1) & 0xff
+            succ = []
+            nxt = (a + length(mode)) & 0xffff
+            if op == 'JSR':
+                succ.append((b1 | (b2 << 8), ((S - 2) & 0xff) if S not in (UNK, CONFLICT) else S, X))
+                succ.append((nxt, S, UNK))
+            elif op == 'JMP':
+                succ.append((b1 | (b2 << 8), S, X))
+            elif mode == M_REL:
+                succ.append(((a + 2 + (b1 - 256 if b1 & 0x80 else b1)) & 0xffff, S, X))
+                succ.append((nxt, S, X))
+            elif op not in ('RTS', 'RTI', 'BRK', 'JMPI', 'JAM'):
+                succ.append((nxt, S, X))
+            for t, ns, nx in succ:
+                if t not in self.code:
+                    continue
+                ms, mx = meet(s_in[t], ns), meet(x_in[t], nx)
+                if ms != s_in[t] or mx != x_in[t]:
+                    s_in[t], x_in[t] = ms, mx
+                    work.append(t)
+        return {a: v for a, v in s_in.items() if v not in (UNK, CONFLICT)}
 
     def entries(self):
         """Addresses native_run can be ENTERED at (the cases of its dispatch switch).  Control only
@@ -259,10 +323,16 @@ class Cart(object):
                 # pull from a stack in RAM (a pull from TIA space reads collision latches: interpreter)
                 # ... or from an input-port address in TIA space (Breakout pulls from $1F inside its
                 # kernel: the read returns the bus noise = the next opcode byte and needs no picture)
-                pre = ['const int s1 = (e.S + 1) & 0xff;', 'int dc = 4, m;',
-                       'if (s1 & 0x80) m = e.ram_rd(s1 & 0x7f);',
-                       'else if ((s1 & 0x0f) >= 8) { e.cyc += 4; dc = 0; m = e.tia_read(s1, 0x%02x); }' % b1,
-                       'else { --n; e.PC = 0x%04x; return; }' % a, 'e.S = s1;']
+                pre = ['const int s1 = (e.S + 1) & 0xff;', 'int dc = 4, m;']
+                h = self.s_hint.get(a)
+                hs1 = None if h is None else (h + 1) & 0xff
+                if hs1 is not None and not (hs1 & 0x80) and (hs1 & 0x0f) >= 8:
+                    # known (guarded) pull from an input-port address: Emu::tia_read folds to constants
+                    pre.append('if (__builtin_expect(s1 == 0x%02x, 1)) { e.cyc += 4; dc = 0; m = e.tia_read(0x%02x, 0x%02x); } else'
+                               % (hs1, hs1, b1))
+                pre += ['if (s1 & 0x80) m = e.ram_rd(s1 & 0x7f);',
+                        'else if ((s1 & 0x0f) >= 8) { e.cyc += 4; dc = 0; m = e.tia_read(s1, 0x%02x); }' % b1,
+                        'else { --n; e.PC = 0x%04x; return; }' % a, 'e.S = s1;']
                 dc = None
                 op = 'LDA'
             else:
@@ -371,12 +441,22 @@ class Cart(object):
                             'e.PC = 0x%04x; return; } }' % (dc - 1, reg, val, static, val, nxt)]
                 return ['if (__builtin_expect(!e.tia_store_is_nop(0x%02x, %s), 0)) %s' % (reg, val, pend % ('0x%02x' % static)),
                         'e.cyc += %d;' % dc]
-            return [
+            generic = [
                 'const int ea = %s;' % ea,
                 'if (ea & 0x80) e.ram_wr(ea & 0x7f, %s);' % val,
                 'else if (__builtin_expect(!e.tia_store_is_nop(ea & 0x3f, %s), 0)) %s' % (val, pend % 'ea'),
                 ('%s e.cyc += %d;' % (dec_s, dc)).strip()
             ]
+            h = self.s_hint.get(a) if mode == M_PUSH else None
+            if h is None or (h & 0x3f) == 0x02 and not (h & 0x80):
+                return generic
+            # stack pointer known (guarded): address class, register number and the no-op test fold
+            if h & 0x80:
+                fast = ['e.ram_wr(0x%02x, %s);' % (h & 0x7f, val)]
+            else:
+                fast = ['if (__builtin_expect(!e.tia_store_is_nop(0x%02x, %s), 0)) %s' % (h & 0x3f, val, pend % ('0x%02x' % h))]
+            fast.append('e.S = 0x%02x; e.cyc += %d;' % ((h - 1) & 0xff, dc))
+            return ['if (__builtin_expect(e.S == 0x%02x, 1)) { %s } else { %s }' % (h, ' '.join(fast), ' '.join(generic))]
         # K_RMW
         rmw = {
             'ASL': 'e.cf = m >> 7; wv = (m << 1) & 0xff;',
