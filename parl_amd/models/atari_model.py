@@ -24,6 +24,38 @@ from ..core import Model
 __all__ = ['AtariModel42', 'AtariModel84', 'GemmConv2d']
 
 
+class _ColGemmFn(torch.autograd.Function):
+    """out = col @ w^T + b with a backward whose weight gradient is a SPLIT-K batched GEMM.
+    dW = d_out^T @ col has a tiny output ([O, K]: 32x256 ... 64x576) and an enormous reduction
+    dimension (rows x positions: 2.5 M for a 6,400-row chunk of the 84x84 model); rocBLAS runs that
+    as ONE column of workgroups (no split-K: 3.9 ms per call, 220 ms per 51,200-row update).  Cutting
+    the reduction into S slices makes it S well-shaped GEMMs + a sum over S."""
+
+    @staticmethod
+    def forward(ctx, col, wmat, bias):
+        ctx.save_for_backward(col, wmat)
+        ctx.has_bias = bias is not None
+        return col @ wmat.t() if bias is None else torch.addmm(bias, col, wmat.t())
+
+    @staticmethod
+    def backward(ctx, d_out):
+        col, wmat = ctx.saved_tensors
+        d_out = d_out.contiguous()
+        rows = col.shape[0]
+        d_col = d_out @ wmat if ctx.needs_input_grad[0] else None
+        S = 1
+        for cand in (256, 128, 64, 32, 16, 8, 4, 2):
+            if rows % cand == 0 and rows // cand >= 2048:
+                S = cand
+                break
+        if S == 1:
+            d_w = d_out.t() @ col
+        else:
+            d_w = torch.bmm(d_out.view(S, rows // S, -1).transpose(1, 2), col.view(S, rows // S, -1)).sum(0)
+        d_b = d_out.sum(0) if ctx.has_bias else None
+        return d_col, d_w, d_b
+
+
 class GemmConv2d(nn.Conv2d):
     """nn.Conv2d whose forward is ONE strided-gather copy (im2col through a 6-D unfold view) + ONE
     rocBLAS GEMM [N*Ho*Wo, C*kh*kw] x [C*kh*kw, O]; fp32, same arithmetic up to the GEMM's
@@ -43,7 +75,7 @@ class GemmConv2d(nn.Conv2d):
         patches = x.unfold(2, kh, self.stride[0]).unfold(3, kw, self.stride[1])  # [N,C,Ho,Wo,kh,kw] view
         ho, wo = patches.shape[2], patches.shape[3]
         col = patches.permute(0, 2, 3, 1, 4, 5).reshape(n * ho * wo, c * kh * kw)
-        out = col @ wmat.t() if self.bias is None else torch.addmm(self.bias, col, wmat.t())
+        out = _ColGemmFn.apply(col, wmat, self.bias)
         return out.view(n, ho, wo, -1).permute(0, 3, 1, 2)
 
 
