@@ -371,6 +371,9 @@ class Cart(object):
                 test = {'FN': '(e.nv & 0x80)', 'FZ': '((e.zv & 0xff) == 0)', 'FC': 'e.cf', 'FV': '(e.P & FV)'}[flag]
                 cond = test if want else '!' + test
                 body = 'e.cyc += %d; ' % dc
+                # (measured: leaving on every backward edge and dispatching again — which makes native_run
+                # acyclic and spares the loop-entry guard flags LLVM's FixIrreducible / UnifyLoopExits add to
+                # blocks inside 6507 loops that are also dispatch entries — is slower: Pong 1.20 -> 1.43 ms)
                 if tgt <= a:  # backward edge: the only place a frame can loop without bound
                     body += 'if (__builtin_expect(n > kNativeInstrLimit, 0)) { e.PC = 0x%04x; return; } ' % tgt
                 body += self.goto(tgt)
