@@ -324,7 +324,7 @@ def main():
                                  clip_rho_threshold=cfg['clip_rho_threshold'],
                                  clip_pg_rho_threshold=cfg['clip_pg_rho_threshold'])
     pdist.broadcast_model(model)
-    if world > 1:
+    if pdist.active():  # also a one-rank group (PARL_AMD_FORCE_DIST=1): the whole DP path over RCCL
         alg.grad_hook = pdist.FlatGradAllReduce(model)
     lr_s = parl.utils.PiecewiseScheduler(cfg['lr_scheduler'])
     ent_s = parl.utils.PiecewiseScheduler(cfg['entropy_coeff_scheduler'])
@@ -348,7 +348,7 @@ def main():
             batch = rollout.collect(model)
             loss, kl = alg.learn(batch['obs'], batch['actions'], batch['behaviour_logits'], batch['rewards'],
                                  batch['dones'], lr_s.step(), ent_s.step(), time_major=True)
-            if world > 1:  # small-tensor trajectory all-gather (global statistics), SURVEY 8e
+            if pdist.active():  # small-tensor trajectory all-gather (global statistics), SURVEY 8e
                 pdist.all_gather_small({'rewards': rollout.rewards, 'dones': rollout.dones,
                                         'actions': rollout.actions})
             return loss
@@ -359,7 +359,7 @@ def main():
         rollout = pipe.rollout
         pipe.prime()  # untimed: every timed step = one rollout + one learner update
 
-        pipe.gather_small = world > 1  # small-tensor trajectory all-gather on the learner stream
+        pipe.gather_small = pdist.active()  # small-tensor trajectory all-gather on the learner stream
 
         def step():
             loss, kl = pipe.step(lr_s.step(), ent_s.step())
@@ -401,7 +401,8 @@ def main():
             'envs_per_gpu': E, 'sample_batch_steps': T, 'obs_dim': dim, 'train_batch': T * E * world,
             'frame_skip': 4, 'parallelism': 'dp%d (envs sharded by rank, grad all-reduce)' % world,
             'actor_learner_overlap': not args.no_overlap, 'actor_groups': G,
-            'collectives': ('none (single process)' if world == 1 else
+            'collectives': (('none (single process)' if not pdist.active() else 'RCCL, one-rank group (PARL_AMD_FORCE_DIST)')
+                            if world == 1 else
                             ('gloo, ranks SHARE GPUs (fewer devices than ranks: functional run, not a scaling number)'
                              if shared else 'RCCL: flat-gradient all-reduce + small-tensor all-gather per update')),
         },

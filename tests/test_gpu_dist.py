@@ -45,3 +45,19 @@ def test_bench_self_launches_two_ranks_without_torchrun():
     import torch
     if torch.cuda.device_count() < 2:
         assert 'SHARE' in out['config']['collectives']
+
+
+def test_bench_data_parallel_path_over_rccl_with_one_rank():
+    """PARL_AMD_FORCE_DIST=1: bench.py creates a one-rank RCCL group and runs its complete
+    data-parallel path (weight broadcast, flat-gradient all-reduce + trajectory all-gather on the
+    learner stream inside the overlapped pipeline, barrier, max-over-ranks timing) on the real backend."""
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', PARL_AMD_FORCE_DIST='1',
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'PARL_AMD_SHARE_GPU', 'PARL_AMD_DIST_BACKEND'):
+        env.pop(k, None)
+    cmd = [sys.executable, 'bench.py', '--gpus', '1', '--steps', '2', '--warmup', '1', '--envs', '64',
+           '--sample-batch-steps', '10', '--no-cpu-baseline', '--quick']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][0])
+    assert out['n_gpus'] == 1 and out['value'] > 0 and 'RCCL' in out['config']['collectives']
