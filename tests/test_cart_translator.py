@@ -36,7 +36,8 @@ def test_entry_set_structure(name):
             assert (b1 | (b2 << 8)) in ent or (b1 | (b2 << 8)) not in c.code
             assert ((a + 3) & 0xffff) in ent or ((a + 3) & 0xffff) not in c.code
         elif mode != g.M_REL and op not in ('JMP', 'BRK', 'RTS', 'RTI', 'JMPI', 'JAM') and \
-                any('return' in ln for ln in body):
+                sum(ln.count('return') - ln.count('/*rare*/ return') for ln in body) > 0:
+            # (a `/*rare*/ return` deliberately creates no entry: the interpreter keeps stepping to the next one)
             nxt = (a + g.length(mode)) & 0xffff     # execution resumes here after the deferral
             assert nxt in ent or nxt not in c.code, hex(a)
     src = c.source('GAME_PONG' if name == 'pong' else 'GAME_BREAKOUT')

@@ -29,6 +29,7 @@ uint16_t host_alu(int op, uint8_t A, uint8_t m, uint8_t P);
 }
 
 #define DEVI inline
+enum : int { JAM_NATIVE = 0x4000 };
 enum : int { FN = 0x80, FV = 0x40, FU = 0x20, FB = 0x10, FD = 0x08, FI = 0x04, FZ = 0x02, FC = 0x01 };
 constexpr int kMaxInstrPerFrame = 25000;
 constexpr int kNativeInstrLimit = kMaxInstrPerFrame - 8192;
@@ -39,6 +40,7 @@ struct Emu {
   int A, X, Y, S, PC;
   int P, nv, zv, cf;   // lazy flags as in atari_core.hpp
   int pend;
+  int jam = 0;
   int& cyc;
   explicit Emu(Atari* m) : a(m), cyc(m->cyc) {}
 
@@ -143,6 +145,7 @@ static void frame_translated(Atari* a, uint8_t* fb, long* native_instr, long* de
     const int n0 = n;
     native_run<GAME>(e, n);
     e.store();
+    if (e.jam) { fprintf(stderr, "translated code raised JAM_NATIVE at PC %04x\n", e.PC); exit(1); }
     *native_instr += n - n0;
     if (e.pend == -2) continue;   // translated RTS / RTI: PC set, dispatch again (Emu::frame)
     if (e.pend < 0 && n >= kMaxInstrPerFrame) break;
