@@ -303,6 +303,19 @@ int parlhip_atari42_conv12_bwd_f32(const uint8_t* obs, const float* w1, const fl
 int parlhip_atari84_conv1_u8_f32(const uint8_t* obs, const float* w1, const float* b1, float* out,
                                  int n_obs, parlhip_stream_t stream);
 
+/* examples/A2C/atari_model.py:21-104 (AtariModel trunk), second and third layer, fused:
+ * conv2 32->64 k4 s2 p2 + ReLU (20x20 -> 11x11), conv3 64->64 k3 s1 + ReLU (-> 9x9).
+ * a1 f32 [n,32,20,20] (the output of parlhip_atari84_conv1_u8_f32, 16-byte aligned), out a3 f32
+ * [n, 64*9*9] in NCHW flatten order (the input of the 5184->512 fc layer); a2_out (optional, may be
+ * NULL) receives the conv2 activation [n,64,11,11] the backward pass needs.  The weights arrive in
+ * MFMA operand order, streamed from L2 by the kernel:
+ *   wt2[ks][nt][lane] = w2[16 nt + (lane & 15)][4 ks + (lane >> 4)]          ks < 128, nt < 4
+ *   wt3[ks][nt][lane] = w3[16 nt + (lane & 15)][c][kh][kw],  4 ks + (lane >> 4) = (3 kh + kw) 64 + c
+ * (w2 = conv2.weight.flatten(1), nn.Conv2d layout).                                              */
+int parlhip_atari84_conv23_f32(const float* a1, const float* wt2, const float* b2, const float* wt3,
+                               const float* b3, float* a2_out, float* a3_out, int n_obs,
+                               parlhip_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * PPO: running observation / return normalisation and the minibatch gather
  * ------------------------------------------------------------------------------------ */

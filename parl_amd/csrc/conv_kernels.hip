@@ -455,6 +455,123 @@ __global__ __launch_bounds__(256) void conv1_84_u8_mfma_kernel(
   }
 }
 
+
+// ----------------------------------------------------------------------------------------
+// conv2 + conv3 of the A2C Atari network, fused (examples/A2C/atari_model.py:21-104):
+//   a1 [32,20,20] (the output of conv1_84_u8_mfma_kernel) -> conv2 32->64 k4 s2 p2 + ReLU
+//   -> a2 [64,11,11] (stays in LDS) -> conv3 64->64 k3 s1 + ReLU -> a3 [64,9,9] = the 5184-wide
+//   input of the fc layer.  13.9 MFLOP per observation.
+// One workgroup per observation (grid-stride); a1 zero-padded in LDS ([32][24][24] f32, 73.7 KB),
+// a2 in LDS ([64][121], 31 KB).  The weight matrices (128 KB + 147 KB) fit neither registers nor
+// the remaining LDS: they are STREAMED from L2 in MFMA operand order — `wt2[ks][nt][lane]`,
+// `wt3[ks][nt][lane]` (prepared by the host wrapper: one 256-byte coalesced load per wave and
+// k-step) — each wave owning one 16-channel N tile and all M tiles, so every streamed B value
+// feeds 8 (conv2) / 6 (conv3) MFMAs.  k order: conv2 k = c*16 + kh*4 + kw (natural, kw = lane
+// quarter); conv3 k' = (kh*3 + kw)*64 + c (tap-major, so the tap is uniform per k-step).
+// a2 is also written to HBM when the learner needs it for the backward pass.
+// ----------------------------------------------------------------------------------------
+constexpr int kA1 = 20, kA1P = 24, kA1Plane = kA1P * kA1P;      // conv1 output, padded by 2
+constexpr int kA2 = 11, kM2b = kA2 * kA2;                        // 121 conv2 outputs
+constexpr int kA3 = 9, kM3 = kA3 * kA3;                          // 81 conv3 outputs
+constexpr int kLds23Floats = 32 * kA1Plane + 64 * kM2b;          // 18,432 + 7,744 = 26,176 floats = 104,704 B
+
+__global__ __launch_bounds__(256) void conv23_84_mfma_kernel(
+    const float* __restrict__ a1, const float* __restrict__ wt2, const float* __restrict__ b2,
+    const float* __restrict__ wt3, const float* __restrict__ b3, float* __restrict__ a2_out,
+    float* __restrict__ a3_out, int n_obs) {
+  extern __shared__ float lds[];
+  float* a1p = lds;                       // [32][24][24]
+  float* a2s = lds + 32 * kA1Plane;       // [64][121]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, col = lane & 15;
+  const float bias2 = b2[16 * wave + col], bias3 = b3[16 * wave + col];
+  for (int i = tid; i < 32 * kA1Plane; i += 256) a1p[i] = 0.0f;   // borders stay zero
+  // conv2 gather offsets of this lane's 8 M tiles: position m -> (2*oy)*24 + 2*ox + kw (kw = q)
+  int off2[8];
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    int m = mt * 16 + col;
+    m = m < kM2b ? m : kM2b - 1;
+    const int oy = m / kA2, ox = m - oy * kA2;
+    off2[mt] = (2 * oy) * kA1P + 2 * ox + q;
+  }
+  int off3[6];
+#pragma unroll
+  for (int mt = 0; mt < 6; ++mt) {
+    int m = mt * 16 + col;
+    m = m < kM3 ? m : kM3 - 1;
+    const int oy = m / kA3, ox = m - oy * kA3;
+    off3[mt] = oy * kA2 + ox + q * kM2b;   // + channel (c = 4*(ks&15) + q) and tap offsets per k-step
+  }
+#pragma unroll 1
+  for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
+    __syncthreads();
+    // ---- a1 -> padded LDS tile ----
+    const float4* src = reinterpret_cast<const float4*>(a1 + (size_t)n * 32 * kA1 * kA1);
+    for (int i = tid; i < 32 * kA1 * kA1 / 4; i += 256) {
+      const float4 v = src[i];
+      const int e = i * 4, c = e / (kA1 * kA1), r = e - c * kA1 * kA1, y = r / kA1, x = r - y * kA1;   // 20 % 4 == 0
+      float* d = a1p + c * kA1Plane + (y + 2) * kA1P + (x + 2);
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    // ---- conv2: wave = N tile (channels 16*wave ..), 8 M tiles, 128 k-steps ----
+    {
+      f32x4 acc[8];
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* wp = wt2 + wave * 64 + lane;            // wt2[ks][nt = wave][lane]
+#pragma clang loop unroll_count(2)
+      for (int ks = 0; ks < 128; ++ks) {
+        const float b = wp[ks * 256];
+        const float* ab = a1p + (ks >> 2) * kA1Plane + (ks & 3) * kA1P;   // c = ks >> 2, kh = ks & 3
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[off2[mt]], b, acc[mt], 0, 0, 0);
+      }
+      float* g2 = a2_out ? a2_out + (size_t)n * 64 * kM2b : nullptr;
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mo = mt * 16 + q * 4 + r;
+          if (mo < kM2b) {
+            float v = acc[mt][r] + bias2;
+            v = v > 0.f ? v : 0.f;
+            a2s[(16 * wave + col) * kM2b + mo] = v;
+            if (g2) g2[(16 * wave + col) * kM2b + mo] = v;
+          }
+        }
+    }
+    __syncthreads();
+    // ---- conv3: wave = N tile, 6 M tiles, 144 k-steps in tap-major order ----
+    {
+      f32x4 acc[6];
+#pragma unroll
+      for (int mt = 0; mt < 6; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* wp = wt3 + wave * 64 + lane;
+#pragma clang loop unroll_count(2)
+      for (int ks = 0; ks < 144; ++ks) {
+        const float b = wp[ks * 256];
+        const int tap = ks >> 4, kh = tap / 3, kw = tap - kh * 3;   // k' = tap*64 + c, c = 4*(ks & 15) + q
+        const float* ab = a2s + (4 * (ks & 15)) * kM2b + kh * kA2 + kw;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[off3[mt]], b, acc[mt], 0, 0, 0);
+      }
+      float* g3 = a3_out + (size_t)n * 64 * kM3;
+#pragma unroll
+      for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mo = mt * 16 + q * 4 + r;
+          if (mo < kM3) {
+            const float v = acc[mt][r] + bias3;
+            g3[(16 * wave + col) * kM3 + mo] = v > 0.f ? v : 0.f;
+          }
+        }
+    }
+  }
+}
+
 }  // namespace parlhip
 
 using namespace parlhip;
@@ -533,5 +650,25 @@ PARLHIP_EXPORT int parlhip_atari42_conv12_bwd_f32(const uint8_t* obs, const floa
   int rc = check_launch();
   if (rc) return rc;
   conv12_bwd_reduce_kernel<<<(kBwdPartial + 255) / 256, 256, 0, s>>>(workspace, grid, dw1, db1, dw2, db2);
+  return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_atari84_conv23_f32(const float* a1, const float* wt2, const float* b2, const float* wt3,
+                                              const float* b3, float* a2_out, float* a3_out, int n_obs,
+                                              parlhip_stream_t stream) {
+  if (n_obs < 0) return PARLHIP_EINVAL;
+  if (n_obs == 0) return PARLHIP_OK;
+  if (!a1 || !wt2 || !b2 || !wt3 || !b3 || !a3_out) return PARLHIP_EINVAL;
+  if ((uintptr_t)a1 & 15u) return PARLHIP_EINVAL;   // 16-byte loads of the conv1 activation
+  static bool attr_set = false;
+  const size_t lds_bytes = kLds23Floats * sizeof(float);
+  if (!attr_set) {
+    int rc = check(hipFuncSetAttribute((const void*)conv23_84_mfma_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int grid = n_obs < kNumCU ? n_obs : kNumCU;   // 105 KB of LDS: one workgroup per CU
+  conv23_84_mfma_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(a1, wt2, b2, wt3, b3, a2_out, a3_out, n_obs);
   return check_launch();
 }

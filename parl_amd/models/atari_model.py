@@ -140,8 +140,10 @@ class AtariModel84(Model):
             # the actors' / bootstrap-value path (no autograd): the 84x84 -> 20x20 contraction as one
             # MFMA kernel on the uint8 observations with /255, bias and ReLU fused (ops.atari84_conv1)
             x = ops.atari84_conv1(obs, self.conv1.weight, self.conv1.bias)
-        else:
-            x = F.relu(self.conv1(obs.float() / 255.0))
+            # conv2 + conv3 fused (a2 stays in LDS, weights streamed from L2 in MFMA operand order)
+            x = ops.atari84_conv23(x, self.conv2.weight, self.conv2.bias, self.conv3.weight, self.conv3.bias)
+            return F.relu(self.fc(x))
+        x = F.relu(self.conv1(obs.float() / 255.0))
         x = F.relu(self.conv2(x))
         x = F.relu(self.conv3(x))
         return F.relu(self.fc(x.flatten(1)))

@@ -352,6 +352,36 @@ def atari84_conv1(obs, conv1_weight, conv1_bias, out=None):
     return out
 
 
+def _mfma_b_layout(wflat):
+    """[N, K] weight matrix (N = 16*NT, K = 4*KS) -> [KS, NT, 64] in MFMA B-operand order:
+    out[ks][nt][q*16 + col] = w[16*nt + col][4*ks + q] (one coalesced 256-byte load per wave)"""
+    n, k = wflat.shape
+    return wflat.reshape(n // 16, 16, k // 4, 4).permute(2, 0, 3, 1).contiguous()
+
+
+def atari84_conv23(a1, conv2_weight, conv2_bias, conv3_weight, conv3_bias, save_a2=False):
+    """conv2 + ReLU + conv3 + ReLU of the A2C Atari network (examples/A2C/atari_model.py:21-104) fused
+    in one MFMA kernel: a1 f32 [n,32,20,20] (atari84_conv1's output) -> a3 f32 [n,5184]; with
+    save_a2 also the conv2 activation [n,64,11,11] (for the backward pass)."""
+    if a1.dtype != torch.float32 or a1.dim() != 4 or tuple(a1.shape[1:]) != (32, 20, 20):
+        raise N.ParlHipError('atari84_conv23: a1 must be f32 [n,32,20,20]')
+    if tuple(conv2_weight.shape) != (64, 32, 4, 4) or tuple(conv3_weight.shape) != (64, 64, 3, 3):
+        raise N.ParlHipError('atari84_conv23: weights must be [64,32,4,4] and [64,64,3,3]')
+    n = a1.shape[0]
+    w2 = _f32(conv2_weight.detach(), 'conv2_weight')
+    w3 = _f32(conv3_weight.detach(), 'conv3_weight')
+    wt2 = _mfma_b_layout(w2.reshape(64, 512))
+    wt3 = _mfma_b_layout(w3.permute(0, 2, 3, 1).reshape(64, 576))   # k' = (kh*3 + kw)*64 + c
+    b2, b3 = _f32(conv2_bias.detach(), 'conv2_bias'), _f32(conv3_bias.detach(), 'conv3_bias')
+    a3 = torch.empty((n, 64 * 81), dtype=torch.float32, device=a1.device)
+    a2 = torch.empty((n, 64, 11, 11), dtype=torch.float32, device=a1.device) if save_a2 else None
+    N.check(
+        N.lib().parlhip_atari84_conv23_f32(N.ptr(a1.contiguous()), N.ptr(wt2), N.ptr(b2), N.ptr(wt3), N.ptr(b3),
+                                          N.ptr(a2) if a2 is not None else None, N.ptr(a3), n, N.stream_ptr()),
+        'parlhip_atari84_conv23_f32')
+    return (a3, a2) if save_a2 else a3
+
+
 def _f64(t, name):
     if t.dtype != torch.float64 or not t.is_cuda:
         raise N.ParlHipError('%s must be a float64 CUDA tensor' % name)

@@ -245,3 +245,43 @@ def test_model_learner_path_gradients_match_gemm_lowered_autograd(dev):
     for (name, _), a, b in zip(m.named_parameters(), ga, gb):
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-6, name
+
+
+# ---------------------------------------------------------------------------------------------
+# the 84x84 model: fused conv2 + conv3 (parlhip_atari84_conv23_f32)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n', [1, 7, 300])
+def test_conv23_84_matches_torch_reference(dev, n):
+    from parl_amd import ops
+    g = torch.Generator().manual_seed(50 + n)
+    a1 = torch.relu(torch.randn(n, 32, 20, 20, generator=g))
+    w2 = torch.randn(64, 32, 4, 4, generator=g) * 0.05
+    b2 = torch.randn(64, generator=g) * 0.1
+    w3 = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    b3 = torch.randn(64, generator=g) * 0.1
+    a3, a2 = ops.atari84_conv23(a1.to(dev), w2.to(dev), b2.to(dev), w3.to(dev), b3.to(dev), save_a2=True)
+    r2 = F.relu(F.conv2d(a1.double(), w2.double(), b2.double(), stride=2, padding=2))
+    r3 = F.relu(F.conv2d(r2, w3.double(), b3.double())).flatten(1)
+    for got, ref in ((a2.cpu().double(), r2), (a3.cpu().double(), r3)):
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    only3 = ops.atari84_conv23(a1.to(dev), w2.to(dev), b2.to(dev), w3.to(dev), b3.to(dev))
+    assert torch.equal(only3, a3)
+
+
+def test_conv23_84_one_hot_weights_select_single_taps(dev):
+    """one-hot conv2 / conv3 weights: the output must be exactly one (shifted, strided) input plane —
+    checks the streamed-weight layout (wt2 / wt3) and the gather arithmetic without summation noise"""
+    from parl_amd import ops
+    g = torch.Generator().manual_seed(4)
+    a1 = torch.rand(2, 32, 20, 20, generator=g)
+    for (o2, c2, kh2, kw2, o3, kh3, kw3) in [(0, 0, 0, 0, 0, 0, 0), (63, 31, 3, 3, 63, 2, 2), (17, 5, 1, 2, 40, 1, 0), (33, 20, 2, 0, 9, 0, 2)]:
+        w2 = torch.zeros(64, 32, 4, 4)
+        w2[o2, c2, kh2, kw2] = 1.0
+        w3 = torch.zeros(64, 64, 3, 3)
+        w3[o3, o2, kh3, kw3] = 1.0
+        z = torch.zeros(64)
+        a3, a2 = ops.atari84_conv23(a1.to(dev), w2.to(dev), z.to(dev), w3.to(dev), z.to(dev), save_a2=True)
+        r2 = F.conv2d(a1, w2, None, stride=2, padding=2)
+        r3 = F.conv2d(r2, w3).flatten(1)
+        assert torch.equal(a2.cpu(), r2) and torch.equal(a3.cpu(), r3)

@@ -51,6 +51,12 @@ def main():
             o = ob.float()
         s = timeit(lambda: alg.learn(o, act, bl, rew, dn, 1e-4, -0.01, time_major=True), iters=5, warmup=2)
         res['%s_T%d_E%d' % (name, T, E)] = {'ms': s * 1e3}
+    for m in (1024, 8192):
+        a1 = torch.relu(torch.randn(m, 32, 20, 20, device=dev))
+        w2c, b2c = torch.randn(64, 32, 4, 4, device=dev) * 0.05, torch.zeros(64, device=dev)
+        w3c, b3c = torch.randn(64, 64, 3, 3, device=dev) * 0.05, torch.zeros(64, device=dev)
+        s = timeit(lambda: ops.atari84_conv23(a1, w2c, b2c, w3c, b3c), iters=10)
+        res['conv23_84_fwd_n%d' % m] = {'ms': s * 1e3, 'TFLOPs': m * 2.0 * (121 * 512 * 64 + 81 * 576 * 64) / s / 1e12}
     for k, v in res.items():
         print(k, {a: round(b, 3) for a, b in v.items()})
     if args.json:
