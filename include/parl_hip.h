@@ -316,6 +316,18 @@ int parlhip_atari84_conv23_f32(const float* a1, const float* wt2, const float* b
                                const float* b3, float* a2_out, float* a3_out, int n_obs,
                                parlhip_stream_t stream);
 
+/* Backward of conv3 (64->64 k3 s1) of the same network for the learner: given the saved activations
+ * a2 [n,64,11,11] and a3 [n,5184] and dy3 = d loss / d a3 [n,5184]:
+ *   dz2 [n,64,11,11] = (d loss / d a2) * (a2 > 0)   (the input of parlhip_atari84_conv2_bwd_f32)
+ *   dw3_db3 [64*576 + 64]: d loss / d w3 as [o][k'] with k' = (3 kh + kw) 64 + c, then d loss / d b3
+ * wt3b = the B operand of the transposed convolution in MFMA order:
+ *   wt3b[ks][nt][lane] = w3[o][16 nt + (lane & 15)][kh][kw],  4 ks + (lane >> 4) = (3 kh + kw) 64 + o
+ * workspace: parlhip_atari84_conv3_bwd_workspace_bytes(n) bytes; deterministic.                   */
+size_t parlhip_atari84_conv3_bwd_workspace_bytes(int n_obs);
+int parlhip_atari84_conv3_bwd_f32(const float* a2, const float* a3, const float* dy3, const float* wt3b,
+                                  int n_obs, float* workspace, float* dz2, float* dw3_db3,
+                                  parlhip_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * PPO: running observation / return normalisation and the minibatch gather
  * ------------------------------------------------------------------------------------ */

@@ -572,6 +572,154 @@ __global__ __launch_bounds__(256) void conv23_84_mfma_kernel(
   }
 }
 
+
+// ----------------------------------------------------------------------------------------
+// Backward of the 84x84 model's convolutions for the learner (A2C.learn / IMPALA.learn on
+// examples/A2C/atari_model.py:21-104), layer by layer, one workgroup per observation, the
+// activations a1 / a2 / a3 saved by the forward kernels (51 + 31 + 21 KB per observation: HBM traffic
+// of the whole backward pass ~0.3 MB per observation against 41 MFLOP of MFMA work).  Weight
+// gradients accumulate in registers across the observations of a workgroup and leave as
+// per-workgroup partials summed in a fixed order (partial_sum_kernel): deterministic.
+//
+// conv3_84_bwd_kernel: dz3 = dy3 * (a3 > 0);
+//   (A) dW3[o][k'] += sum_p dz3[o][p] a2[c][oy+kh][ox+kw]       [64 x 81] x [81 x 576], k' = tap*64 + c
+//       wave w owns the k' tiles {w, w+4, ..} (9 tiles x 4 o tiles = 36 accumulators)
+//   (B) dA2[c][y][x] = sum_{o,kh,kw} dz3[o][y-kh][x-kw] w3[o][c][kh][kw]   (gather from dz3 padded
+//       by 2) = [121 x 576] x [576 x 64] with the B operand streamed (wt3b[ks][nt][lane],
+//       k'' = tap*64 + o); dz2 = dA2 * (a2 > 0) -> HBM
+// ----------------------------------------------------------------------------------------
+constexpr int kZ3P = 13, kZ3Plane = kZ3P * kZ3P;                      // dz3 padded by 2: 13 x 13
+constexpr int kLds3bFloats = 64 * kM2b + 64 * kZ3Plane + 128;          // 7,744 + 10,816 + 128 = 18,688 floats = 74,752 B
+constexpr int kPart3 = 64 * 576 + 64;                                  // dW3 [o][k'] + db3
+
+__global__ __launch_bounds__(256) void conv3_84_bwd_kernel(
+    const float* __restrict__ a2, const float* __restrict__ a3, const float* __restrict__ dy3,
+    const float* __restrict__ wt3b, float* __restrict__ dz2, float* __restrict__ partial, int n_obs) {
+  extern __shared__ float lds[];
+  float* a2s = lds;                         // [64][121]
+  float* z3p = lds + 64 * kM2b;             // [64][13][13], zero border
+  float* red = z3p + 64 * kZ3Plane;         // [128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, col = lane & 15;
+  f32x4 accw[4][9];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) accw[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dba[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 64 * kZ3Plane; i += 256) z3p[i] = 0.0f;
+  // (A) B-operand offsets of this lane's 9 k' tiles: tile nt = wave + 4 j -> tap = nt >> 2, c = 16 (nt & 3) + col
+  int boff[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int nt = wave + 4 * j, tap = nt >> 2, kh = tap / 3, kw = tap - kh * 3;
+    boff[j] = (16 * (nt & 3) + col) * kM2b + kh * kA2 + kw;
+  }
+  // (B) A-operand offsets of the 8 M tiles (positions of the 11 x 11 input): z3p[o][y + 2][x + 2]
+  int aoff[8];
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    int m = mt * 16 + col;
+    m = m < kM2b ? m : kM2b - 1;
+    const int y = m / kA2, x = m - y * kA2;
+    aoff[mt] = (y + 2) * kZ3P + (x + 2) + q * kZ3Plane;    // + o = 4 (ks & 15) + q, - kh * 13 - kw per k-step
+  }
+#pragma unroll 1
+  for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
+    __syncthreads();
+    const float4* s2 = reinterpret_cast<const float4*>(a2 + (size_t)n * 64 * kM2b);   // 7,744 floats: 16-byte multiple
+    for (int i = tid; i < 64 * kM2b / 4; i += 256) reinterpret_cast<float4*>(a2s)[i] = s2[i];
+    const float* a3n = a3 + (size_t)n * 64 * kM3;
+    const float* dyn = dy3 + (size_t)n * 64 * kM3;
+    for (int i = tid; i < 64 * kM3; i += 256) {
+      const int o = i / kM3, p = i - o * kM3, y = p / kA3, x = p - y * kA3;
+      z3p[o * kZ3Plane + (y + 2) * kZ3P + (x + 2)] = a3n[i] > 0.f ? dyn[i] : 0.f;
+    }
+    __syncthreads();
+    // ---- (A) dW3 ----
+    {
+      int oy = 0, ox = q;                                  // p = 4 ks + q
+#pragma clang loop unroll(disable)
+      for (int ks = 0; ks < 21; ++ks) {
+        const bool valid = (ks < 20) | (q == 0);           // p < 81
+        const int zo = valid ? (oy + 2) * kZ3P + (ox + 2) : 0;   // z3p[o][0][0] is border: 0
+        const int po = valid ? oy * kA2 + ox : 0;
+        float av[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          av[mt] = z3p[(16 * mt + col) * kZ3Plane + zo];
+          dba[mt] += av[mt];
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+          const float b = a2s[boff[j] + po];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) accw[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], b, accw[mt][j], 0, 0, 0);
+        }
+        ox += 4;
+        const bool wrap = ox >= kA3;
+        ox -= wrap ? kA3 : 0;
+        oy += wrap ? 1 : 0;
+      }
+    }
+    // ---- (B) dz2 = (transposed conv3 of dz3) * (a2 > 0) ----
+    {
+      f32x4 acc[8];
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* wp = wt3b + wave * 64 + lane;
+#pragma clang loop unroll_count(2)
+      for (int ks = 0; ks < 144; ++ks) {
+        const float b = wp[ks * 256];
+        const int tap = ks >> 4, kh = tap / 3, kw = tap - kh * 3;
+        const float* ab = z3p + (4 * (ks & 15)) * kZ3Plane - kh * kZ3P - kw;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[aoff[mt]], b, acc[mt], 0, 0, 0);
+      }
+      float* g = dz2 + (size_t)n * 64 * kM2b;
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mo = mt * 16 + q * 4 + r;
+          if (mo < kM2b) {
+            const int idx = (16 * wave + col) * kM2b + mo;
+            g[idx] = a2s[idx] > 0.f ? acc[mt][r] : 0.f;
+          }
+        }
+    }
+  }
+  // ---- partials: dW3[o][k'] (o = 16 mt + 4 q + r, k' = 16 (wave + 4 j) + col), db3 ----
+  float* P = partial + (size_t)blockIdx.x * kPart3;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[(16 * mt + 4 * q + r) * 576 + 16 * (wave + 4 * j) + col] = accw[mt][j][r];
+  __syncthreads();
+  if (wave == 0) {   // every wave accumulated the same dz3 row sums
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) red[(mt * 4 + q) * 16 + col] = dba[mt];   // [mt][q][col]
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int mt = tid >> 4, c = tid & 15;
+    P[64 * 576 + tid] = red[(mt * 4 + 0) * 16 + c] + red[(mt * 4 + 1) * 16 + c] + red[(mt * 4 + 2) * 16 + c] +
+                        red[(mt * 4 + 3) * 16 + c];
+  }
+}
+
+// out[j] = sum over parts of partial[part][j], fixed order (deterministic)
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ partial, int n_parts, int len,
+                                                          float* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= len) return;
+  float s = 0.f;
+  for (int g = 0; g < n_parts; ++g) s += partial[(size_t)g * len + j];
+  out[j] = s;
+}
+
 }  // namespace parlhip
 
 using namespace parlhip;
@@ -670,5 +818,34 @@ PARLHIP_EXPORT int parlhip_atari84_conv23_f32(const float* a1, const float* wt2,
   }
   const int grid = n_obs < kNumCU ? n_obs : kNumCU;   // 105 KB of LDS: one workgroup per CU
   conv23_84_mfma_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(a1, wt2, b2, wt3, b3, a2_out, a3_out, n_obs);
+  return check_launch();
+}
+
+static int bwd84_grid(int n_obs) { return n_obs < kNumCU ? n_obs : kNumCU; }
+
+PARLHIP_EXPORT size_t parlhip_atari84_conv3_bwd_workspace_bytes(int n_obs) {
+  return n_obs <= 0 ? 0 : (size_t)bwd84_grid(n_obs) * kPart3 * sizeof(float);
+}
+
+PARLHIP_EXPORT int parlhip_atari84_conv3_bwd_f32(const float* a2, const float* a3, const float* dy3, const float* wt3b,
+                                                 int n_obs, float* workspace, float* dz2, float* dw3_db3,
+                                                 parlhip_stream_t stream) {
+  if (n_obs <= 0) return n_obs < 0 ? PARLHIP_EINVAL : PARLHIP_OK;
+  if (!a2 || !a3 || !dy3 || !wt3b || !workspace || !dz2 || !dw3_db3) return PARLHIP_EINVAL;
+  if ((uintptr_t)a2 & 15u) return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  const size_t lds_bytes = kLds3bFloats * sizeof(float);
+  if (!attr_set) {
+    int rc = check(hipFuncSetAttribute((const void*)conv3_84_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes));
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int grid = bwd84_grid(n_obs);
+  conv3_84_bwd_kernel<<<grid, 256, lds_bytes, s>>>(a2, a3, dy3, wt3b, dz2, workspace, n_obs);
+  int rc = check_launch();
+  if (rc) return rc;
+  partial_sum_kernel<<<(kPart3 + 255) / 256, 256, 0, s>>>(workspace, grid, kPart3, dw3_db3);
   return check_launch();
 }

@@ -382,6 +382,28 @@ def atari84_conv23(a1, conv2_weight, conv2_bias, conv3_weight, conv3_bias, save_
     return (a3, a2) if save_a2 else a3
 
 
+def atari84_conv3_backward(a2, a3, grad_a3, conv3_weight):
+    """backward of conv3 + ReLU of the A2C Atari network: (dz2 [n,64,11,11] = grad w.r.t. a2 masked by
+    a2 > 0, d conv3.weight [64,64,3,3], d conv3.bias [64]); deterministic"""
+    n = a2.shape[0]
+    a2, a3 = _f32(a2, 'a2'), _f32(a3, 'a3')
+    g3 = _f32(grad_a3.contiguous(), 'grad_a3')
+    if a2.numel() != n * 7744 or a3.numel() != n * 5184 or g3.numel() != n * 5184:
+        raise N.ParlHipError('atari84_conv3_backward: a2 [n,64,11,11], a3 / grad_a3 [n,5184]')
+    w3 = _f32(conv3_weight.detach(), 'conv3_weight')
+    wt3b = _mfma_b_layout(w3.permute(1, 2, 3, 0).reshape(64, 576))   # [c][k'' = tap*64 + o]
+    dev = a2.device
+    dz2 = torch.empty((n, 64, 11, 11), dtype=torch.float32, device=dev)
+    out = torch.empty(64 * 576 + 64, dtype=torch.float32, device=dev)
+    ws = torch.empty(max(N.lib().parlhip_atari84_conv3_bwd_workspace_bytes(n) // 4, 1), dtype=torch.float32, device=dev)
+    N.check(
+        N.lib().parlhip_atari84_conv3_bwd_f32(N.ptr(a2.contiguous()), N.ptr(a3.contiguous()), N.ptr(g3), N.ptr(wt3b), n,
+                                             N.ptr(ws), N.ptr(dz2), N.ptr(out), N.stream_ptr()),
+        'parlhip_atari84_conv3_bwd_f32')
+    dw3 = out[:64 * 576].view(64, 9, 64).permute(0, 2, 1).reshape(64, 64, 3, 3).contiguous()
+    return dz2, dw3, out[64 * 576:].clone()
+
+
 def _f64(t, name):
     if t.dtype != torch.float64 or not t.is_cuda:
         raise N.ParlHipError('%s must be a float64 CUDA tensor' % name)

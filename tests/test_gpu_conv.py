@@ -285,3 +285,30 @@ def test_conv23_84_one_hot_weights_select_single_taps(dev):
         r2 = F.conv2d(a1, w2, None, stride=2, padding=2)
         r3 = F.conv2d(r2, w3).flatten(1)
         assert torch.equal(a2.cpu(), r2) and torch.equal(a3.cpu(), r3)
+
+
+def _dyadic(gen, shape, lo, hi, denom):
+    return torch.randint(lo, hi, shape, generator=gen).float() / denom
+
+
+@pytest.mark.parametrize('n', [1, 3, 300])
+def test_conv3_84_backward_matches_fp64_autograd(dev, n):
+    """dyadic data (activations k/8, weights k/32, biases odd/512): every pre-activation is an exactly
+    representable non-zero number, so the ReLU masks of the f32 kernels and the f64 reference agree"""
+    from parl_amd import ops
+    g = torch.Generator().manual_seed(70 + n)
+    a2 = torch.relu(_dyadic(g, (n, 64, 11, 11), -8, 9, 8.0))
+    w3 = _dyadic(g, (64, 64, 3, 3), -4, 5, 32.0)
+    b3 = (2 * torch.randint(-16, 16, (64, ), generator=g).float() + 1) / 512.0
+    dy = torch.randn(n, 5184, generator=g)
+    p = [t.double().clone().requires_grad_(True) for t in (a2, w3, b3)]
+    a3r = F.relu(F.conv2d(p[0], p[1], p[2])).flatten(1)
+    (a3r * dy.double()).sum().backward()
+    a3 = a3r.detach().float()
+    dz2, dw3, db3 = ops.atari84_conv3_backward(a2.to(dev), a3.to(dev), dy.to(dev), w3.to(dev))
+    again = ops.atari84_conv3_backward(a2.to(dev), a3.to(dev), dy.to(dev), w3.to(dev))
+    ref_dz2 = p[0].grad * (a2 > 0).double()
+    for name, got, got2, ref in (('dz2', dz2, again[0], ref_dz2), ('dw3', dw3, again[1], p[1].grad), ('db3', db3, again[2], p[2].grad)):
+        assert torch.equal(got, got2), name
+        scale = float(ref.abs().max())
+        assert float((got.cpu().double() - ref).abs().max()) <= 1e-5 * scale * max(1.0, (n / 64.0) ** 0.5), name
