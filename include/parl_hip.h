@@ -328,6 +328,19 @@ int parlhip_atari84_conv3_bwd_f32(const float* a2, const float* a3, const float*
                                   int n_obs, float* workspace, float* dz2, float* dw3_db3,
                                   parlhip_stream_t stream);
 
+/* Backward of conv2 (32->64 k4 s2 p2): a1 [n,32,20,20] saved by the forward, dz2 from the conv3
+ * backward -> dz1 [n,32,20,20] = (d loss / d a1) * (a1 > 0), dw2_db2 [64*512 + 64] (d w2 as
+ * [64][c*16 + kh*4 + kw], then d b2).  wt2b[cls][o][nt][lane] = w2[o][16 nt + (lane & 15)]
+ * [py + 2 (lane >> 5)][px + 2 ((lane >> 4) & 1)] for the output parity class cls = 2 py + px.          */
+size_t parlhip_atari84_conv2_bwd_workspace_bytes(int n_obs);
+int parlhip_atari84_conv2_bwd_f32(const float* a1, const float* dz2, const float* wt2b, int n_obs,
+                                  float* workspace, float* dz1, float* dw2_db2, parlhip_stream_t stream);
+/* Backward of conv1 (4->32 k8 s4 p1) w.r.t. its parameters: obs u8 [n,4,84,84], dz1 from the conv2
+ * backward -> dw1_db1 [32*256 + 32] (d w1 as [32][ci*64 + kh*8 + kw], then d b1).                  */
+size_t parlhip_atari84_conv1_bwd_workspace_bytes(int n_obs);
+int parlhip_atari84_conv1_bwd_f32(const uint8_t* obs, const float* dz1, int n_obs, float* workspace,
+                                  float* dw1_db1, parlhip_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * PPO: running observation / return normalisation and the minibatch gather
  * ------------------------------------------------------------------------------------ */

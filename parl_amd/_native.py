@@ -69,6 +69,10 @@ SIGNATURES = {
     'parlhip_atari84_conv23_f32': (_i, [_p] * 7 + [_i, _p]),
     'parlhip_atari84_conv3_bwd_workspace_bytes': (_sz, [_i]),
     'parlhip_atari84_conv3_bwd_f32': (_i, [_p] * 4 + [_i] + [_p] * 4),
+    'parlhip_atari84_conv2_bwd_workspace_bytes': (_sz, [_i]),
+    'parlhip_atari84_conv2_bwd_f32': (_i, [_p] * 3 + [_i] + [_p] * 4),
+    'parlhip_atari84_conv1_bwd_workspace_bytes': (_sz, [_i]),
+    'parlhip_atari84_conv1_bwd_f32': (_i, [_p, _p, _i, _p, _p, _p]),
     'parlhip_atari42_conv12_bwd_workspace_bytes': (_sz, [_i]),
     'parlhip_atari42_conv12_bwd_f32': (_i, [_p] * 6 + [_i] + [_p] * 6),
     'parlhip_vecnorm_obs_f64': (_i, [_p] * 7 + [_i, _i, _d, _d, _i, _p]),

@@ -710,6 +710,222 @@ __global__ __launch_bounds__(256) void conv3_84_bwd_kernel(
   }
 }
 
+// conv2_84_bwd_kernel: given a1 [32,20,20] and dz2 [64,11,11] (already masked by a2 > 0):
+//   (A) dW2[o][k] += sum_p dz2[o][p] a1pad[c][2 oy + kh][2 ox + kw]    [64 x 121] x [121 x 512], k = c*16 + kh*4 + kw
+//       wave w owns the input channels {w, w+4, ..} (8 k tiles x 4 o tiles = 32 accumulators)
+//   (B) dA1 = the transposed convolution as a gather per output parity class (stride 2, kernel 4, as
+//       in conv12_bwd_u8_mfma_kernel): y = 2 iy + py receives from dz2[o][iy+1-a][ix+1-b] through
+//       taps (py+2a, px+2b); one class per wave: [100 x 256] x [256 x 32], B operand (class slice of
+//       w2, 32 KB) streamed: wt2b[class][ks][nt][lane], k = (o, a, b) = 4 ks + q; dz1 = dA1 * (a1 > 0) -> HBM
+constexpr int kLds2bFloats = 32 * kA1Plane + 64 * kM2b + 128;            // 18,432 + 7,744 + 128 = 26,304 floats = 105,216 B
+constexpr int kPart2 = 64 * 512 + 64;
+
+__global__ __launch_bounds__(256) void conv2_84_bwd_kernel(
+    const float* __restrict__ a1, const float* __restrict__ dz2, const float* __restrict__ wt2b,
+    float* __restrict__ dz1, float* __restrict__ partial, int n_obs) {
+  extern __shared__ float lds[];
+  float* a1p = lds;                       // [32][24][24], zero border
+  float* z2s = lds + 32 * kA1Plane;       // [64][11][11]
+  float* red = z2s + 64 * kM2b;           // [128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, col = lane & 15;
+  f32x4 accw[4][8];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) accw[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dba[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 32 * kA1Plane; i += 256) a1p[i] = 0.0f;
+  const int kh = col >> 2, kw = col & 3;
+  // (B) this wave's parity class; A-operand offsets of its 7 M tiles (100 positions iy, ix < 10)
+  const int py = wave >> 1, px = wave & 1, ta = q >> 1, tb = q & 1;
+  int aoff[7];
+#pragma unroll
+  for (int mt = 0; mt < 7; ++mt) {
+    int m = mt * 16 + col;
+    m = m < 100 ? m : 99;
+    const int iy = m / 10, ix = m - iy * 10;
+    aoff[mt] = (iy + 1 - ta) * kA2 + (ix + 1 - tb);        // z2s[o][iy+1-a][ix+1-b], + o * 121 per k-step
+  }
+#pragma unroll 1
+  for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
+    __syncthreads();
+    const float4* src = reinterpret_cast<const float4*>(a1 + (size_t)n * 32 * kA1 * kA1);
+    for (int i = tid; i < 32 * kA1 * kA1 / 4; i += 256) {
+      const float4 v = src[i];
+      const int e = i * 4, c = e / (kA1 * kA1), r = e - c * kA1 * kA1, y = r / kA1, x = r - y * kA1;
+      float* d = a1p + c * kA1Plane + (y + 2) * kA1P + (x + 2);
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    const float4* sz = reinterpret_cast<const float4*>(dz2 + (size_t)n * 64 * kM2b);
+    for (int i = tid; i < 64 * kM2b / 4; i += 256) reinterpret_cast<float4*>(z2s)[i] = sz[i];
+    __syncthreads();
+    // ---- (A) dW2 ----
+    {
+      int ox = q, zoff = q, boff = kh * kA1P + 2 * q + kw;   // p = 4 ks + q: (oy, ox) = (0, q)
+#pragma clang loop unroll(disable)
+      for (int ks = 0; ks < 31; ++ks) {
+        const bool valid = (ks < 30) | (q == 0);             // p < 121
+        float av[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const float v = z2s[(16 * mt + col) * kM2b + (valid ? zoff : 0)];
+          av[mt] = valid ? v : 0.f;
+          dba[mt] += av[mt];
+        }
+        const float* bb = a1p + wave * kA1Plane + (valid ? boff : 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float b = bb[(4 * j) * kA1Plane];            // input channel c = wave + 4 j
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) accw[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], b, accw[mt][j], 0, 0, 0);
+        }
+        ox += 4;
+        const bool wrap = ox >= kA2;
+        ox -= wrap ? kA2 : 0;
+        zoff += 4;                                           // z2s rows are contiguous: p itself
+        boff += wrap ? 8 + (2 * kA1P - 2 * kA2) : 8;         // two rows down, 22 columns back
+      }
+    }
+    // ---- (B) dz1 for this wave's parity class ----
+    {
+      f32x4 acc[7][2];
+#pragma unroll
+      for (int mt = 0; mt < 7; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      const float* wp = wt2b + (size_t)wave * 64 * 2 * 64 + lane;   // wt2b[class][ks][nt][lane]
+#pragma clang loop unroll_count(2)
+      for (int o = 0; o < 64; ++o) {
+        const float b0 = wp[(o * 2 + 0) * 64], b1v = wp[(o * 2 + 1) * 64];
+        const float* ab = z2s + o * kM2b;
+#pragma unroll
+        for (int mt = 0; mt < 7; ++mt) {
+          const float a = ab[aoff[mt]];
+          acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[mt][0], 0, 0, 0);
+          acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1v, acc[mt][1], 0, 0, 0);
+        }
+      }
+      float* g = dz1 + (size_t)n * 32 * kA1 * kA1;
+#pragma unroll
+      for (int mt = 0; mt < 7; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mo = mt * 16 + q * 4 + r;
+          if (mo < 100) {
+            const int jy = mo / 10, jx = mo - jy * 10, y = 2 * jy + py, x = 2 * jx + px;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const int c = 16 * nt + col;
+              g[c * kA1 * kA1 + y * kA1 + x] = a1p[c * kA1Plane + (y + 2) * kA1P + (x + 2)] > 0.f ? acc[mt][nt][r] : 0.f;
+            }
+          }
+        }
+    }
+  }
+  // ---- partials: dW2[o][k] (o = 16 mt + 4 q + r, k = 16 (wave + 4 j) + col), db2 ----
+  float* P = partial + (size_t)blockIdx.x * kPart2;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[(16 * mt + 4 * q + r) * 512 + 16 * (wave + 4 * j) + col] = accw[mt][j][r];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) red[(mt * 4 + q) * 16 + col] = dba[mt];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int mt = tid >> 4, c = tid & 15;
+    P[64 * 512 + tid] = red[(mt * 4 + 0) * 16 + c] + red[(mt * 4 + 1) * 16 + c] + red[(mt * 4 + 2) * 16 + c] +
+                        red[(mt * 4 + 3) * 16 + c];
+  }
+}
+
+// conv1_84_bwd_kernel: dW1[c][k] += sum_p dz1[c][p] x[ci][4 oy + kh - 1][4 ox + kw - 1] / 255
+//   [32 x 400] x [400 x 256], k = ci*64 + kh*8 + kw; the observation stays uint8 in LDS (the shifted
+//   tile of conv1_84_u8_mfma_kernel) next to the (float)u / 255.0f table; wave w owns the k tiles
+//   {w, w+4, w+8, w+12} x 2 c tiles.
+constexpr int kLds1bFloats = (4 * kPlane84) / 4 + 256 + 32 * kM84 + 64;   // 7,056 + 256 + 12,800 + 64 floats = 80,704 B
+constexpr int kPart1 = 32 * 256 + 32;
+
+__global__ __launch_bounds__(256) void conv1_84_bwd_kernel(
+    const uint8_t* __restrict__ obs, const float* __restrict__ dz1, float* __restrict__ partial, int n_obs) {
+  extern __shared__ float lds[];
+  uint8_t* tile = reinterpret_cast<uint8_t*>(lds);        // [4][84][84] uint8, shifted by the padding
+  float* lut = lds + kPlane84;                            // [256]
+  float* z1s = lut + 256;                                 // [32][400]
+  float* red = z1s + 32 * kM84;                           // [64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, col = lane & 15;
+  f32x4 accw[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accw[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dba[2] = {0.f, 0.f};
+  for (int i = tid; i < kPlane84; i += 256) lds[i] = 0.0f;   // the tile incl. its zero row 0 / column 0
+  __syncthreads();
+  lut[tid] = (float)tid / 255.0f;
+  // B-operand offsets of this lane's 4 k tiles: nt = wave + 4 j -> ci = nt >> 2, kh = 2 (nt & 3) + (col >> 3), kw = col & 7
+  int boff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int nt = wave + 4 * j;
+    boff[j] = (nt >> 2) * kPlane84 + (2 * (nt & 3) + (col >> 3)) * kD84 + (col & 7);
+  }
+#pragma unroll 1
+  for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
+    __syncthreads();
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(obs + (size_t)n * 4 * kPlane84);
+    for (int wi = tid; wi < kPlane84; wi += 256) {
+      const uint32_t v = src[wi];
+      const int i = wi * 4;
+      const int c = i / kPlane84, r = i - c * kPlane84, y = r / kD84, x = r - y * kD84;
+      if (y < kD84 - 1) {
+        uint8_t* d = tile + c * kPlane84 + (y + 1) * kD84 + (x + 1);
+        d[0] = (uint8_t)v; d[1] = (uint8_t)(v >> 8); d[2] = (uint8_t)(v >> 16);
+        if (x + 4 < kD84) d[3] = (uint8_t)(v >> 24);
+      }
+    }
+    const float4* sz = reinterpret_cast<const float4*>(dz1 + (size_t)n * 32 * kM84);
+    for (int i = tid; i < 32 * kM84 / 4; i += 256) reinterpret_cast<float4*>(z1s)[i] = sz[i];
+    __syncthreads();
+    int ox = q, poff = q * 4;                               // p = 4 ks + q: (oy, ox) = (0, q); tile offset (4 oy) * 84 + 4 ox
+#pragma clang loop unroll(disable)
+    for (int ks = 0; ks < 100; ++ks) {
+      const float a0 = z1s[col * kM84 + ks * 4 + q], a1v = z1s[(16 + col) * kM84 + ks * 4 + q];
+      dba[0] += a0;
+      dba[1] += a1v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float b = lut[tile[boff[j] + poff]];
+        accw[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, accw[0][j], 0, 0, 0);
+        accw[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, b, accw[1][j], 0, 0, 0);
+      }
+      ox += 4;
+      const bool wrap = ox >= kO84;
+      ox -= wrap ? kO84 : 0;
+      poff += wrap ? 16 + (4 * kD84 - 4 * kO84) : 16;       // four rows down, 80 columns back
+    }
+  }
+  float* P = partial + (size_t)blockIdx.x * kPart1;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[(16 * mt + 4 * q + r) * 256 + 16 * (wave + 4 * j) + col] = accw[mt][j][r];
+  __syncthreads();
+  if (wave == 0) { red[(0 * 4 + q) * 16 + col] = dba[0]; red[(1 * 4 + q) * 16 + col] = dba[1]; }
+  __syncthreads();
+  if (tid < 32) {
+    const int mt = tid >> 4, c = tid & 15;
+    P[32 * 256 + tid] = red[(mt * 4 + 0) * 16 + c] + red[(mt * 4 + 1) * 16 + c] + red[(mt * 4 + 2) * 16 + c] +
+                        red[(mt * 4 + 3) * 16 + c];
+  }
+}
+
 // out[j] = sum over parts of partial[part][j], fixed order (deterministic)
 __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ partial, int n_parts, int len,
                                                           float* __restrict__ out) {
@@ -847,5 +1063,57 @@ PARLHIP_EXPORT int parlhip_atari84_conv3_bwd_f32(const float* a2, const float* a
   int rc = check_launch();
   if (rc) return rc;
   partial_sum_kernel<<<(kPart3 + 255) / 256, 256, 0, s>>>(workspace, grid, kPart3, dw3_db3);
+  return check_launch();
+}
+
+PARLHIP_EXPORT size_t parlhip_atari84_conv2_bwd_workspace_bytes(int n_obs) {
+  return n_obs <= 0 ? 0 : (size_t)bwd84_grid(n_obs) * kPart2 * sizeof(float);
+}
+
+PARLHIP_EXPORT int parlhip_atari84_conv2_bwd_f32(const float* a1, const float* dz2, const float* wt2b, int n_obs,
+                                                 float* workspace, float* dz1, float* dw2_db2, parlhip_stream_t stream) {
+  if (n_obs <= 0) return n_obs < 0 ? PARLHIP_EINVAL : PARLHIP_OK;
+  if (!a1 || !dz2 || !wt2b || !workspace || !dz1 || !dw2_db2) return PARLHIP_EINVAL;
+  if (((uintptr_t)a1 | (uintptr_t)dz2) & 15u) return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  const size_t lds_bytes = kLds2bFloats * sizeof(float);
+  if (!attr_set) {
+    int rc = check(hipFuncSetAttribute((const void*)conv2_84_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes));
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int grid = bwd84_grid(n_obs);
+  conv2_84_bwd_kernel<<<grid, 256, lds_bytes, s>>>(a1, dz2, wt2b, dz1, workspace, n_obs);
+  int rc = check_launch();
+  if (rc) return rc;
+  partial_sum_kernel<<<(kPart2 + 255) / 256, 256, 0, s>>>(workspace, grid, kPart2, dw2_db2);
+  return check_launch();
+}
+
+PARLHIP_EXPORT size_t parlhip_atari84_conv1_bwd_workspace_bytes(int n_obs) {
+  return n_obs <= 0 ? 0 : (size_t)bwd84_grid(n_obs) * kPart1 * sizeof(float);
+}
+
+PARLHIP_EXPORT int parlhip_atari84_conv1_bwd_f32(const uint8_t* obs, const float* dz1, int n_obs, float* workspace,
+                                                 float* dw1_db1, parlhip_stream_t stream) {
+  if (n_obs <= 0) return n_obs < 0 ? PARLHIP_EINVAL : PARLHIP_OK;
+  if (!obs || !dz1 || !workspace || !dw1_db1) return PARLHIP_EINVAL;
+  if (((uintptr_t)obs & 3u) || ((uintptr_t)dz1 & 15u)) return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  const size_t lds_bytes = kLds1bFloats * sizeof(float);
+  if (!attr_set) {
+    int rc = check(hipFuncSetAttribute((const void*)conv1_84_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes));
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int grid = bwd84_grid(n_obs);
+  conv1_84_bwd_kernel<<<grid, 256, lds_bytes, s>>>(obs, dz1, workspace, n_obs);
+  int rc = check_launch();
+  if (rc) return rc;
+  partial_sum_kernel<<<(kPart1 + 255) / 256, 256, 0, s>>>(workspace, grid, kPart1, dw1_db1);
   return check_launch();
 }

@@ -143,6 +143,12 @@ class AtariModel84(Model):
             # conv2 + conv3 fused (a2 stays in LDS, weights streamed from L2 in MFMA operand order)
             x = ops.atari84_conv23(x, self.conv2.weight, self.conv2.bias, self.conv3.weight, self.conv3.bias)
             return F.relu(self.fc(x))
+        if obs.dtype == torch.uint8 and obs.is_cuda and obs.shape[0] > 0:
+            # the learner's path: the same forward kernels under ONE autograd node whose backward is three
+            # per-layer MFMA kernels (ops.Atari84TrunkFn): no im2col; fc and the heads stay rocBLAS GEMMs
+            x = ops.Atari84TrunkFn.apply(obs, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                         self.conv3.weight, self.conv3.bias)
+            return F.relu(self.fc(x))
         x = F.relu(self.conv1(obs.float() / 255.0))
         x = F.relu(self.conv2(x))
         x = F.relu(self.conv3(x))

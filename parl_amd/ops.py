@@ -404,6 +404,66 @@ def atari84_conv3_backward(a2, a3, grad_a3, conv3_weight):
     return dz2, dw3, out[64 * 576:].clone()
 
 
+def atari84_conv2_backward(a1, dz2, conv2_weight):
+    """backward of conv2 + ReLU: (dz1 [n,32,20,20] = grad w.r.t. a1 masked by a1 > 0,
+    d conv2.weight [64,32,4,4], d conv2.bias [64]); deterministic"""
+    n = a1.shape[0]
+    a1, dz2 = _f32(a1, 'a1'), _f32(dz2, 'dz2')
+    if a1.numel() != n * 12800 or dz2.numel() != n * 7744:
+        raise N.ParlHipError('atari84_conv2_backward: a1 [n,32,20,20], dz2 [n,64,11,11]')
+    w2 = _f32(conv2_weight.detach(), 'conv2_weight')
+    # per output parity class (py, px): B[k = (o, a, b)][c] = w2[o][c][py + 2a][px + 2b]
+    wt2b = torch.stack([_mfma_b_layout(w2[:, :, py::2, px::2].permute(1, 0, 2, 3).reshape(32, 256))
+                        for py in (0, 1) for px in (0, 1)]).contiguous()
+    dev = a1.device
+    dz1 = torch.empty((n, 32, 20, 20), dtype=torch.float32, device=dev)
+    out = torch.empty(64 * 512 + 64, dtype=torch.float32, device=dev)
+    ws = torch.empty(max(N.lib().parlhip_atari84_conv2_bwd_workspace_bytes(n) // 4, 1), dtype=torch.float32, device=dev)
+    N.check(
+        N.lib().parlhip_atari84_conv2_bwd_f32(N.ptr(a1.contiguous()), N.ptr(dz2.contiguous()), N.ptr(wt2b), n, N.ptr(ws),
+                                             N.ptr(dz1), N.ptr(out), N.stream_ptr()), 'parlhip_atari84_conv2_bwd_f32')
+    return dz1, out[:64 * 512].view(64, 32, 4, 4), out[64 * 512:]
+
+
+def atari84_conv1_backward(obs, dz1):
+    """backward of conv1 w.r.t. its parameters: (d conv1.weight [32,4,8,8], d conv1.bias [32]); deterministic"""
+    if obs.dtype != torch.uint8 or obs.dim() != 4 or tuple(obs.shape[1:]) != (4, 84, 84):
+        raise N.ParlHipError('atari84_conv1_backward: obs must be uint8 [n,4,84,84]')
+    n = obs.shape[0]
+    dz1 = _f32(dz1, 'dz1')
+    if dz1.numel() != n * 12800:
+        raise N.ParlHipError('atari84_conv1_backward: dz1 must be [n,32,20,20]')
+    dev = obs.device
+    out = torch.empty(32 * 256 + 32, dtype=torch.float32, device=dev)
+    ws = torch.empty(max(N.lib().parlhip_atari84_conv1_bwd_workspace_bytes(n) // 4, 1), dtype=torch.float32, device=dev)
+    N.check(
+        N.lib().parlhip_atari84_conv1_bwd_f32(N.ptr(obs.contiguous()), N.ptr(dz1.contiguous()), n, N.ptr(ws), N.ptr(out),
+                                             N.stream_ptr()), 'parlhip_atari84_conv1_bwd_f32')
+    return out[:32 * 256].view(32, 4, 8, 8), out[32 * 256:]
+
+
+class Atari84TrunkFn(torch.autograd.Function):
+    """autograd node for the three convolutions of the A2C Atari network on uint8 observations:
+    forward = conv1 (MFMA, u8 -> a1) + fused conv2/conv3 (a2, a3), backward = three per-layer MFMA
+    kernels (conv3: dW3 + dz2; conv2: dW2 + dz1; conv1: dW1).  No im2col, deterministic; the
+    observations get no gradient."""
+
+    @staticmethod
+    def forward(ctx, obs, w1, b1, w2, b2, w3, b3):
+        a1 = atari84_conv1(obs, w1, b1)
+        a3, a2 = atari84_conv23(a1, w2, b2, w3, b3, save_a2=True)
+        ctx.save_for_backward(obs, a1, a2, a3, w2, w3)
+        return a3
+
+    @staticmethod
+    def backward(ctx, grad_a3):
+        obs, a1, a2, a3, w2, w3 = ctx.saved_tensors
+        dz2, dw3, db3 = atari84_conv3_backward(a2, a3, grad_a3, w3)
+        dz1, dw2, db2 = atari84_conv2_backward(a1, dz2, w2)
+        dw1, db1 = atari84_conv1_backward(obs, dz1)
+        return None, dw1, db1, dw2, db2, dw3, db3
+
+
 def _f64(t, name):
     if t.dtype != torch.float64 or not t.is_cuda:
         raise N.ParlHipError('%s must be a float64 CUDA tensor' % name)
