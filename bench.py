@@ -175,7 +175,7 @@ def extra_legs(dev):
         g = _event_time(lambda: ops.gae(rew, val, dn, nv, 0.99, 1.0))
         by = T * E * 17
         return {'workload': 'BASELINE configs[1]: PongNoFrameskip-v4 A2C, 256 on-GPU envs, 84x84, T=20, lambda=1.0; '
-                            'rollout then update (synchronous A2C), learner convs GEMM-lowered',
+                            'rollout then update (synchronous A2C), convolutions on the MFMA kernels',
                 'env_frames_per_s': K * T * E * 4 / dt, 'updates_per_s': K / dt, 'ms_per_step': dt / K * 1e3, 'steps': K,
                 'gae_kernel': {'shape': 'T=20 B=256 u8 dones', 'us': g * 1e6, 'bytes': by, 'GBps': by / g / 1e9,
                                'frac_of_hbm_peak': by / g / 1e9 / HBM_PEAK_GBPS,
@@ -188,7 +188,10 @@ def extra_legs(dev):
         model = AtariModel84(env.act_dim).to(dev)
         alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
                                      clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
-        alg.max_learn_rows = 6400  # the GEMM-lowered 84x84 convs need ~2 MB of im2col per row
+        # the update in 8 chunks of 128 sequences: the backward kernels are persistent (one workgroup per CU
+        # until the chunk is done) and share no CU with the actors' conv kernels (LDS), so one 51,200-row
+        # pass stalls the rollout for its whole length (measured: 1.26 M frames/s in one pass, 1.58 M in 8)
+        alg.max_learn_rows = 6400
         pipe = AsyncActorLearner(alg, [env], T, seed=4)
         pipe.prime()
         pipe.step(0.001, -0.01)
@@ -201,9 +204,9 @@ def extra_legs(dev):
         dt = time.time() - t0
         assert np.isfinite(float(loss.total_loss))
         env.check_faults()
-        return {'workload': 'PongNoFrameskip-v4 IMPALA V-trace at 84x84, 1024 actors, T=50, actor/learner overlapped; ONE '
-                            'update per step on the 51,200-row batch (8 chunks of 128 sequences accumulated), learner convs '
-                            'GEMM-lowered (the fused MFMA learner path exists for the 42x42 model only)',
+        return {'workload': 'PongNoFrameskip-v4 IMPALA V-trace at 84x84 (the north-star frame size), 1024 actors, T=50, '
+                            'actor/learner overlapped; ONE update per step on the 51,200-row batch (8 chunks accumulated); convolutions of actors '
+                            'and learner on the MFMA kernels (conv1_84 / conv23_84 forward, three backward kernels)',
                 'env_frames_per_s': K * T * E * 4 / dt, 'updates_per_s': K / dt, 'ms_per_step': dt / K * 1e3, 'steps': K}
 
     # ---- configs[3] per GPU: Breakout IMPALA, 1024 of the 8192 actors, A=4 ----
@@ -287,6 +290,11 @@ def main():
     ap.add_argument('--game', default='PongNoFrameskip-v4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--actor-groups', type=int, default=1, help='env groups (actor streams) per GPU')
+    ap.add_argument('--learn-rows', type=int, default=6400,
+                    help='rows per forward / backward pass of the ONE learner update per step (gradients accumulated, '
+                    'IMPALA.max_learn_rows; 0: the whole batch in one pass).  The backward kernels are persistent and '
+                    'share no CU with the actors\' conv kernels, so shorter passes stall the rollout less: '
+                    '2.54 M frames/s in one pass, 2.61-2.64 M at 6400 rows')
     ap.add_argument('--quick', action='store_true',
                     help='headline workload only: skip the saturating-shape roofline and the extra config legs')
     ap.add_argument('--no-overlap', action='store_true',
@@ -323,6 +331,7 @@ def main():
     alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=cfg['gamma'], vf_loss_coeff=cfg['vf_loss_coeff'],
                                  clip_rho_threshold=cfg['clip_rho_threshold'],
                                  clip_pg_rho_threshold=cfg['clip_pg_rho_threshold'])
+    alg.max_learn_rows = args.learn_rows or None
     pdist.broadcast_model(model)
     if pdist.active():  # also a one-rank group (PARL_AMD_FORCE_DIST=1): the whole DP path over RCCL
         alg.grad_hook = pdist.FlatGradAllReduce(model)
@@ -401,6 +410,7 @@ def main():
             'envs_per_gpu': E, 'sample_batch_steps': T, 'obs_dim': dim, 'train_batch': T * E * world,
             'frame_skip': 4, 'parallelism': 'dp%d (envs sharded by rank, grad all-reduce)' % world,
             'actor_learner_overlap': not args.no_overlap, 'actor_groups': G,
+            'learner_rows_per_pass': args.learn_rows or T * E,
             'collectives': (('none (single process)' if not pdist.active() else 'RCCL, one-rank group (PARL_AMD_FORCE_DIST)')
                             if world == 1 else
                             ('gloo, ranks SHARE GPUs (fewer devices than ranks: functional run, not a scaling number)'

@@ -51,6 +51,21 @@ def main():
             o = ob.float()
         s = timeit(lambda: alg.learn(o, act, bl, rew, dn, 1e-4, -0.01, time_major=True), iters=5, warmup=2)
         res['%s_T%d_E%d' % (name, T, E)] = {'ms': s * 1e3}
+    # the 84x84 model (A2C network): one A2C.learn at the configs[1] batch and at an IMPALA-sized one
+    from parl_amd.models import AtariModel84
+    m84 = AtariModel84(6).to(dev)
+    a2c = parl.algorithms.A2C(m84, vf_loss_coeff=0.5)
+    for rows in (5120, 25600):
+        o84 = torch.randint(0, 256, (rows, 4, 84, 84), dtype=torch.uint8, device=dev)
+        a84 = torch.randint(0, 6, (rows, ), device=dev)
+        adv, tgt = torch.randn(rows, device=dev), torch.randn(rows, device=dev)
+        s = timeit(lambda: a2c.learn(o84, a84, adv, tgt, 1e-4, -0.01), iters=5, warmup=2)
+        res['a2c_learn_84_u8_mfma_rows%d' % rows] = {'ms': s * 1e3}
+        if rows == 5120:
+            of = o84.float()
+            s = timeit(lambda: a2c.learn(of, a84, adv, tgt, 1e-4, -0.01), iters=5, warmup=2)
+            res['a2c_learn_84_f32_gemm_rows%d' % rows] = {'ms': s * 1e3}
+        del o84
     for m in (1024, 8192):
         a1 = torch.relu(torch.randn(m, 32, 20, 20, device=dev))
         w2c, b2c = torch.randn(64, 32, 4, 4, device=dev) * 0.05, torch.zeros(64, device=dev)
