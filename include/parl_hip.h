@@ -201,6 +201,14 @@ int parlhip_frame_post_tables_init(void* host_blob, int dim);
 int parlhip_frame_post_u8(const uint8_t* frames0, const uint8_t* frames1, int64_t in_stride,
                           int fmt, const uint8_t* flags, uint8_t* out, int64_t out_stride,
                           int E, int dim, const void* tables_dev, parlhip_stream_t stream);
+/* The same plus the FrameStack bookkeeping of parlhip_stack_since_update_u8 in ONE launch (the device
+ * env's per-step path): since_next[e] = (flags[e] & 2) ? 0 : min(since_prev[e] + 1, 3); since_prev
+ * may be NULL (treated as 0).  dim <= 84.                                                        */
+int parlhip_frame_post_since_u8(const uint8_t* frames0, const uint8_t* frames1, int64_t in_stride, int fmt,
+                                const uint8_t* flags, uint8_t* out, int64_t out_stride, int E, int dim,
+                                const void* tables_dev, const uint8_t* since_prev, uint8_t* since_next,
+                                parlhip_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------
  * Vectorised Atari env: VectorEnv([wrap_deepmind(gym.make(id), dim, obs_format='NCHW')]*E)

@@ -50,6 +50,7 @@ SIGNATURES = {
     'parlhip_frame_post_tables_bytes': (_sz, [_i]),
     'parlhip_frame_post_tables_init': (_i, [_p, _i]),
     'parlhip_frame_post_u8': (_i, [_p, _p, _i64, _i, _p, _p, _i64, _i, _i, _p, _p]),
+    'parlhip_frame_post_since_u8': (_i, [_p, _p, _i64, _i, _p, _p, _i64, _i, _i, _p, _p, _p, _p]),
     'parlhip_atari_state_bytes': (_sz, []),
     'parlhip_atari_frame_bytes': (_sz, []),
     'parlhip_atari_rom_table_bytes': (_sz, [ctypes.c_uint32]),

@@ -30,13 +30,14 @@ DEVI uint32_t gray_of_colors(uint32_t c0, uint32_t c1, const uint32_t* pal) {
 // LDS of one workgroup: gray frame + palette + the tap tables, sized by the bound of area_tab
 // (<= src + 2 * dst taps per axis) so that dim <= 84 fits 4 workgroups per CU (<= 40 KB each)
 static inline size_t frame_post_lds_bytes(int dim) {
-  return (size_t)kFrameBytes + 128 * 4 + (size_t)(kW + kH + 4 * dim) * sizeof(Tap) + 2 * (size_t)(dim + 1) * 4;
+  return (size_t)kFrameBytes + 128 * 4 + (size_t)(kW + kH + 4 * dim) * sizeof(Tap) + 2 * (size_t)(dim + 1) * 4 + 128;  // + g1[128]
 }
 
 __global__ __launch_bounds__(512) void frame_post_kernel(
     const uint8_t* __restrict__ frames0, const uint8_t* __restrict__ frames1, int64_t in_stride,
     int fmt, const uint8_t* __restrict__ flags, uint8_t* __restrict__ out, int64_t out_stride,
-    int dim, const uint8_t* __restrict__ blob) {
+    int dim, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ since_prev,
+    uint8_t* __restrict__ since_next) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fp_lds[];
   uint8_t* gray = fp_lds;                                   // [kFrameBytes] (33,600: 16-byte multiple)
   uint32_t* pal = (uint32_t*)(fp_lds + kFrameBytes);        // [128]
@@ -45,6 +46,10 @@ __global__ __launch_bounds__(512) void frame_post_kernel(
   int* s_xstart = (int*)(s_yt + (kH + 2 * dim));            // [dim + 1]
   int* s_ystart = s_xstart + (dim + 1);                     // [dim + 1]
   const int e = blockIdx.x;
+  if (since_next && threadIdx.x == 0) {  // FrameStack bookkeeping of this env (since_update_kernel), same launch
+    const int p = since_prev ? since_prev[e] : 0;
+    since_next[e] = (flags[e] & 2) ? 0 : (uint8_t)(p + 1 > 3 ? 3 : p + 1);
+  }
   const int* hdr = (const int*)blob;
   const int* xstart = (const int*)(blob + hdr[3]);
   const int* ystart = (const int*)(blob + hdr[4]);
@@ -65,19 +70,39 @@ __global__ __launch_bounds__(512) void frame_post_kernel(
   const uint8_t* f0 = frames0 + (size_t)e * in_stride;
   const uint8_t* f1 = single ? f0 : frames1 + (size_t)e * in_stride;
   if (fmt == 1) {
+    // gray of ONE colour byte (both frames agree: the static part of every picture) from a 128-entry
+    // table built here from the palette with the same integer formula; 16 pixels per lane and step,
+    // and a wave whose 1024 pixels all agree never runs the two-colour path (max per channel)
+    uint8_t* g1 = (uint8_t*)s_ystart + 4 * (dim + 1);      // [128] bytes behind the tap tables (see lds size)
+    if (threadIdx.x < 128) {
+      const uint32_t c = pal[threadIdx.x];
+      g1[threadIdx.x] = (uint8_t)((((c >> 16) & 255) * 4899u + ((c >> 8) & 255) * 9617u + (c & 255) * 1868u + 8192u) >> 14);
+    }
+    __syncthreads();
     const uint4* a4 = (const uint4*)f0;
     const uint4* b4 = (const uint4*)f1;
     for (int i = threadIdx.x; i < kFrameBytes / 16; i += blockDim.x) {
       const uint4 a = a4[i], b = b4[i];
       const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
       uint32_t ow[4];
+      const bool same = (((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) & 0xfefefefeu) == 0u;
+      if (__ballot(!same) == 0ull) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        uint32_t o = 0;
+        for (int q = 0; q < 4; ++q) {
+          uint32_t o = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          o |= gray_of_colors((aw[q] >> (8 * j)) & 255, (bw[q] >> (8 * j)) & 255, pal) << (8 * j);
-        ow[q] = o;
+          for (int j = 0; j < 4; ++j) o |= (uint32_t)g1[(aw[q] >> (8 * j + 1)) & 127] << (8 * j);
+          ow[q] = o;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t o = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            o |= gray_of_colors((aw[q] >> (8 * j)) & 255, (bw[q] >> (8 * j)) & 255, pal) << (8 * j);
+          ow[q] = o;
+        }
       }
       ((uint4*)gray)[i] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
     }
@@ -93,26 +118,68 @@ __global__ __launch_bounds__(512) void frame_post_kernel(
   }
   __syncthreads();
   uint8_t* o = out + (size_t)e * out_stride;
-  for (int p = threadIdx.x; p < dim * dim; p += blockDim.x) {
-    const int dy = p / dim, dx = p - dy * dim;
-    const int x0 = s_xstart[dx], x1 = s_xstart[dx + 1];
-    const int j0 = s_ystart[dy], j1 = s_ystart[dy + 1];
-    float sum = 0.f;
-    for (int j = j0; j < j1; ++j) {
-      const Tap ty = s_yt[j];
-      const uint8_t* S = gray + ty.si * kW;
-      float buf = 0.f;
-      for (int k = x0; k < x1; ++k) {
-        const Tap tx = s_xt[k];
-        buf = __fadd_rn(buf, __fmul_rn((float)S[tx.si], tx.alpha));
-      }
-      const float tmp = __fmul_rn(ty.alpha, buf);
-      sum = (j == j0) ? tmp : __fadd_rn(sum, tmp);
+  // a thread keeps ONE output column dx (its x taps live in registers) and walks the rows in steps of
+  // blockDim / dim; float operation order as in the oracle: buf = sum_k S[x_k] * alpha_k in tap order,
+  // sum = beta_0 * buf_0, then += beta_j * buf_j
+  const int rows_per_pass = blockDim.x / dim;
+  if ((int)threadIdx.x < rows_per_pass * dim && rows_per_pass > 0) {
+    const int dy0 = threadIdx.x / dim, dx = threadIdx.x - dy0 * dim;
+    const int x0 = s_xstart[dx], nxt = s_xstart[dx + 1] - x0;
+    constexpr int kMaxXT = 8;
+    int xsi[kMaxXT];
+    float xal[kMaxXT];
+#pragma unroll
+    for (int k = 0; k < kMaxXT; ++k) {
+      const Tap tx = s_xt[x0 + (k < nxt ? k : 0)];
+      xsi[k] = tx.si;
+      xal[k] = tx.alpha;
     }
-    // cv::saturate_cast<uchar>(float): cvRound (round half to even) then clamp
-    int r = (int)__builtin_rintf(sum);
-    r = r < 0 ? 0 : (r > 255 ? 255 : r);
-    o[p] = (uint8_t)r;
+    for (int dy = dy0; dy < dim; dy += rows_per_pass) {
+      const int j0 = s_ystart[dy], j1 = s_ystart[dy + 1];
+      float sum = 0.f;
+      for (int j = j0; j < j1; ++j) {
+        const Tap ty = s_yt[j];
+        const uint8_t* S = gray + ty.si * kW;
+        float buf = 0.f;
+        if (nxt <= kMaxXT) {
+#pragma unroll
+          for (int k = 0; k < kMaxXT; ++k)
+            if (k < nxt) buf = __fadd_rn(buf, __fmul_rn((float)S[xsi[k]], xal[k]));
+        } else {  // dim < 20: more than 8 source columns per output column
+          for (int k = x0; k < x0 + nxt; ++k) {
+            const Tap tx = s_xt[k];
+            buf = __fadd_rn(buf, __fmul_rn((float)S[tx.si], tx.alpha));
+          }
+        }
+        const float tmp = __fmul_rn(ty.alpha, buf);
+        sum = (j == j0) ? tmp : __fadd_rn(sum, tmp);
+      }
+      // cv::saturate_cast<uchar>(float): cvRound (round half to even) then clamp
+      int r = (int)__builtin_rintf(sum);
+      r = r < 0 ? 0 : (r > 255 ? 255 : r);
+      o[dy * dim + dx] = (uint8_t)r;
+    }
+  } else if (rows_per_pass == 0) {  // dim > blockDim: generic walk
+    for (int p = threadIdx.x; p < dim * dim; p += blockDim.x) {
+      const int dy = p / dim, dx = p - dy * dim;
+      const int x0 = s_xstart[dx], x1 = s_xstart[dx + 1];
+      const int j0 = s_ystart[dy], j1 = s_ystart[dy + 1];
+      float sum = 0.f;
+      for (int j = j0; j < j1; ++j) {
+        const Tap ty = s_yt[j];
+        const uint8_t* S = gray + ty.si * kW;
+        float buf = 0.f;
+        for (int k = x0; k < x1; ++k) {
+          const Tap tx = s_xt[k];
+          buf = __fadd_rn(buf, __fmul_rn((float)S[tx.si], tx.alpha));
+        }
+        const float tmp = __fmul_rn(ty.alpha, buf);
+        sum = (j == j0) ? tmp : __fadd_rn(sum, tmp);
+      }
+      int r = (int)__builtin_rintf(sum);
+      r = r < 0 ? 0 : (r > 255 ? 255 : r);
+      o[p] = (uint8_t)r;
+    }
   }
 }
 
@@ -263,7 +330,22 @@ PARLHIP_EXPORT int parlhip_frame_post_u8(const uint8_t* frames0, const uint8_t* 
     }
   }
   frame_post_kernel<<<E, 512, lds, (hipStream_t)stream>>>(frames0, frames1, in_stride, fmt, flags, out,
-                                                          out_stride, dim, (const uint8_t*)tables_dev);
+                                                          out_stride, dim, (const uint8_t*)tables_dev, nullptr, nullptr);
+  return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_frame_post_since_u8(const uint8_t* frames0, const uint8_t* frames1, int64_t in_stride,
+                                               int fmt, const uint8_t* flags, uint8_t* out, int64_t out_stride, int E,
+                                               int dim, const void* tables_dev, const uint8_t* since_prev,
+                                               uint8_t* since_next, parlhip_stream_t stream) {
+  if (E < 0 || dim < 1 || dim > 84 || (fmt != 0 && fmt != 1)) return PARLHIP_EINVAL;
+  if (E == 0) return PARLHIP_OK;
+  if (!frames0 || !out || !tables_dev || !flags || !since_next) return PARLHIP_EINVAL;
+  if (fmt == 1 && ((reinterpret_cast<uintptr_t>(frames0) | (uintptr_t)in_stride |
+                    (frames1 ? reinterpret_cast<uintptr_t>(frames1) : 0)) & 15))
+    return PARLHIP_EINVAL;
+  frame_post_kernel<<<E, 512, frame_post_lds_bytes(dim), (hipStream_t)stream>>>(
+      frames0, frames1, in_stride, fmt, flags, out, out_stride, dim, (const uint8_t*)tables_dev, since_prev, since_next);
   return check_launch();
 }
 

@@ -104,18 +104,15 @@ class DeviceVectorEnv(object):
 
     # ---------------------------------------------------------------- internals
     def _frame_post(self, slot):
+        # max-2 + gray + INTER_AREA into ring[slot] and the FrameStack `since` counters, one launch
         L = N.lib()
-        out = self.ring[slot]
-        N.check(
-            L.parlhip_frame_post_u8(
-                N.ptr(self.raw_frames), self.raw_frames.data_ptr() + 210 * 160, 2 * 210 * 160, 1,
-                N.ptr(self.obs_flags), N.ptr(out), self.fsz, self.envs_num, self.dim,
-                N.ptr(self.fp_tables), N.stream_ptr()), 'parlhip_frame_post_u8')
         prev = self.since[slot - 1] if slot > 0 else None
         N.check(
-            L.parlhip_stack_since_update_u8(
-                N.ptr(self.obs_flags), N.ptr(prev) if prev is not None else None,
-                N.ptr(self.since[slot]), self.envs_num, N.stream_ptr()), 'stack_since_update')
+            L.parlhip_frame_post_since_u8(
+                N.ptr(self.raw_frames), self.raw_frames.data_ptr() + 210 * 160, 2 * 210 * 160, 1,
+                N.ptr(self.obs_flags), N.ptr(self.ring[slot]), self.fsz, self.envs_num, self.dim,
+                N.ptr(self.fp_tables), N.ptr(prev) if prev is not None else None, N.ptr(self.since[slot]),
+                N.stream_ptr()), 'parlhip_frame_post_since_u8')
 
     def gather(self, slots, envs, out=None):
         """Stacked obs u8 [n,4,dim,dim] for (ring slot, env) pairs (int32 tensors)."""
