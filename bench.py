@@ -72,7 +72,7 @@ def pmc_traffic(key):
     shape (profiles/r01_scan_hbm_traffic.json, produced by tools/prof_traffic.sh: separate
     FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction).  bench.py cannot run under two
     rocprofv3 passes itself; the source file is named next to the number."""
-    for name in ('r01e_scan_hbm_traffic.json', 'r01_scan_hbm_traffic.json'):
+    for name in ('r02_hbm_traffic.json', 'r01e_scan_hbm_traffic.json', 'r01_scan_hbm_traffic.json'):
         try:
             t = json.load(open(os.path.join(ROOT, 'profiles', name)))[key]
             return {'traffic': t['hbm_traffic_bytes'], 'traffic_source': 'profiles/%s:%s' % (name, key)}
@@ -466,8 +466,9 @@ def main():
         out['roofline_frame_post'] = {
             'kernel': 'frame_post_kernel + since_update_kernel (max-2, gray, INTER_AREA %dx%d, E=%d)' % (dim, dim, Eg),
             'bound': 'hbm', 'achieved': fpb / fps / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-            'frac': fpb / fps / 1e9 / HBM_PEAK_GBPS, 'traffic': None, 'bytes_per_launch': fpb,
+            'frac': fpb / fps / 1e9 / HBM_PEAK_GBPS, 'bytes_per_launch': fpb,
         }
+        out['roofline_frame_post'].update(pmc_traffic('frame_post_E%d_d%d' % (Eg, dim)))
         es = env_timer.mean_seconds()
         # the dominant kernel, for completeness: algorithmic HBM bytes of one VectorEnv.step launch
         # (per env: 512 B state read + written, two 33,600 B colour frames written, action / reward /

@@ -70,5 +70,34 @@ flush_cache()
 ops.impala_loss(bl, tl, act, rw, dn, vl, 0.99)
 out['impala_loss_T50_B1024_A6'] = {'kernel': 'impala_loss_wave_kernel', 'read': T * B * (2 * A * 4 + 8 + 4 + 1 + 4),
                                    'write': (T - 1) * B * 8 + T * B * (4 * A + 4)}
+del bl, tl, act, rw, dn, vl
+# --- frame_post at the bench shape (1024 envs, 42x42): two 33,600 B colour frames in, 1,764 B out per env
+from parl_amd.env import DeviceVectorEnv  # noqa: E402
+env = DeviceVectorEnv('PongNoFrameskip-v4', 1024, dim=42, horizon=8, seed=1, device=dev)
+env.reset()
+env.step_async(torch.zeros(1024, dtype=torch.int64, device=dev))
+flush_cache()
+env._frame_post(2)
+out['frame_post_E1024_d42'] = {'kernel': 'frame_post_kernel', 'read': 1024 * 2 * 33600, 'write': 1024 * (1764 + 1)}
+del env
+# --- the conv kernels (compute-bound; traffic = are activations / observations read once?)
+n = 8192
+obs = torch.randint(0, 256, (n, 4, 42, 42), dtype=torch.uint8, device=dev)
+w1, b1 = torch.randn(16, 4, 4, 4, device=dev) * 0.2, torch.zeros(16, device=dev)
+w2, b2 = torch.randn(32, 16, 4, 4, device=dev) * 0.1, torch.zeros(32, device=dev)
+flush_cache()
+a2 = ops.atari42_conv12(obs, w1, b1, w2, b2)
+out['conv12_fwd_n8192'] = {'kernel': 'conv12_u8_mfma_kernel', 'read': n * 7056, 'write': n * 15488}
+dy = torch.randn((n, 3872), device=dev)
+flush_cache()
+ops.atari42_conv12_backward(obs, w1, b1, w2, a2, dy)
+out['conv12_bwd_n8192'] = {'kernel': 'conv12_bwd_u8_mfma_kernel', 'read': n * (7056 + 2 * 15488), 'write': 512 * 9264 * 4}
+del obs, a2, dy
+a1 = torch.relu(torch.randn(n, 32, 20, 20, device=dev))
+w2c, w3c = torch.randn(64, 32, 4, 4, device=dev) * 0.05, torch.randn(64, 64, 3, 3, device=dev) * 0.05
+z = torch.zeros(64, device=dev)
+flush_cache()
+ops.atari84_conv23(a1, w2c, z, w3c, z)
+out['conv23_84_fwd_n8192'] = {'kernel': 'conv23_84_mfma_kernel', 'read': n * 51200, 'write': n * 20736}
 torch.cuda.synchronize()
 print(json.dumps(out))
