@@ -35,7 +35,7 @@ from parl_amd import dist as pdist  # noqa: E402
 from parl_amd import ops  # noqa: E402
 from parl_amd.env import DeviceVectorEnv  # noqa: E402
 from parl_amd.models import AtariModel42, AtariModel84  # noqa: E402
-from parl_amd.rollout import AsyncActorLearner, DeviceRollout  # noqa: E402
+from parl_amd.rollout import AsyncActorLearner, DeviceRollout, ElasticDeviceRollout  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
 
@@ -212,24 +212,31 @@ def extra_legs(dev):
     # ---- configs[3] per GPU: Breakout IMPALA, 1024 of the 8192 actors, A=4 ----
     def breakout_c4():
         E, T, K = 1024, 50, 3
-        env = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=42, horizon=T, seed=9, device=dev)
+        # elastic launches: an env inside a life-loss reset drops out of the next launches instead of making
+        # every launch 16 frames long (ElasticDeviceRollout); the env's horizon bounds the launches of a batch
+        env = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=42, horizon=4 * T + 32, seed=9, device=dev)
         model = AtariModel42(env.act_dim).to(dev)
         alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
                                      clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
-        pipe = AsyncActorLearner(alg, [env], T, seed=5)
+        alg.max_learn_rows = 6400
+        pipe = AsyncActorLearner(alg, [env], T, seed=5, elastic=True)
         pipe.prime()
         pipe.step(0.001, -0.01)
         pipe.synchronize()
         t0 = time.time()
+        launches = 0
         for _ in range(K):
             loss, kl = pipe.step(0.001, -0.01)
+            launches += pipe.rollout.launches
         pipe.synchronize()
         torch.cuda.synchronize()
         dt = time.time() - t0
         assert np.isfinite(float(loss.total_loss))
         env.check_faults()
         return {'workload': 'BASELINE configs[3], one GPU\'s share: BreakoutNoFrameskip-v4 IMPALA, 1024 of 8192 actors, '
-                            'A=4, 42x42, T=50, actor/learner overlapped',
+                            'A=4, 42x42, T=50, actor/learner overlapped, elastic launches (<= 4 frames per env and launch; '
+                            'frames counted = 4 per agent step, the reset sequences\' own frames are not counted)',
+                'launches_per_batch': launches / K,
                 'env_frames_per_s': K * T * E * 4 / dt, 'updates_per_s': K / dt, 'ms_per_step': dt / K * 1e3, 'steps': K}
 
     # ---- configs[4]: the PPO scans at HalfCheetah shapes (T=2048, E=4096; minibatch 262,144) ----
@@ -295,6 +302,8 @@ def main():
                     'IMPALA.max_learn_rows; 0: the whole batch in one pass).  The backward kernels are persistent and '
                     'share no CU with the actors\' conv kernels, so shorter passes stall the rollout less: '
                     '2.54 M frames/s in one pass, 2.61-2.64 M at 6400 rows')
+    ap.add_argument('--elastic', choices=('auto', 'on', 'off'), default='auto',
+                    help='elastic launches (ElasticDeviceRollout): auto = games with lives (Breakout)')
     ap.add_argument('--quick', action='store_true',
                     help='headline workload only: skip the saturating-shape roofline and the extra config legs')
     ap.add_argument('--no-overlap', action='store_true',
@@ -324,7 +333,9 @@ def main():
     G = 1 if args.no_overlap else max(1, args.actor_groups)
     assert E % G == 0
     Eg = E // G
-    envs = [DeviceVectorEnv(args.game, Eg, dim=dim, horizon=T, seed=1234, env_id0=rank * E + g * Eg, device=dev)
+    elastic = args.elastic == 'on' or (args.elastic == 'auto' and 'Breakout' in args.game and G == 1)
+    envs = [DeviceVectorEnv(args.game, Eg, dim=dim, horizon=4 * T + 32 if elastic else T, seed=1234,
+                            env_id0=rank * E + g * Eg, device=dev)
             for g in range(G)]
     env = envs[0]
     model = (AtariModel42 if dim == 42 else AtariModel84)(env.act_dim).to(dev)
@@ -347,11 +358,12 @@ def main():
     env_timer, fp_timer = KernelTimer(), KernelTimer()
     for e in envs:
         e.step_async = env_timer.wrap(e.step_async)
+        e.step_elastic_async = env_timer.wrap(e.step_elastic_async)
         e._frame_post = fp_timer.wrap(e._frame_post)
 
     if args.no_overlap:
         pipe = None
-        rollout = DeviceRollout(env, T, seed=99)
+        rollout = (ElasticDeviceRollout if elastic else DeviceRollout)(env, T, seed=99)
 
         def step():
             batch = rollout.collect(model)
@@ -364,7 +376,7 @@ def main():
     else:
         # IMPALA's actor/learner decoupling on one GPU: the learner update on batch i-1 runs on its
         # own stream while the actors collect batch i (behaviour policy lags by one update)
-        pipe = AsyncActorLearner(alg, envs, T, seed=99)
+        pipe = AsyncActorLearner(alg, envs, T, seed=99, elastic=elastic)
         rollout = pipe.rollout
         pipe.prime()  # untimed: every timed step = one rollout + one learner update
 
@@ -409,7 +421,7 @@ def main():
             'workload': 'BASELINE configs[2]: PongNoFrameskip-v4 IMPALA V-trace, %d actors per GPU' % E,
             'envs_per_gpu': E, 'sample_batch_steps': T, 'obs_dim': dim, 'train_batch': T * E * world,
             'frame_skip': 4, 'parallelism': 'dp%d (envs sharded by rank, grad all-reduce)' % world,
-            'actor_learner_overlap': not args.no_overlap, 'actor_groups': G,
+            'actor_learner_overlap': not args.no_overlap, 'actor_groups': G, 'elastic_launches': elastic,
             'learner_rows_per_pass': args.learn_rows or T * E,
             'collectives': (('none (single process)' if not pdist.active() else 'RCCL, one-rank group (PARL_AMD_FORCE_DIST)')
                             if world == 1 else

@@ -10,7 +10,7 @@ import parl_amd as parl
 from atari_agent import AtariAgent
 from atari_model import AtariModel
 from parl_amd.env import DeviceVectorEnv
-from parl_amd.rollout import DeviceRollout
+from parl_amd.rollout import DeviceRollout, ElasticDeviceRollout
 
 
 @parl.remote_class(wait=False)
@@ -18,7 +18,11 @@ class Actor(object):
     def __init__(self, config, actor_id=0, model=None, device=None):
         self.config = config
         E, T = config['env_num'], config['sample_batch_steps']
-        self.vector_env = DeviceVectorEnv(config['env_name'], E, dim=config['env_dim'], horizon=T,
+        # games with lives (Breakout): elastic launches, an env inside its life-loss reset does not hold the
+        # others up (ElasticDeviceRollout; the env's horizon then bounds the launches of one batch)
+        elastic = config.get('elastic_launches', 'Breakout' in config['env_name'])
+        self.vector_env = DeviceVectorEnv(config['env_name'], E, dim=config['env_dim'],
+                                          horizon=4 * T + 32 if elastic else T,
                                           seed=config.get('seed', 0), env_id0=actor_id * E, device=device)
         act_dim = self.vector_env.act_dim
         # in-process actor: share the learner's live parameters when given (the reference ships a
@@ -29,7 +33,8 @@ class Actor(object):
             model, sample_batch_steps=T, gamma=config['gamma'], vf_loss_coeff=config['vf_loss_coeff'],
             clip_rho_threshold=config['clip_rho_threshold'], clip_pg_rho_threshold=config['clip_pg_rho_threshold'])
         self.agent = AtariAgent(algorithm, seed=config.get('seed', 0) + 1000 + actor_id, device=self.vector_env.device)
-        self.rollout = DeviceRollout(self.vector_env, T, seed=config.get('seed', 0) + 1000 + actor_id)
+        self.rollout = (ElasticDeviceRollout if elastic else DeviceRollout)(
+            self.vector_env, T, seed=config.get('seed', 0) + 1000 + actor_id)
 
     def sample(self):
         """-> dict of device tensors, TIME-major rows ([t0 all envs, t1 all envs, ...])"""

@@ -145,7 +145,9 @@ enum Slot : int {
   S_PADDLE, S_SCORE, S_TERMINAL, S_ALE_LIVES, S_STARTED, S_FRAME_NUMBER,
   // wrappers
   S_LIVES, S_WAS_REAL_DONE, S_HAS_EPISODE, S_CUR_REWARD, S_NUM_STEPS, S_ELAPSED, S_COMPAT_COUNT,
-  S_RESET_COUNT, S_OBS_SINGLE, S_SINCE_RESET, S_COUNT
+  S_RESET_COUNT, S_OBS_SINGLE, S_SINCE_RESET,
+  // wrapper state machine suspended between launches (atari_env.hip, elastic stepping)
+  S_SUSP, S_SUSP_TOTAL, S_SUSP_ACT, S_SUSP_ALE_J, S_SUSP_NOOPS, S_COUNT
 };
 static_assert(S_COUNT <= 64, "scalar slots");
 

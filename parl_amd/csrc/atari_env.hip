@@ -29,7 +29,19 @@ struct EnvParams {
   int game, rom_size, E, mode;
   unsigned long long seed, env_id0;
   long long max_episode_steps;
+  int budget;  // elastic stepping: frames one launch may emulate per env (0: every step runs to its end)
 };
+
+// Elastic stepping (parlhip_atari_vec_step_elastic): a launch emulates at most `budget` frames per
+// env.  An env whose step needs more (the 12 frames of a life-loss reset: EpisodicLifeEnv's NOOP step +
+// FireResetEnv's two steps; the 64+ frames of a real reset when the snapshot cache cannot be used)
+// parks its wrapper state machine in the state blob (S_SUSP*) and goes on in the next launches,
+// taking no action and delivering no observation until its step is complete; the others keep
+// stepping.  Each env still sees exactly the sequence of frames and inputs the synchronous path gives
+// it.  The per-batch row accounting lives in two tiny kernels around the emulator (elastic_pre /
+// elastic_post): anything more that is live across the emulator's frame loop costs it dearly — with
+// the six row pointers as arguments of the env kernel itself its SGPR spills went from 420 to 24,881.
+enum : int { CTL_STEP = 0, CTL_CONTINUE = 1, CTL_IDLE = 2 };
 
 enum : int { MODE_STEP = 0, MODE_RESET = 1, MODE_SNAPSHOT = 2 };
 
@@ -110,7 +122,8 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
     const long long* __restrict__ actions, uint8_t* __restrict__ frames,
     float* __restrict__ rewards, uint8_t* __restrict__ dones, uint8_t* __restrict__ obs_flags,
     float* __restrict__ ep_returns, int* __restrict__ ep_lengths,
-    uint8_t* __restrict__ snap /* [30][kSnapBytes] or null */, int* __restrict__ jam_out) {
+    uint8_t* __restrict__ snap /* [30][kSnapBytes] or null */, int* __restrict__ jam_out,
+    const uint8_t* __restrict__ ctl /* [E] CTL_* per env, or null */) {
   __shared__ uint32_t rom_lds[kMaxRomWords];
   for (int i = threadIdx.x; i < prm.rom_size; i += blockDim.x) rom_lds[i] = romw_g[i];
   __syncthreads();
@@ -121,6 +134,11 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
   const int wave = rfl((int)(threadIdx.x >> 6));
   const int e = blockIdx.x * kEnvsPerBlock + wave;
   if (e >= prm.E) return;
+  // elastic stepping: this env's rows of the batch are complete, it waits for the others (its obs_flags /
+  // ep_lengths were written by elastic_pre_kernel).  The exit must be HERE: the same `return` placed
+  // after the Emu state exists (inside the MODE_STEP arm) took the kernel from 460 to 24,053 SGPR
+  // spills and its compile from 15 s to 190 s.
+  if (ctl && rfl((int)ctl[e]) == CTL_IDLE) return;
   const int mode = prm.mode, game = prm.game;
   // translated code is only used for the cartridge it was generated from (tag set by
   // parlhip_atari_rom_table_build after a CRC match)
@@ -153,12 +171,26 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
   int out_total = 0, out_done = 0, did_reset = 0;
   const int fixed_noops = mode == MODE_SNAPSHOT ? e + 1 : 0;
 
+  // frames this launch may still emulate (a counter, not a loop-invariant `budget &&` test: LLVM
+  // would unswitch the frame loop on it, i.e. duplicate the emulator)
+  int frames_left = (mode == MODE_STEP && prm.budget) ? prm.budget : 0x7fffffff;
   if (mode == MODE_STEP) {
+    const int c = ctl ? rfl((int)ctl[e]) : CTL_STEP;
     load_env(emu, v, blob, lane);
-    int a = rfl((int)actions[e]);
-    const int na = game == GAME_BREAKOUT ? 4 : 6;
-    if (a < 0 || a >= na) a = 0;
-    phase = PH_SKIP; ctx = CTX_MAIN; skip_act = action_code(a);
+    if (c == CTL_CONTINUE) {  // go on where the previous launch stopped; no action is consumed
+      const int* sc = (const int*)(blob + kOffScalars);
+      const int susp = rfl(sc[S_SUSP]);
+      phase = susp & 3; ctx = (susp >> 2) & 3; cont = (susp >> 4) & 3; skip_i = (susp >> 6) & 7;
+      no_render = (susp >> 9) & 1;
+      skip_total = rfl(sc[S_SUSP_TOTAL]); skip_act = rfl(sc[S_SUSP_ACT]);
+      ale_j = rfl(sc[S_SUSP_ALE_J]); noops_left = rfl(sc[S_SUSP_NOOPS]);
+      did_reset = 1;  // only reset sequences are ever cut
+    } else {
+      int a = rfl((int)actions[e]);
+      const int na = game == GAME_BREAKOUT ? 4 : 6;
+      if (a < 0 || a >= na) a = 0;
+      phase = PH_SKIP; ctx = CTX_MAIN; skip_act = action_code(a);
+    }
   } else {
     emu.system_reset();
     v.paddle = kPaddleDefault; v.score = v.terminal = v.ale_lives = v.started = v.frame_number = 0;
@@ -190,6 +222,8 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
   } while (0)
 
   while (phase != PH_END) {
+    if (frames_left == 0) break;  // suspended: phase != PH_END at the exit
+    frames_left--;
     // ------------------------------------------------------------------ choose input + target
     int act;
     uint8_t* fbp = nullptr;
@@ -362,10 +396,55 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
       ep_returns[e] = (float)ep_return;
       ep_lengths[e] = ep_closed ? ep_length : 0;
     }
-    obs_flags[e] = (uint8_t)((did_reset ? 2 : 0) | (v.obs_single ? 1 : 0));
+    // bit 2: the env's step is not complete, no observation in this launch (frame_post skips the env)
+    const int suspended = phase != PH_END;
+    obs_flags[e] = (uint8_t)((suspended ? 4 : 0) | (did_reset ? 2 : 0) | (v.obs_single ? 1 : 0));
     if (emu.jam) atomicOr(jam_out, emu.jam);
+    int* sc = (int*)(blob + kOffScalars);
+    sc[S_SUSP] = suspended ? (0x400 | phase | (ctx << 2) | (cont << 4) | (skip_i << 6) | (no_render << 9)) : 0;
+    sc[S_SUSP_TOTAL] = skip_total; sc[S_SUSP_ACT] = skip_act;
+    sc[S_SUSP_ALE_J] = ale_j; sc[S_SUSP_NOOPS] = noops_left;
   }
   store_env(emu, v, blob, lane);
+}
+
+// row accounting of an elastic launch, before the emulator: who starts a row, who goes on, who waits
+__global__ void elastic_pre_kernel(const uint8_t* __restrict__ states, int E, int rows_target, int launch,
+                                   int* __restrict__ rows_done, int* __restrict__ row_launch,
+                                   uint8_t* __restrict__ ctl, uint8_t* __restrict__ obs_flags,
+                                   int* __restrict__ ep_lengths) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int susp = ((const int*)(states + (size_t)e * kStateBytes + kOffScalars))[S_SUSP];
+  if (susp) { ctl[e] = CTL_CONTINUE; return; }
+  const int row = rows_done[e];
+  if (row >= rows_target) { ctl[e] = CTL_IDLE; obs_flags[e] = 4; ep_lengths[e] = 0; return; }
+  ctl[e] = CTL_STEP;
+  row_launch[(size_t)row * E + e] = launch;
+  rows_done[e] = row + 1;
+}
+
+// ... and after it: the row's reward / done (a plain step of 4 frames always fits the budget, so they
+// are known in the launch that started the row), completion bookkeeping
+__global__ void elastic_post_kernel(const uint8_t* __restrict__ states, int E, int rows_target, int launch,
+                                    const int* __restrict__ rows_done, const uint8_t* __restrict__ ctl,
+                                    const float* __restrict__ rewards, const uint8_t* __restrict__ dones,
+                                    float* __restrict__ rewards_rows, uint8_t* __restrict__ dones_rows,
+                                    int* __restrict__ last_obs_launch, int* __restrict__ finished) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int c = ctl[e];
+  if (c == CTL_IDLE) return;
+  const int rd = rows_done[e];
+  if (c == CTL_STEP) {
+    rewards_rows[(size_t)(rd - 1) * E + e] = rewards[e];
+    dones_rows[(size_t)(rd - 1) * E + e] = dones[e];
+  }
+  const int susp = ((const int*)(states + (size_t)e * kStateBytes + kOffScalars))[S_SUSP];
+  if (!susp) {
+    last_obs_launch[e] = launch;
+    if (rd >= rows_target) atomicAdd(finished, 1);
+  }
 }
 
 }  // namespace atari
@@ -419,13 +498,14 @@ static int check_env_args(const void* states, const void* romw, uint32_t rom_siz
 static int launch_env(int mode, void* states, const uint32_t* romw, uint32_t rom_size, int game,
                       const int64_t* actions, uint8_t* frames, float* rewards, uint8_t* dones,
                       uint8_t* obs_flags, float* ep_returns, int32_t* ep_lengths, int E, uint64_t seed,
-                      uint64_t env_id0, int64_t max_steps, void* snap, int32_t* jam, hipStream_t s) {
-  EnvParams prm{game, (int)rom_size, E, mode, seed, env_id0, (long long)max_steps};
+                      uint64_t env_id0, int64_t max_steps, void* snap, int32_t* jam, hipStream_t s,
+                      int budget = 0, const uint8_t* ctl = nullptr) {
+  EnvParams prm{game, (int)rom_size, E, mode, seed, env_id0, (long long)max_steps, budget};
   const dim3 grid(ceil_div(E, kEnvsPerBlock)), block(64 * kEnvsPerBlock);
 #define PARLHIP_LAUNCH_ENV(G)                                                                           \
   atari_env_kernel<G><<<grid, block, 0, s>>>((uint8_t*)states, romw, prm, (const long long*)actions,     \
                                              frames, rewards, dones, obs_flags, ep_returns, ep_lengths, \
-                                             (uint8_t*)snap, jam)
+                                             (uint8_t*)snap, jam, ctl)
   if (game == GAME_PONG) PARLHIP_LAUNCH_ENV(GAME_PONG);
   else PARLHIP_LAUNCH_ENV(GAME_BREAKOUT);
 #undef PARLHIP_LAUNCH_ENV
@@ -470,4 +550,34 @@ PARLHIP_EXPORT int parlhip_atari_vec_step(void* states, const uint32_t* rom_tabl
   return launch_env(MODE_STEP, states, rom_table_dev, rom_size, game, actions, frames, rewards, dones,
                     obs_flags, ep_returns, ep_lengths, E, seed, env_id0, max_episode_steps,
                     (void*)reset_cache_dev, jam_flag_dev, (hipStream_t)stream);
+}
+
+PARLHIP_EXPORT int parlhip_atari_vec_step_elastic(void* states, const uint32_t* rom_table_dev, uint32_t rom_size,
+                                                  int game, const int64_t* actions, uint8_t* frames, float* rewards,
+                                                  uint8_t* dones, uint8_t* obs_flags, float* ep_returns,
+                                                  int32_t* ep_lengths, int E, uint64_t seed, uint64_t env_id0,
+                                                  int64_t max_episode_steps, const void* reset_cache_dev,
+                                                  int32_t* jam_flag_dev, int frame_budget, int rows_target,
+                                                  int launch, int32_t* rows_done, int32_t* row_launch,
+                                                  uint8_t* ctl, int32_t* last_obs_launch, int32_t* finished,
+                                                  float* rewards_rows, uint8_t* dones_rows,
+                                                  parlhip_stream_t stream) {
+  int rc = check_env_args(states, rom_table_dev, rom_size, game, E);
+  if (rc) return rc;
+  if (E == 0) return PARLHIP_OK;
+  if (!actions || !frames || !rewards || !dones || !obs_flags || !ep_returns || !ep_lengths || !jam_flag_dev ||
+      !rows_done || !row_launch || !ctl || !last_obs_launch || !finished || !rewards_rows || !dones_rows)
+    return PARLHIP_EINVAL;
+  if (frame_budget < 4 || rows_target < 1 || launch < 0) return PARLHIP_EINVAL;  // a plain step (4 frames) must fit
+  hipStream_t s = (hipStream_t)stream;
+  elastic_pre_kernel<<<ceil_div(E, 256), 256, 0, s>>>((const uint8_t*)states, E, rows_target, launch, rows_done,
+                                                      row_launch, ctl, obs_flags, ep_lengths);
+  rc = launch_env(MODE_STEP, states, rom_table_dev, rom_size, game, actions, frames, rewards, dones, obs_flags,
+                  ep_returns, ep_lengths, E, seed, env_id0, max_episode_steps, (void*)reset_cache_dev,
+                  jam_flag_dev, s, frame_budget, ctl);
+  if (rc) return rc;
+  elastic_post_kernel<<<ceil_div(E, 256), 256, 0, s>>>((const uint8_t*)states, E, rows_target, launch, rows_done,
+                                                       ctl, rewards, dones, rewards_rows, dones_rows,
+                                                       last_obs_launch, finished);
+  return check_launch();
 }

@@ -46,6 +46,10 @@ __global__ __launch_bounds__(512) void frame_post_kernel(
   int* s_xstart = (int*)(s_yt + (kH + 2 * dim));            // [dim + 1]
   int* s_ystart = s_xstart + (dim + 1);                     // [dim + 1]
   const int e = blockIdx.x;
+  if (flags && (flags[e] & 4)) {  // elastic stepping: this env delivered no observation in this launch
+    if (since_next && threadIdx.x == 0) since_next[e] = 0;
+    return;
+  }
   if (since_next && threadIdx.x == 0) {  // FrameStack bookkeeping of this env (since_update_kernel), same launch
     const int p = since_prev ? since_prev[e] : 0;
     since_next[e] = (flags[e] & 2) ? 0 : (uint8_t)(p + 1 > 3 ? 3 : p + 1);

@@ -171,6 +171,40 @@ class DeviceVectorEnv(object):
         self.t += 1
         self._frame_post(self.t + 3)
 
+    def step_elastic_async(self, actions, launch, rows_target, rows_done, row_launch, last_obs_launch, finished,
+                           rewards_rows, dones_rows, frame_budget=4):
+        """Enqueue one ELASTIC launch (parlhip_atari_vec_step_elastic): every env emulates at most
+        `frame_budget` frames; an env inside a life-loss / slow reset sequence goes on with it instead of
+        taking `actions[e]`, an env that already started `rows_target` rows waits.  The observation of
+        an env that completed its step lands in ring slot launch + 4 (untouched otherwise)."""
+        if actions.dtype != torch.int64:
+            raise N.ParlHipError('actions must be int64')
+        if launch != self.t or launch >= self.horizon:
+            raise N.ParlHipError('elastic launch %d: ring position is %d of %d' % (launch, self.t, self.horizon))
+        if not hasattr(self, '_ctl'):
+            self._ctl = torch.zeros(self.envs_num, dtype=torch.uint8, device=self.device)
+        L = N.lib()
+        N.check(
+            L.parlhip_atari_vec_step_elastic(
+                N.ptr(self.states), N.ptr(self.rom_table), self.rom_size, self.game, N.ptr(actions.contiguous()),
+                N.ptr(self.raw_frames), N.ptr(self.rewards), N.ptr(self.dones), N.ptr(self.obs_flags),
+                N.ptr(self.ep_returns), N.ptr(self.ep_lengths), self.envs_num, self.seed, self.env_id0,
+                self.max_episode_steps, N.ptr(self.reset_cache), N.ptr(self.jam), int(frame_budget),
+                int(rows_target), int(launch), N.ptr(rows_done), N.ptr(row_launch), N.ptr(self._ctl),
+                N.ptr(last_obs_launch), N.ptr(finished), N.ptr(rewards_rows), N.ptr(dones_rows), N.stream_ptr()),
+            'parlhip_atari_vec_step_elastic')
+        self.t += 1
+        self._frame_post(self.t + 3)
+
+    def roll_elastic(self, last_obs_launch):
+        """roll() after an elastic batch: each env's newest observation sits in its own slot
+        (last_obs_launch[e] + 4); that slot and the three before it become slots 0..3."""
+        k = torch.arange(-3, 1, device=self.device)[:, None] + (last_obs_launch.long() + 4)[None, :]  # [4, E]
+        ev = self._env_idx.long()[None, :]
+        self.ring[0:4].copy_(self.ring[k, ev])
+        self.since[0:4].copy_(self.since[k, ev])
+        self.t = 0
+
     def roll(self):
         """Start the next rollout: the last 4 frame slots become the history of obs time 0."""
         T = self.t

@@ -86,11 +86,14 @@ class DeviceRollout(object):
             'dones': self.dones.reshape(self.T * E).bool(),
         }
 
+    def collect_steps(self, model):
+        for t in range(self.T):
+            self.collect_step(model, t)
+
     def collect(self, model):
         """Run T env steps with `model` as behaviour policy; returns the time-major batch."""
         self.collect_begin()
-        for t in range(self.T):
-            self.collect_step(model, t)
+        self.collect_steps(model)
         return self.collect_end()
 
     def state_dict(self):
@@ -112,6 +115,115 @@ class DeviceRollout(object):
         n, r, l = (float(x) for x in self.ep_stats.tolist())
         self.ep_stats.zero_()
         return n, (r / n if n else None), (l / n if n else None)
+
+
+class ElasticDeviceRollout(DeviceRollout):
+    """DeviceRollout whose launches are ELASTIC (DeviceVectorEnv.step_elastic_async): a launch never
+    emulates more than 4 frames per env.  With synchronous launches the whole vector waits for its
+    slowest env, and with 1024 Breakout envs some env is inside the 12-frame life-loss reset
+    (EpisodicLifeEnv + FireResetEnv, atari_wrappers.py:200-211, :163-171) in nearly every launch — every
+    launch then takes 16 frames instead of 4.  The reference never has this problem: its actors are
+    independent processes (examples/IMPALA/train.py:155-194).  Here an env in such a sequence drops out
+    of the next launches (no action consumed, no row produced) and the others go on; an env with T rows
+    waits; the batch closes when every env has T rows (~T + 3 * max life losses per env launches).
+    Every env's rows are exactly the ones the synchronous rollout would have produced for the same
+    actions; what changes is only in WHICH launch a row was produced, so per-launch outputs (policy
+    logits, sampled actions) are kept launch-major and compacted through row_launch at the end."""
+
+    def __init__(self, env, sample_batch_steps, seed=0, n_buffers=1, poll_lag=2):
+        super(ElasticDeviceRollout, self).__init__(env, sample_batch_steps, seed=seed, n_buffers=n_buffers)
+        E, A, dev, T = env.envs_num, env.act_dim, env.device, self.T
+        self.Lmax = env.horizon
+        assert self.Lmax >= T + 3, 'elastic rollout: env horizon (max launches per batch) must exceed T'
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.actions_lm = torch.zeros((self.Lmax, E), dtype=torch.int64, device=dev)
+        self.logits_lm = torch.zeros((self.Lmax, E, A), dtype=torch.float32, device=dev)
+        self.rows_done = torch.zeros(E, **i32)
+        self.row_launch = torch.zeros((T, E), **i32)
+        self.last_obs_launch = torch.zeros(E, **i32)
+        self.finished = torch.zeros(1, **i32)
+        self._fin_host = torch.zeros(self.Lmax, dtype=torch.int32).pin_memory() if dev.type == 'cuda' else \
+            torch.zeros(self.Lmax, dtype=torch.int32)
+        self._fin_events = [None] * self.Lmax
+        self.poll_lag = int(poll_lag)
+        self.launches = 0  # of the last batch
+
+    @torch.no_grad()
+    def collect_begin(self):
+        env = self.env
+        self._cur = (self._cur + 1) % len(self._bufs)
+        self._select(self._cur)
+        if not self.started:
+            env.reset()
+            self.started = True
+        else:
+            env.roll_elastic(self.last_obs_launch)
+        self.rows_done.zero_()
+        self.finished.zero_()
+
+    @torch.no_grad()
+    def collect_launch(self, model, l):
+        env = self.env
+        obs = env.current_obs(self._obs_step)
+        logits = self.logits_lm[l]
+        if hasattr(model, 'policy_into'):
+            model.policy_into(obs, logits)
+        else:
+            logits.copy_(model.policy(obs))
+        ops.policy_sample_into(logits, self.actions_lm[l], self.seed, self.step_count, env.env_id0)
+        env.step_elastic_async(self.actions_lm[l], l, self.T, self.rows_done, self.row_launch, self.last_obs_launch,
+                               self.finished, self.rewards, self.dones)
+        env.accumulate_episode_stats(self.ep_stats)
+        self.step_count += 1
+
+    @torch.no_grad()
+    def collect_steps(self, model):
+        """launches until every env has T rows.  The host runs `poll_lag` launches ahead of the completion
+        counter it polls (no launch can close the batch before launch T-1), so the GPU never waits
+        for the host; at most `poll_lag` all-idle launches are enqueued past the end."""
+        E, T = self.env.envs_num, self.T
+        st = torch.cuda.current_stream(self.env.device)
+        l = 0
+        while True:
+            if l >= self.Lmax:
+                raise RuntimeError('elastic rollout: %d launches did not complete %d rows of every env' % (l, T))
+            self.collect_launch(model, l)
+            if l >= T - 1:
+                self._fin_host[l:l + 1].copy_(self.finished, non_blocking=True)
+                ev = self._fin_events[l] or torch.cuda.Event()
+                self._fin_events[l] = ev
+                ev.record(st)
+                k = l - self.poll_lag
+                if k >= T - 1:
+                    self._fin_events[k].synchronize()
+                    if int(self._fin_host[k]) >= E:
+                        break
+            l += 1
+        self.launches = l + 1
+
+    @torch.no_grad()
+    def collect_end(self):
+        env, T = self.env, self.T
+        E = env.envs_num
+        idx = self.row_launch.long()  # [T, E]: launch of env e's row r
+        torch.gather(self.actions_lm, 0, idx, out=self.actions)
+        torch.gather(self.logits_lm, 0, idx[:, :, None].expand(T, E, self.logits_lm.shape[2]), out=self.behaviour_logits)
+        env.gather((self.row_launch.reshape(-1) + 3), self._envs, self.obs)
+        return {
+            'obs': self.obs,
+            'actions': self.actions.reshape(T * E),
+            'behaviour_logits': self.behaviour_logits.reshape(T * E, -1),
+            'rewards': self.rewards.reshape(T * E),
+            'dones': self.dones.reshape(T * E).bool(),
+        }
+
+    def collect(self, model):
+        self.collect_begin()
+        self.collect_steps(model)
+        return self.collect_end()
+
+    def collect_step(self, model, t):
+        raise RuntimeError('ElasticDeviceRollout has no fixed step count: use collect_steps()')
 
 
 class DeviceA2CRollout(object):
@@ -198,14 +310,18 @@ class AsyncActorLearner(object):
     the role of the reference actor's `set_weights` (actor.py:103-104): it is refreshed from the
     learner before every rollout, so the behaviour policy lags the learner by exactly one update."""
 
-    def __init__(self, alg, envs, sample_batch_steps, seed=0):
+    def __init__(self, alg, envs, sample_batch_steps, seed=0, elastic=False):
+        """elastic: ElasticDeviceRollout (one env group; the env's horizon is the launch bound of a batch)"""
         import copy
         self.alg = alg
         self.envs = list(envs) if isinstance(envs, (list, tuple)) else [envs]
         self.env = self.envs[0]
         self.T = int(sample_batch_steps)
         # one Philox key for all groups: streams are told apart by the global env id
-        self.rollouts = [DeviceRollout(e, sample_batch_steps, seed=seed, n_buffers=2) for e in self.envs]
+        if elastic and len(self.envs) != 1:
+            raise ValueError('elastic rollouts take one env group')
+        cls = ElasticDeviceRollout if elastic else DeviceRollout
+        self.rollouts = [cls(e, sample_batch_steps, seed=seed, n_buffers=2) for e in self.envs]
         self.rollout = self.rollouts[0]
         self.actor_model = copy.deepcopy(alg.model)
         for p in self.actor_model.parameters():
@@ -257,11 +373,15 @@ class AsyncActorLearner(object):
                 st.wait_event(self.snapshot_done)
                 st.wait_event(self.batch_free[k])
                 ro.collect_begin()
-        # step-interleaved enqueue: every group's stream always has work queued
-        for t in range(self.T):
-            for st, ro in zip(self.actor_streams, self.rollouts):
-                with torch.cuda.stream(st):
-                    ro.collect_step(self.actor_model, t)
+        if len(self.rollouts) == 1:
+            with torch.cuda.stream(self.actor_streams[0]):
+                self.rollouts[0].collect_steps(self.actor_model)
+        else:
+            # step-interleaved enqueue: every group's stream always has work queued
+            for t in range(self.T):
+                for st, ro in zip(self.actor_streams, self.rollouts):
+                    with torch.cuda.stream(st):
+                        ro.collect_step(self.actor_model, t)
         batches = []
         for g, (st, ro) in enumerate(zip(self.actor_streams, self.rollouts)):
             with torch.cuda.stream(st):
