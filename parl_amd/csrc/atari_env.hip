@@ -114,6 +114,10 @@ DEVI void store_env(const Emu& e, const Wrap& v, uint8_t* blob, int lane) {
   }
 }
 
+#ifdef PARLHIP_ENV_TIMING  // diagnostic build only (tools/env_wave_times.py): per-wave start / end clocks
+__device__ unsigned long long g_env_t0[8192], g_env_t1[8192];
+#endif
+
 // One wavefront per env.  mode STEP: VectorEnv.step; RESET: VectorEnv.reset; SNAPSHOT: wave k
 // builds reset snapshot k (noops = k+1) for the O(1) real-reset path.
 template <int GAME>
@@ -139,6 +143,9 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
   // after the Emu state exists (inside the MODE_STEP arm) took the kernel from 460 to 24,053 SGPR
   // spills and its compile from 15 s to 190 s.
   if (ctl && rfl((int)ctl[e]) == CTL_IDLE) return;
+#ifdef PARLHIP_ENV_TIMING
+  if (lane == 0 && e < 8192) g_env_t0[e] = wall_clock64();
+#endif
   const int mode = prm.mode, game = prm.game;
   // translated code is only used for the cartridge it was generated from (tag set by
   // parlhip_atari_rom_table_build after a CRC match)
@@ -406,6 +413,9 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
     sc[S_SUSP_ALE_J] = ale_j; sc[S_SUSP_NOOPS] = noops_left;
   }
   store_env(emu, v, blob, lane);
+#ifdef PARLHIP_ENV_TIMING
+  if (lane == 0 && e < 8192) g_env_t1[e] = wall_clock64();
+#endif
 }
 
 // row accounting of an elastic launch, before the emulator: who starts a row, who goes on, who waits
@@ -581,3 +591,12 @@ PARLHIP_EXPORT int parlhip_atari_vec_step_elastic(void* states, const uint32_t* 
                                                        last_obs_launch, finished);
   return check_launch();
 }
+
+#ifdef PARLHIP_ENV_TIMING
+PARLHIP_EXPORT int parlhip_debug_env_clocks(unsigned long long* t0_host, unsigned long long* t1_host, int n) {
+  if (n > 8192) return PARLHIP_EINVAL;
+  if (hipMemcpyFromSymbol(t0_host, HIP_SYMBOL(parlhip::atari::g_env_t0), (size_t)n * 8) != hipSuccess) return PARLHIP_EINVAL;
+  if (hipMemcpyFromSymbol(t1_host, HIP_SYMBOL(parlhip::atari::g_env_t1), (size_t)n * 8) != hipSuccess) return PARLHIP_EINVAL;
+  return PARLHIP_OK;
+}
+#endif
