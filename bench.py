@@ -298,8 +298,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--actor-groups', type=int, default=1, help='env groups (actor streams) per GPU')
     ap.add_argument('--learn-rows', type=int, default=6400,
-                    help='rows per forward / backward pass of the ONE learner update per step (gradients accumulated, '
-                    'IMPALA.max_learn_rows; 0: the whole batch in one pass).  The backward kernels are persistent and '
+                    help='rows per network forward / backward pass of the ONE learner update per step '
+                    '(IMPALA.max_learn_rows, chunk mode "forward": the V-trace loss kernel still runs once on the '
+                    'whole batch; 0: the whole batch in one pass).  The backward kernels are persistent and '
                     'share no CU with the actors\' conv kernels, so shorter passes stall the rollout less: '
                     '2.54 M frames/s in one pass, 2.61-2.64 M at 6400 rows')
     ap.add_argument('--elastic', choices=('auto', 'on', 'off'), default='auto',

@@ -127,18 +127,48 @@ class IMPALA(Algorithm):
         # rows per forward / backward pass of learn() (None: the whole batch at once).  Models whose
         # convolutions are GEMM-lowered (the 84x84 network) need ~2 MB of im2col per row.
         self.max_learn_rows = None
+        # how learn() uses max_learn_rows.  'forward': the network runs chunk by chunk (separate autograd
+        # nodes, so the backward kernels also run chunk by chunk), the heads' outputs are concatenated and
+        # the fused V-trace loss runs ONCE on the whole [T, B] batch — activations of the whole batch are
+        # kept (15.5 KB per row for the 42x42 model).  'accumulate': forward + loss + backward per chunk
+        # (bounded memory: what the GEMM-lowered float path needs, ~2 MB of im2col per row).
+        self.learn_chunk_mode = 'forward'
 
     def _heads(self, obs):
         if hasattr(self.model, 'policy_and_value'):
             return self.model.policy_and_value(obs)
         return self.model.policy(obs), self.model.value(obs)
 
+    def _heads_in_chunks(self, obs, time_major):
+        """policy logits [N, A] and values [N] of a flat batch; with max_learn_rows (mode 'forward') the
+        network sees chunks of whole sequences, the outputs come back in the batch's row order"""
+        T = self.sample_batch_steps
+        N = obs.shape[0]
+        B = N // T
+        per = max(1, (self.max_learn_rows or N) // T)
+        if self.learn_chunk_mode != 'forward' or per >= B:
+            return self._heads(obs)
+        ls, vs = [], []
+        if time_major:
+            o = obs.reshape((T, B) + tuple(obs.shape[1:]))
+            for b0 in range(0, B, per):
+                b1 = min(B, b0 + per)
+                l, v = self._heads(o[:, b0:b1].reshape((T * (b1 - b0), ) + tuple(obs.shape[1:])))
+                ls.append(l.reshape(T, b1 - b0, -1))
+                vs.append(v.reshape(T, b1 - b0))
+            return torch.cat(ls, 1).reshape(N, -1), torch.cat(vs, 1).reshape(N)
+        for b0 in range(0, B, per):
+            l, v = self._heads(obs[b0 * T:min(B, b0 + per) * T])
+            ls.append(l)
+            vs.append(v)
+        return torch.cat(ls, 0), torch.cat(vs, 0)
+
     def _vtrace_loss(self, obs, actions, behaviour_logits, rewards, dones, entropy_coeff, time_major):
         """forward pass + fused V-trace + loss terms for one flat batch (no parameter update)"""
         T = self.sample_batch_steps
         N = obs.shape[0]
         B = N // T
-        target_logits, values = self._heads(obs)
+        target_logits, values = self._heads_in_chunks(obs, time_major)
         A = target_logits.shape[-1]
         if self.fused_loss and T <= 256 and A in (2, 3, 4, 6, 9, 18):
             # log-softmax gather, entropy, KL, V-trace, the three sums AND their gradient: one kernel
@@ -188,7 +218,7 @@ class IMPALA(Algorithm):
         rewards f32 [N], dones bool [N].  Returns (vtrace_loss, kl)."""
         T = self.sample_batch_steps
         N = obs.shape[0]
-        if self.max_learn_rows and N > self.max_learn_rows and N // T > 1:
+        if self.learn_chunk_mode == 'accumulate' and self.max_learn_rows and N > self.max_learn_rows and N // T > 1:
             # bounded-memory update: the batch in chunks of whole sequences, gradients accumulated
             # (the losses are sums over rows, impala.py:67-79), ONE clip + Adam step
             B = N // T

@@ -372,15 +372,16 @@ def test_impala_learn_in_row_chunks_equals_one_pass(dev):
     dn = torch.rand(T * B, device=dev) < 0.05
     for tm in (True, False):
         outs = []
-        for rows in (None, 3 * T):
+        for rows, mode in ((None, 'forward'), (3 * T, 'forward'), (5 * T, 'accumulate')):
             m = copy.deepcopy(base)
             alg = parl.algorithms.IMPALA(m, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
                                          clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
-            alg.max_learn_rows = rows
+            alg.max_learn_rows, alg.learn_chunk_mode = rows, mode
             loss, kl = alg.learn(obs, act, bl, rew, dn, 1e-3, -0.01, time_major=tm)
             # the (clipped) gradients the Adam step consumed; Adam's first step is lr * sign-like, so the
             # parameters themselves amplify rounding differences of tiny gradients
             outs.append((float(loss.total_loss.detach()), [p.grad.detach().clone() for p in m.parameters()]))
-        assert abs(outs[0][0] - outs[1][0]) <= 1e-4 * abs(outs[0][0])
-        for a, b in zip(outs[0][1], outs[1][1]):
-            assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-7
+        for other in outs[1:]:
+            assert abs(outs[0][0] - other[0]) <= 1e-4 * abs(outs[0][0])
+            for a, b in zip(outs[0][1], other[1]):
+                assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-7
