@@ -354,8 +354,11 @@ def main():
     # time the C-ABI entry itself (the kernel launch on the learner stream), not the Python wrapper
     # around it (output allocations, the zero fill of the sums)
     from parl_amd import _native
+    hl_timer = KernelTimer()
     for name in ('parlhip_impala_loss_f32', 'parlhip_vtrace_from_logits_f32'):
         setattr(_native.lib(), name, vt_timer.wrap(getattr(_native.lib(), name)))
+    setattr(_native.lib(), 'parlhip_impala_heads_loss_f32',
+            hl_timer.wrap(getattr(_native.lib(), 'parlhip_impala_heads_loss_f32')))
     env_timer, fp_timer = KernelTimer(), KernelTimer()
     for e in envs:
         e.step_async = env_timer.wrap(e.step_async)
@@ -391,7 +394,7 @@ def main():
         step()
     pdist.barrier()
     torch.cuda.synchronize()
-    vt_timer.enabled = env_timer.enabled = fp_timer.enabled = True
+    vt_timer.enabled = hl_timer.enabled = env_timer.enabled = fp_timer.enabled = True
     t0 = time.time()
     for _ in range(args.steps):
         loss = step()
@@ -443,15 +446,32 @@ def main():
         by = T * Eg * (2 * A * 4 + 8 + 4 + 1 + 4) + (T - 1) * Eg * 8 + (T * Eg * (4 * A + 4) if fused else 0)
         kname = ('impala_loss_wave_kernel (V-trace + log-prob gather + entropy + KL + loss sums + gradient, '
                  if fused else 'vtrace_logits_wave_kernel (fused log-prob gather + V-trace, ')
-        out['roofline'] = {
-            'kernel': kname + 'wave per sequence, T=%d B=%d A=%d; %d launch(es) per update, one per actor group)' %
-            (T, Eg, A, G),
-            'bound': 'hbm', 'achieved': by / vt / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-            'frac': by / vt / 1e9 / HBM_PEAK_GBPS, 'bytes_per_launch': by,
-            'note': 'workload shape is %.1f MB: launch-latency-bound by construction (SURVEY §8d); '
-                    'see roofline_saturating for the HBM-bound shape' % (by / 1e6),
-        }
-        out['roofline'].update(pmc_traffic(('impala_loss' if fused else 'vtrace_logits') + '_T%d_B%d_A%d' % (T, Eg, A)))
+        hl = hl_timer.mean_seconds()
+        if hl is not None:
+            # the heads + loss + heads' backward kernel: per (t, b) row the trunk output in (1024 B),
+            # its gradient out (1024 B), behaviour logits, action, reward, done in; vs, pg_adv out for T-1 rows
+            Bl = E if G == 1 else Eg
+            by = T * Bl * (2 * 256 * 4 + A * 4 + 8 + 4 + 1) + (T - 1) * Bl * 8
+            out['roofline'] = {
+                'kernel': 'impala_heads_loss_kernel (policy_fc + value_fc + log-softmax / entropy / KL + V-trace + loss '
+                          'sums + gradient w.r.t. the trunk output and the heads, wave per sequence, T=%d B=%d A=%d, '
+                          'one launch per update; timed with its 1,799-thread partial-sum kernel)' % (T, Bl, A),
+                'bound': 'hbm', 'achieved': by / hl / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                'frac': by / hl / 1e9 / HBM_PEAK_GBPS, 'bytes_per_launch': by,
+                'note': 'the V-trace scan at the WORKLOAD shape, fused with the two heads so that the 52 MB trunk '
+                        'output and its gradient cross HBM once each; see roofline_saturating for the bare scan',
+            }
+            out['roofline'].update(pmc_traffic('impala_heads_loss_T%d_B%d_A%d' % (T, Bl, A)))
+        else:
+            out['roofline'] = {
+                'kernel': kname + 'wave per sequence, T=%d B=%d A=%d; %d launch(es) per update, one per actor group)' %
+                (T, Eg, A, G),
+                'bound': 'hbm', 'achieved': by / vt / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                'frac': by / vt / 1e9 / HBM_PEAK_GBPS, 'bytes_per_launch': by,
+                'note': 'workload shape is %.1f MB: launch-latency-bound by construction (SURVEY §8d); '
+                        'see roofline_saturating for the HBM-bound shape' % (by / 1e6),
+            }
+            out['roofline'].update(pmc_traffic(('impala_loss' if fused else 'vtrace_logits') + '_T%d_B%d_A%d' % (T, Eg, A)))
         # --- the same scan family at the saturating shape (T'=127, B=262,144: 932 MB) ---
         Ts, Bs = (127, 262144) if not args.quick else (127, 8192)
         x = [torch.randn((Ts, Bs), device=dev) for _ in range(5)]

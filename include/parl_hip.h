@@ -106,6 +106,26 @@ int parlhip_impala_loss_f32(const float* behaviour_logits, const float* target_l
                             float gamma, float clip_rho_threshold, float clip_pg_rho_threshold,
                             float vf_coeff, float entropy_coeff, parlhip_stream_t stream);
 
+/* parlhip_impala_loss_f32 with the two heads of the network in front and behind it: IMPALA.learn's
+ * policy_fc / value_fc (examples/IMPALA/atari_model.py:44-57, :73-90), the loss, and the heads'
+ * backward in one kernel.  hidden f32 [T,B,H] (the trunk's output, time-major rows), w_policy [A,H],
+ * b_policy [A], w_value [H] (= value_fc.weight [1,H]), b_value [1]; the loss inputs as above
+ * (time-major).  Outputs: vs, pg_advantages [T-1,B]; grad_hidden [T,B,H] = d total / d hidden;
+ * grad_heads f32 [(A+1)*H + (A+1)]: d total / d w_policy rows, d / d w_value, then d / d b_policy,
+ * d / d b_value; sums as above (ADDED to).  workspace: parlhip_impala_heads_loss_workspace_bytes(B, A)
+ * bytes, 16-byte aligned like hidden / grad_hidden / the weights.  The trunk output and its gradient
+ * cross HBM once each (the four head GEMMs of the framework path read / write them 3 times).
+ * PARLHIP_ENOSUP unless H == 256, T <= 64, A in {4, 6}: callers use parlhip_impala_loss_f32.      */
+size_t parlhip_impala_heads_loss_workspace_bytes(int B, int A);
+int parlhip_impala_heads_loss_f32(const float* hidden, const float* w_policy, const float* b_policy,
+                                  const float* w_value, const float* b_value,
+                                  const float* behaviour_logits, const int64_t* actions,
+                                  const float* rewards, const uint8_t* dones, float* vs,
+                                  float* pg_advantages, float* grad_hidden, float* grad_heads,
+                                  double* sums, void* workspace, int T, int B, int hidden_units, int A,
+                                  float gamma, float clip_rho_threshold, float clip_pg_rho_threshold,
+                                  float vf_coeff, float entropy_coeff, parlhip_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * GAE / n-step returns / discounted sums
  * ------------------------------------------------------------------------------------ */

@@ -37,6 +37,8 @@ SIGNATURES = {
     'parlhip_vtrace_f32': (_i, [_p] * 8 + [_i, _i, _f, _f, _p]),
     'parlhip_vtrace_from_logits_f32':
     (_i, [_p] * 10 + [_i, _i, _i, _i, _f, _f, _f, _p]),
+    'parlhip_impala_heads_loss_workspace_bytes': (_sz, [_i, _i]),
+    'parlhip_impala_heads_loss_f32': (_i, [_p] * 15 + [_i, _i, _i, _i, _f, _f, _f, _f, _f, _p]),
     'parlhip_impala_loss_f32': (_i, [_p] * 11 + [_i, _i, _i, _i, _f, _f, _f, _f, _f, _p]),
     'parlhip_gae_f32': (_i, [_p] * 7 + [_i, _i, _f, _f, _i, _i, _p]),
     'parlhip_gae_workspace_bytes': (_sz, [_i, _i]),

@@ -88,6 +88,29 @@ class _FusedLossFn(torch.autograd.Function):
         return g_total * glog, g_total * gval, None, None, None, None, None
 
 
+class _FusedHeadsLossFn(torch.autograd.Function):
+    """policy_fc + value_fc + total_loss + the gradient w.r.t. the trunk output and the heads' parameters
+    from ONE kernel (ops.impala_heads_loss): the trunk output crosses HBM once forward, its gradient once."""
+
+    @staticmethod
+    def forward(ctx, hidden, w_pi, b_pi, w_v, b_v, behaviour_logits, actions, rewards, dones, cfg):
+        gamma, crho, cpg, vf_c, ent_c = cfg
+        out = ops.impala_heads_loss(hidden, w_pi, b_pi, w_v, b_v, behaviour_logits, actions, rewards, dones, gamma,
+                                    crho, cpg, vf_c, ent_c)
+        if out is None:
+            raise NotImplementedError
+        vs, pg, gh, gwp, gbp, gwv, gbv, sums = out
+        ctx.save_for_backward(gh, gwp, gbp, gwv.reshape(w_v.shape), gbv.reshape(b_v.shape))
+        total = (sums[0] + vf_c * sums[1] + ent_c * sums[2]).float()
+        ctx.mark_non_differentiable(sums, vs, pg)
+        return total, sums, vs, pg
+
+    @staticmethod
+    def backward(ctx, g_total, g_sums, g_vs, g_pg):
+        gh, gwp, gbp, gwv, gbv = ctx.saved_tensors
+        return g_total * gh, g_total * gwp, g_total * gbp, g_total * gwv, g_total * gbv, None, None, None, None, None
+
+
 class _KernelVTraceLoss(object):
     """VTraceLoss whose terms and gradient came from the fused loss kernel"""
 
@@ -133,30 +156,41 @@ class IMPALA(Algorithm):
         # kept (15.5 KB per row for the 42x42 model).  'accumulate': forward + loss + backward per chunk
         # (bounded memory: what the GEMM-lowered float path needs, ~2 MB of im2col per row).
         self.learn_chunk_mode = 'forward'
+        # heads + loss + heads' backward in one kernel when the model exposes its trunk (`_trunk`,
+        # `policy_fc`, `value_fc`), the batch is time-major, T <= 64, 256 hidden units, A in {4, 6}
+        self.fused_heads = True
 
     def _heads(self, obs):
         if hasattr(self.model, 'policy_and_value'):
             return self.model.policy_and_value(obs)
         return self.model.policy(obs), self.model.value(obs)
 
-    def _heads_in_chunks(self, obs, time_major):
-        """policy logits [N, A] and values [N] of a flat batch; with max_learn_rows (mode 'forward') the
-        network sees chunks of whole sequences, the outputs come back in the batch's row order"""
+    def _heads_in_chunks(self, obs, time_major, trunk_only=False):
+        """policy logits [N, A] and values [N] of a flat batch (trunk_only: the trunk's output [N, H]); with
+        max_learn_rows (mode 'forward') the network sees chunks of whole sequences, the outputs come
+        back in the batch's row order"""
         T = self.sample_batch_steps
         N = obs.shape[0]
         B = N // T
         per = max(1, (self.max_learn_rows or N) // T)
         if self.learn_chunk_mode != 'forward' or per >= B:
-            return self._heads(obs)
+            return self.model._trunk(obs) if trunk_only else self._heads(obs)
         ls, vs = [], []
         if time_major:
             o = obs.reshape((T, B) + tuple(obs.shape[1:]))
             for b0 in range(0, B, per):
                 b1 = min(B, b0 + per)
-                l, v = self._heads(o[:, b0:b1].reshape((T * (b1 - b0), ) + tuple(obs.shape[1:])))
+                oc = o[:, b0:b1].reshape((T * (b1 - b0), ) + tuple(obs.shape[1:]))
+                if trunk_only:
+                    ls.append(self.model._trunk(oc).reshape(T, b1 - b0, -1))
+                    continue
+                l, v = self._heads(oc)
                 ls.append(l.reshape(T, b1 - b0, -1))
                 vs.append(v.reshape(T, b1 - b0))
+            if trunk_only:
+                return torch.cat(ls, 1).reshape(N, -1)
             return torch.cat(ls, 1).reshape(N, -1), torch.cat(vs, 1).reshape(N)
+        assert not trunk_only
         for b0 in range(0, B, per):
             l, v = self._heads(obs[b0 * T:min(B, b0 + per) * T])
             ls.append(l)
@@ -168,6 +202,19 @@ class IMPALA(Algorithm):
         T = self.sample_batch_steps
         N = obs.shape[0]
         B = N // T
+        m = self.model
+        if (self.fused_loss and self.fused_heads and time_major and T <= 64 and obs.is_cuda and hasattr(m, '_trunk')
+                and isinstance(getattr(m, 'policy_fc', None), torch.nn.Linear)
+                and isinstance(getattr(m, 'value_fc', None), torch.nn.Linear) and m.policy_fc.in_features == 256
+                and m.policy_fc.out_features in (4, 6)):
+            hidden = self._heads_in_chunks(obs, True, trunk_only=True)
+            A = m.policy_fc.out_features
+            total, sums, vs, pg_adv = _FusedHeadsLossFn.apply(
+                hidden.reshape(T, B, 256), m.policy_fc.weight, m.policy_fc.bias, m.value_fc.weight, m.value_fc.bias,
+                behaviour_logits.reshape(T, B, A), actions.reshape(T, B), rewards.reshape(T, B), dones.reshape(T, B),
+                (self.gamma, self.clip_rho_threshold, self.clip_pg_rho_threshold, self.vf_loss_coeff,
+                 float(entropy_coeff)))
+            return _KernelVTraceLoss(total, sums, vs, pg_adv), (sums[3] / N).float()
         target_logits, values = self._heads_in_chunks(obs, time_major)
         A = target_logits.shape[-1]
         if self.fused_loss and T <= 256 and A in (2, 3, 4, 6, 9, 18):

@@ -1121,3 +1121,289 @@ PARLHIP_EXPORT int parlhip_impala_loss_f32(const float* blog, const float* tlog,
   }
 #undef LARGS
 }
+
+// ----------------------------------------------------------------------------------------
+// IMPALA learner: both heads + the whole V-trace loss + the heads' backward in ONE kernel.
+//
+// What impala_loss_wave_kernel fuses (log-softmax, gather, entropy, KL, V-trace, loss sums, gradient
+// w.r.t. logits / values) moves 5 MB at the reference shape (T=50, B=1024, A=6): launch-bound by
+// construction.  The tensors next to it are not small: the trunk output h [T*B, 256] f32 (52 MB) is
+// read by the two head GEMMs (policy_fc, value_fc: atari_model.py:44-57) and by their weight-gradient
+// GEMMs, and d total / d h (52 MB) is written by their input-gradient GEMMs.  Here one wavefront owns
+// one sequence b: it reads its T rows of h ONCE into registers (lane l holds columns 4l..4l+3 of every
+// row), forms the A+1 head outputs of every row with a butterfly reduction that leaves row t's
+// outputs in lane t (63 shuffles per 64 rows and output instead of 6 per row and output), runs the
+// loss math lane-per-step exactly as impala_loss_wave_kernel does, and then produces d total / d h row
+// by row (one coalesced 1 KiB store each) and the heads' weight / bias gradients from the rows it
+// still holds.  Algorithmic bytes per (t, b) row: 1024 (h) + 1024 (dh) + 4A (behaviour logits) + 8 + 4
+// + 1 in, 8 out for T-1 rows  =>  107 MB per launch at the reference shape instead of 5 MB.
+// Weight-gradient partials: 4 waves through LDS, one partial per workgroup, fixed-order sum
+// (heads_partial_sum_kernel): deterministic.  Time-major, T <= 64, 256 hidden units.
+// ----------------------------------------------------------------------------------------
+template <int A_CT>
+__device__ __forceinline__ void log_softmax_regs(const float (&x)[A_CT], float (&lp)[A_CT]) {
+  float m = x[0];
+#pragma unroll
+  for (int j = 1; j < A_CT; ++j) m = fmaxf(m, x[j]);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < A_CT; ++j) sum += expf(x[j] - m);
+  const float lse = logf(sum);
+#pragma unroll
+  for (int j = 0; j < A_CT; ++j) lp[j] = (x[j] - m) - lse;
+}
+
+__device__ __forceinline__ float lane_bcast(float x, int src_lane) {  // src_lane: compile-time after unrolling
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src_lane));
+}
+
+constexpr int kHeadsHidden = 256;
+
+// TWO wavefronts per sequence, 128 columns each (lane l: columns half * 128 + 2l, +1): with one wave
+// holding whole rows the kernel needed all 512 VGPRs of a SIMD, could not share it with a resident
+// emulator wave (171 VGPRs) and waited for the env kernel to drain (332 us in the bench against 39 us
+// alone).  At <= 256 VGPRs it slots in next to the actors.  The two halves exchange their partial head
+// outputs through LDS and run the (cheap) loss math redundantly; each produces its half of the columns
+// of d total / d h and of the weight gradients.
+template <int A_CT, int TMAX>  // TMAX >= T: rows held in registers (2 VGPRs each)
+__global__ __launch_bounds__(256, 2) void impala_heads_loss_kernel(
+    const float* __restrict__ h, const float* __restrict__ wpi, const float* __restrict__ bpi,
+    const float* __restrict__ wv, const float* __restrict__ bv, const float* __restrict__ blog,
+    const int64_t* __restrict__ actions, const float* __restrict__ rew, const uint8_t* __restrict__ dones,
+    float* __restrict__ vs, float* __restrict__ pg, float* __restrict__ dh, float* __restrict__ wpart,
+    double* __restrict__ sums, int T, int B, float gamma, float clip_rho, float clip_pg, float vf_coeff,
+    float ent_coeff, int* __restrict__ err) {
+  constexpr int NO = A_CT + 1;  // head outputs per row: A logits + the value
+  constexpr int H = kHeadsHidden;
+  // the wave index as a SCALAR: row base addresses then live in SGPRs (one VGPR lane offset for all
+  // rows); as vector values the 52 row addresses cost 104 VGPRs next to the 104 of the rows themselves
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int half = wid & 1, sq = wid >> 1;
+  const int blk = xcd_chunk_block(blockIdx.x, gridDim.x);
+  const int64_t b_raw = (int64_t)blk * 2 + sq;
+  const bool live = b_raw < B;  // waves past the last sequence recompute sequence B-1, everything masked
+  const int64_t b = live ? b_raw : (int64_t)B - 1;
+  const int Tm = T - 1;
+  const int col = half * 128 + 2 * lane;
+
+  // ---- 1. this sequence's rows of h, this wave's 128 columns: all loads in flight at once
+  float2 hr[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    hr[t] = make_float2(0.f, 0.f);
+    if (t < T) hr[t] = *(const float2*)(h + ((int64_t)t * B + b) * H + col);
+  }
+  // ---- 2. head outputs: lane t ends up with row t's A logits and value
+  float2 wj[NO];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) wj[j] = *(const float2*)((j < A_CT ? wpi + (size_t)j * H : wv) + col);
+  __shared__ float xch[2][2][NO][64];  // [sequence of the workgroup][half][output][lane = row]
+  float outv[NO];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    // butterfly: at offset `off` the lanes with that bit clear keep the lower half of the rows, the
+    // others the upper half, each adding what its partner holds of the half it keeps.  The first
+    // stage forms the dot products as it consumes them (rows i and i + 32), 4 exchanges in flight at a
+    // time: with all 64 partials formed up front the kernel spilled rows of h (15 MB of scratch traffic)
+    float part[32];
+    {
+      const bool hi = (lane & 32) != 0;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const float a = __builtin_fmaf(hr[i < TMAX ? i : 0].y, wj[j].y, hr[i < TMAX ? i : 0].x * wj[j].x);
+        const float c = i + 32 < TMAX ? __builtin_fmaf(hr[i + 32 < TMAX ? i + 32 : 0].y, wj[j].y,
+                                                       hr[i + 32 < TMAX ? i + 32 : 0].x * wj[j].x) : 0.f;
+        const float send = hi ? a : c, keep = hi ? c : a;
+        part[i] = keep + __shfl_xor(send, 32, 64);
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int off = 16, n = 32; off >= 1; off >>= 1, n >>= 1) {
+      const bool hi = (lane & off) != 0;
+#pragma unroll
+      for (int i = 0; i < n / 2; ++i) {
+        const float a = part[i], c = part[i + n / 2];
+        const float send = hi ? a : c, keep = hi ? c : a;
+        part[i] = keep + __shfl_xor(send, off, 64);
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    outv[j] = part[0];
+    xch[sq][half][j][lane] = part[0];
+    __builtin_amdgcn_sched_barrier(0);  // one output at a time: 64 partials live, not 64 * (A + 1)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NO; ++j)  // a + b == b + a: both halves get bit-identical outputs
+    outv[j] = (outv[j] + xch[sq][half ^ 1][j][lane]) + (j < A_CT ? bpi[j] : bv[0]);
+  // ---- 3. the loss, lane per step (impala_loss_wave_kernel with K = 1 on register inputs)
+  const int t = lane;
+  const bool in_t = t < T, valid1 = t < Tm;
+  const int64_t i = (int64_t)(in_t ? t : 0) * B + b;
+  const float v_own = outv[A_CT];
+  const float bootstrap = __shfl(v_own, Tm, 64);
+  float lp[A_CT], p[A_CT], blp[A_CT];
+  {
+    float tl[A_CT];
+#pragma unroll
+    for (int j = 0; j < A_CT; ++j) tl[j] = outv[j];
+    log_softmax_regs<A_CT>(tl, lp);
+    log_softmax_row<A_CT>(blog + i * A_CT, blp);
+  }
+  float Hh = 0.f, kl = 0.f;
+#pragma unroll
+  for (int j = 0; j < A_CT; ++j) {
+    p[j] = expf(lp[j]);
+    Hh -= p[j] * lp[j];
+    kl += p[j] * (lp[j] - blp[j]);
+  }
+  const bool owner = live && half == 0;  // one of the two halves reports the sequence's scalars
+  if (!in_t || !owner) kl = 0.f;
+  float rho[1] = {1.f}, dsc[1] = {0.f}, v[1] = {0.f}, r[1] = {0.f}, vst[1], pgv[1];
+  bool valid[1] = {valid1};
+  int act = 0;
+  float tlp = 0.f;
+  if (valid1) {
+    int a = (int)actions[i];
+    if (a < 0 || a >= A_CT) { *err = 1; a = 0; }
+    act = a;
+    float ta = lp[0], ba = blp[0];
+#pragma unroll
+    for (int j = 1; j < A_CT; ++j) { ta = (j == a) ? lp[j] : ta; ba = (j == a) ? blp[j] : ba; }
+    tlp = ta;
+    dsc[0] = dones[i] ? 0.f : gamma;
+    rho[0] = expf(ta - ba);
+    v[0] = v_own;
+    r[0] = rew[i];
+  }
+  vtrace_wave_core<1>(rho, dsc, v, r, valid, lane, Tm, bootstrap, clip_rho, clip_pg, vst, pgv);
+  float g[NO];  // d total / d (logits, value) of row t; zero for the bootstrap row and beyond
+#pragma unroll
+  for (int j = 0; j < NO; ++j) g[j] = 0.f;
+  float pi = 0.f, vf = 0.f, ent = 0.f;
+  if (valid1 && live) {
+    const float dv = v[0] - vst[0];
+#pragma unroll
+    for (int j = 0; j < A_CT; ++j)
+      g[j] = -pgv[0] * ((j == act ? 1.f : 0.f) - p[j]) - ent_coeff * (p[j] * (lp[j] + Hh));
+    g[A_CT] = vf_coeff * dv;
+    if (half == 0) {
+      const int64_t o = (int64_t)t * B + b;
+      pg[o] = pgv[0];
+      vs[o] = vst[0];
+      pi = -tlp * pgv[0];
+      vf = 0.5f * dv * dv;
+      ent = Hh;
+    }
+  }
+  // ---- 4. backward of the heads: dh rows out, weight gradients from the rows still in registers
+  float2 accw[NO];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) accw[j] = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int tt = 0; tt < TMAX; ++tt) {
+    if (tt < T) {
+      float2 d = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < NO; ++j) {
+        const float gj = lane_bcast(g[j], tt);
+        d.x = __builtin_fmaf(gj, wj[j].x, d.x); d.y = __builtin_fmaf(gj, wj[j].y, d.y);
+        accw[j].x = __builtin_fmaf(gj, hr[tt].x, accw[j].x); accw[j].y = __builtin_fmaf(gj, hr[tt].y, accw[j].y);
+      }
+      if (live) *(float2*)(dh + ((int64_t)tt * B + b) * H + col) = d;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- 5. workgroup partials: [NO][256] weight gradients + [NO] bias gradients, then the loss sums
+  __shared__ float2 redw[2][NO][128];  // [sequence][output][column pair]
+  __shared__ float redb[2][NO + 4];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    redw[sq][j][half * 64 + lane] = accw[j];
+    const float s = wave_sum(g[j]);
+    if (lane == 0 && half == 0) redb[sq][j] = s;
+  }
+  pi = wave_sum(pi); vf = wave_sum(vf); ent = wave_sum(ent); kl = wave_sum(kl);
+  if (lane == 0 && half == 0) { redb[sq][NO] = pi; redb[sq][NO + 1] = vf; redb[sq][NO + 2] = ent; redb[sq][NO + 3] = kl; }
+  __syncthreads();
+  float* wp = wpart + (size_t)blk * (NO * H + NO);
+  for (int k = threadIdx.x; k < NO * 128; k += 256) {
+    const int j = k >> 7, c = k & 127;
+    const float2 a0 = redw[0][j][c], a1 = redw[1][j][c];
+    ((float2*)(wp + (size_t)j * H))[c] = make_float2(a0.x + a1.x, a0.y + a1.y);
+  }
+  if (threadIdx.x < NO) wp[NO * H + threadIdx.x] = redb[0][threadIdx.x] + redb[1][threadIdx.x];
+  if (threadIdx.x < 4) atomicAdd(sums + threadIdx.x, (double)redb[0][NO + threadIdx.x] + (double)redb[1][NO + threadIdx.x]);
+}
+
+// out[k] = sum over workgroup partials, fixed order: 16 outputs x 16 slices of the partials per block
+__global__ __launch_bounds__(256) void heads_partial_sum_kernel(const float* __restrict__ wpart, int nblk, int n,
+                                                                float* __restrict__ out) {
+  __shared__ float red[16][16];
+  const int kk = threadIdx.x & 15, qs = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + kk;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (k < n) {
+    int q = qs;
+    for (; q + 48 < nblk; q += 64) {
+      s0 += wpart[(size_t)q * n + k]; s1 += wpart[(size_t)(q + 16) * n + k];
+      s2 += wpart[(size_t)(q + 32) * n + k]; s3 += wpart[(size_t)(q + 48) * n + k];
+    }
+    for (; q < nblk; q += 16) s0 += wpart[(size_t)q * n + k];
+  }
+  red[qs][kk] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (qs == 0 && k < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][kk];
+    out[k] = t;
+  }
+}
+
+PARLHIP_EXPORT size_t parlhip_impala_heads_loss_workspace_bytes(int B, int A) {
+  if (B <= 0 || A <= 0) return 0;
+  return (size_t)ceil_div(B, 2) * ((size_t)(A + 1) * kHeadsHidden + (A + 1)) * sizeof(float);
+}
+
+PARLHIP_EXPORT int parlhip_impala_heads_loss_f32(const float* hidden, const float* w_policy, const float* b_policy,
+                                                 const float* w_value, const float* b_value,
+                                                 const float* behaviour_logits, const int64_t* actions,
+                                                 const float* rewards, const uint8_t* dones, float* vs, float* pg,
+                                                 float* grad_hidden, float* grad_heads, double* sums,
+                                                 void* workspace, int T, int B, int hidden_units, int A, float gamma,
+                                                 float clip_rho, float clip_pg, float vf_coeff, float ent_coeff,
+                                                 parlhip_stream_t stream) {
+  if (T < 2 || B < 0 || A < 1) return PARLHIP_EINVAL;
+  if (T > 64 || hidden_units != kHeadsHidden) return PARLHIP_ENOSUP;
+  const bool small = T <= 50;  // the reference's sample_batch_steps is 50 (impala_config.py)
+  if (B == 0) return PARLHIP_OK;
+  if (!hidden || !w_policy || !b_policy || !w_value || !b_value || !behaviour_logits || !actions || !rewards ||
+      !dones || !vs || !pg || !grad_hidden || !grad_heads || !sums || !workspace)
+    return PARLHIP_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(hidden) | reinterpret_cast<uintptr_t>(grad_hidden) |
+       reinterpret_cast<uintptr_t>(w_policy) | reinterpret_cast<uintptr_t>(w_value) |
+       reinterpret_cast<uintptr_t>(workspace)) & 15)
+    return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int* err = action_err_ptr();
+  if (!err) return PARLHIP_ELAUNCH;
+  const int nblk = ceil_div(B, 2);  // two sequences (four half-sequence waves) per workgroup
+  float* wpart = (float*)workspace;
+#define HLT(AA, TT)                                                                                            \
+  impala_heads_loss_kernel<AA, TT><<<nblk, 256, 0, s>>>(hidden, w_policy, b_policy, w_value, b_value,         \
+      behaviour_logits, actions, rewards, dones, vs, pg, grad_hidden, wpart, sums, T, B, gamma, clip_rho,     \
+      clip_pg, vf_coeff, ent_coeff, err)
+#define HL(AA) do { if (small) HLT(AA, 50); else HLT(AA, 64); } while (0)
+  switch (A) {
+    case 4: HL(4); break;
+    case 6: HL(6); break;
+    default: return PARLHIP_ENOSUP;  // other action counts: parlhip_impala_loss_f32 behind the framework's heads
+  }
+#undef HL
+#undef HLT
+  const int n = (A + 1) * kHeadsHidden + (A + 1);
+  heads_partial_sum_kernel<<<ceil_div(n, 16), 256, 0, s>>>(wpart, nblk, n, grad_heads);
+  return check_launch();
+}

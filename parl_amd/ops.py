@@ -130,6 +130,55 @@ def impala_loss(behaviour_logits, target_logits, actions, rewards, dones, values
     return vs, pg, glog, gval, sums
 
 
+def impala_heads_loss(hidden, w_policy, b_policy, w_value, b_value, behaviour_logits, actions, rewards, dones, gamma,
+                      clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0, vf_coeff=0.5, entropy_coeff=-0.01):
+    """policy_fc + value_fc + impala_loss + the heads' backward in one launch (time-major).  hidden f32
+    [T,B,256]; w_policy [A,256], b_policy [A], w_value [1,256] or [256], b_value [1]; the rest as
+    impala_loss with shapes [T,B(,A)].  Returns (vs, pg_advantages, grad_hidden, grad_w_policy,
+    grad_b_policy, grad_w_value, grad_b_value, sums) or None when the library has no instantiation."""
+    hd = _f32(hidden, 'hidden')
+    T, B, H = hd.shape
+    wp, bp = _f32(w_policy, 'w_policy'), _f32(b_policy, 'b_policy')
+    wv, bv = _f32(w_value, 'w_value').reshape(-1), _f32(b_value, 'b_value').reshape(-1)
+    A = wp.shape[0]
+    if wp.shape != (A, H) or wv.numel() != H or bp.numel() != A or bv.numel() != 1:
+        raise N.ParlHipError('impala_heads_loss: head shapes %r %r %r %r for hidden %r' %
+                             (tuple(wp.shape), tuple(bp.shape), tuple(wv.shape), tuple(bv.shape), tuple(hd.shape)))
+    bl = _f32(behaviour_logits, 'behaviour_logits')
+    if tuple(bl.shape) != (T, B, A):
+        raise N.ParlHipError('behaviour_logits must be [T,B,A]')
+    if actions.dtype != torch.int64:
+        raise N.ParlHipError('actions must be int64')
+    actions = actions.contiguous()
+    rew = _f32(rewards, 'rewards')
+    if dones.dtype == torch.bool:
+        dones = dones.contiguous().view(torch.uint8)
+    elif dones.dtype != torch.uint8:
+        raise N.ParlHipError('dones must be bool or uint8')
+    dones = dones.contiguous()
+    dev = hd.device
+    L = N.lib()
+    nws = L.parlhip_impala_heads_loss_workspace_bytes(B, A)
+    if nws == 0:
+        return None
+    vs = torch.empty((T - 1, B), dtype=torch.float32, device=dev)
+    pg = torch.empty((T - 1, B), dtype=torch.float32, device=dev)
+    gh = torch.empty_like(hd)
+    gheads = torch.empty((A + 1) * H + (A + 1), dtype=torch.float32, device=dev)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    sums = torch.zeros(4, dtype=torch.float64, device=dev)
+    code = L.parlhip_impala_heads_loss_f32(
+        N.ptr(hd), N.ptr(wp), N.ptr(bp), N.ptr(wv), N.ptr(bv), N.ptr(bl), N.ptr(actions), N.ptr(rew), N.ptr(dones),
+        N.ptr(vs), N.ptr(pg), N.ptr(gh), N.ptr(gheads), N.ptr(sums), N.ptr(ws), T, B, H, A, float(gamma),
+        _thr(clip_rho_threshold), _thr(clip_pg_rho_threshold), float(vf_coeff), float(entropy_coeff), N.stream_ptr())
+    if code == ENOSUP:
+        return None
+    N.check(code, 'parlhip_impala_heads_loss_f32')
+    gw = gheads[:(A + 1) * H].view(A + 1, H)
+    gb = gheads[(A + 1) * H:]
+    return vs, pg, gh, gw[:A], gb[:A], gw[A:], gb[A:], sums
+
+
 GAE_DONE_ENDS_STEP = 0
 GAE_DONE_STARTS_STEP = 1
 

@@ -385,3 +385,79 @@ def test_impala_learn_in_row_chunks_equals_one_pass(dev):
             assert abs(outs[0][0] - other[0]) <= 1e-4 * abs(outs[0][0])
             for a, b in zip(outs[0][1], other[1]):
                 assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize('T,B,A', [(50, 1024, 6), (50, 37, 4), (10, 5, 6), (64, 9, 4), (2, 3, 6)])
+def test_impala_heads_loss_matches_heads_plus_fused_loss(dev, T, B, A):
+    """parlhip_impala_heads_loss_f32 (policy_fc + value_fc + loss + the heads' backward, one kernel) against
+    torch heads in float64 + the float64 autograd of the reference formulas' kernel twin (ops.impala_loss
+    applied to float32 heads): sums, V-trace outputs, gradients w.r.t. the trunk output and the heads."""
+    from parl_amd import ops
+    torch.manual_seed(T * 1000 + B)
+    H = 256
+    hd = torch.relu(torch.randn(T, B, H, device=dev))
+    wp, bp = torch.randn(A, H, device=dev) * 0.1, torch.randn(A, device=dev) * 0.1
+    wv, bv = torch.randn(1, H, device=dev) * 0.05, torch.randn(1, device=dev) * 0.1
+    bl = torch.randn(T, B, A, device=dev)
+    act = torch.randint(0, A, (T, B), device=dev)
+    rew = torch.randn(T, B, device=dev)
+    dn = torch.rand(T, B, device=dev) < 0.05
+    out = ops.impala_heads_loss(hd, wp, bp, wv, bv, bl, act, rew, dn, 0.99, 1.0, 1.0, 0.5, -0.01)
+    assert out is not None
+    vs, pg, gh, gwp, gbp, gwv, gbv, sums = out
+    # reference: the same heads by torch (float32 GEMMs), the fused loss kernel behind them
+    hd_r = hd.clone().requires_grad_(True)
+    prm = [x.clone().requires_grad_(True) for x in (wp, bp, wv, bv)]
+    logits = torch.nn.functional.linear(hd_r, prm[0], prm[1])
+    values = torch.nn.functional.linear(hd_r, prm[2], prm[3]).squeeze(-1)
+    rvs, rpg, glog, gval, rsums = ops.impala_loss(bl, logits.detach(), act, rew, dn, values.detach(), 0.99, 1.0, 1.0,
+                                                  0.5, -0.01, time_major=True)
+    torch.autograd.backward([logits, values], [glog, gval])
+    np.testing.assert_allclose(sums.cpu().numpy(), rsums.cpu().numpy(), rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(vs.cpu().numpy(), rvs.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(pg.cpu().numpy(), rpg.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+    def close(a, b, name):
+        a, b = a.double().cpu().numpy(), b.double().cpu().numpy()
+        scale = np.abs(b).max() + 1e-12
+        assert np.abs(a - b).max() <= 2e-4 * scale, (name, np.abs(a - b).max(), scale)
+
+    close(gh, hd_r.grad, 'grad_hidden')
+    close(gwp, prm[0].grad, 'grad_w_policy')
+    close(gbp, prm[1].grad, 'grad_b_policy')
+    close(gwv.reshape(1, H), prm[2].grad, 'grad_w_value')
+    close(gbv, prm[3].grad, 'grad_b_value')
+    # deterministic apart from the f64 atomics of the four sums
+    out2 = ops.impala_heads_loss(hd, wp, bp, wv, bv, bl, act, rew, dn, 0.99, 1.0, 1.0, 0.5, -0.01)
+    for a, b in zip(out[:7], out2[:7]):
+        assert torch.equal(a, b)
+
+
+def test_impala_learn_fused_heads_equals_framework_heads(dev):
+    import copy
+    import parl_amd as parl
+    from parl_amd.models import AtariModel42
+    torch.manual_seed(1)
+    T, B, A = 50, 24, 6
+    base = AtariModel42(A).to(dev)
+    with torch.no_grad():  # N(0,1) heads (atari_model.py:44-57) make huge logits on a random trunk: tame them
+        base.policy_fc.weight.mul_(0.05)
+        base.value_fc.weight.mul_(0.05)
+    obs = torch.randint(0, 256, (T * B, 4, 42, 42), dtype=torch.uint8, device=dev)
+    act = torch.randint(0, A, (T * B, ), device=dev)
+    bl = torch.randn((T * B, A), device=dev)
+    rew = torch.randn(T * B, device=dev)
+    dn = torch.rand(T * B, device=dev) < 0.05
+    outs = []
+    for fused_heads, rows in ((False, None), (True, None), (True, 8 * T)):
+        m = copy.deepcopy(base)
+        alg = parl.algorithms.IMPALA(m, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
+                                     clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+        alg.fused_heads, alg.max_learn_rows = fused_heads, rows
+        loss, kl = alg.learn(obs, act, bl, rew, dn, 1e-3, -0.01, time_major=True)
+        outs.append((float(loss.total_loss.detach()), float(kl), [p.grad.detach().clone() for p in m.parameters()]))
+    for other in outs[1:]:
+        assert abs(outs[0][0] - other[0]) <= 1e-4 * abs(outs[0][0])
+        assert abs(outs[0][1] - other[1]) <= 1e-4 * abs(outs[0][1]) + 1e-7
+        for a, b in zip(outs[0][2], other[2]):
+            assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()) + 1e-7

@@ -99,5 +99,18 @@ z = torch.zeros(64, device=dev)
 flush_cache()
 ops.atari84_conv23(a1, w2c, z, w3c, z)
 out['conv23_84_fwd_n8192'] = {'kernel': 'conv23_84_mfma_kernel', 'read': n * 51200, 'write': n * 20736}
+# --- heads + loss + heads' backward at the workload shape
+T, B, A = 50, 1024, 6
+hd = torch.relu(torch.randn(T, B, 256, device=dev))
+wp, bp = torch.randn(A, 256, device=dev) * 0.1, torch.zeros(A, device=dev)
+wv, bv = torch.randn(1, 256, device=dev) * 0.05, torch.zeros(1, device=dev)
+bl = torch.randn(T, B, A, device=dev)
+ac = torch.randint(0, A, (T, B), device=dev)
+rw = torch.randn(T, B, device=dev)
+dn = torch.rand(T, B, device=dev) < 0.01
+flush_cache()
+ops.impala_heads_loss(hd, wp, bp, wv, bv, bl, ac, rw, dn, 0.99)
+out['impala_heads_loss_T50_B1024_A6'] = {'kernel': 'impala_heads_loss_kernel',
+                                         'read': T * B * (1024 + A * 4 + 8 + 4 + 1), 'write': T * B * 1024 + (T - 1) * B * 8}
 torch.cuda.synchronize()
 print(json.dumps(out))
