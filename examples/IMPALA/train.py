@@ -175,9 +175,13 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--minutes', type=float, default=None, help='stop after this many minutes')
     ap.add_argument('--env-num', type=int, default=None)
+    ap.add_argument('--env-name', default=None, help='PongNoFrameskip-v4 (config default) or BreakoutNoFrameskip-v4')
     ap.add_argument('--train-batch-size', type=int, default=None)
     ap.add_argument('--log-interval', type=float, default=None)
     args = ap.parse_args()
+    if args.env_name:
+        config['env_name'] = args.env_name
+        config['experiment_name'] = args.env_name.split('NoFrameskip')[0]
     if args.env_num:
         config['env_num'] = args.env_num
     if args.train_batch_size:
