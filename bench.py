@@ -364,6 +364,7 @@ def main():
         e.step_async = env_timer.wrap(e.step_async)
         e.step_elastic_async = env_timer.wrap(e.step_elastic_async)
         e._frame_post = fp_timer.wrap(e._frame_post)
+        e._frame_post_elastic = fp_timer.wrap(e._frame_post_elastic)
 
     if args.no_overlap:
         pipe = None

@@ -275,33 +275,39 @@ int parlhip_atari_vec_step(void* states, const uint32_t* rom_table_dev, uint32_t
                            int32_t* ep_lengths, int E, uint64_t seed, uint64_t env_id0,
                            int64_t max_episode_steps, const void* reset_cache_dev,
                            int32_t* jam_flag_dev, parlhip_stream_t stream);
-/* Elastic VectorEnv.step for a rollout of `rows_target` steps per env (examples/IMPALA/actor.py:58-76
- * collects sample_batch_steps steps of every env; the reference's actors are independent processes, so
- * one actor's slow step never holds up another's).  A launch emulates at most `frame_budget` (>= 4)
- * frames per env: an env whose step needs more — the 12 frames of a life-loss reset
- * (atari_wrappers.py:200-211 + :163-171), a real reset the snapshot cache cannot serve — parks its
- * wrapper state machine in its state blob and goes on in the following launches (taking no action,
- * delivering no observation: obs_flags bit 2 set, parlhip_frame_post_*_u8 skips the env) while the
- * other envs keep stepping; an env that has started `rows_target` steps waits.  Every env sees exactly
- * the frames and inputs parlhip_atari_vec_step gives it.  rewards / dones / obs_flags / ep_* [E] are
- * per-launch scratch as in parlhip_atari_vec_step (ep_* valid for every launch: feed each to
- * parlhip_episode_stats_accum_f64).  Per batch (the caller zeroes rows_done and *finished when a
- * batch begins; `launch` = 0, 1, 2, ... within it):
- *   rows_done i32 [E]; ctl u8 [E] scratch (0 started a row, 1 went on, 2 waited);
- *   row_launch i32 [rows_target,E] = the launch in which the env started its row r: the action and
- *     policy output of THAT launch belong to the row, its observation is the one the env held then;
- *   rewards_rows f32 / dones_rows u8 [rows_target,E], written by row;
- *   last_obs_launch i32 [E] = the last launch that completed a step of the env (its observation is
- *     in `frames` after that launch); *finished += 1 per env whose rows are complete.           */
+/* Elastic VectorEnv.step (examples/IMPALA/actor.py:58-76 collects sample_batch_steps steps of every env;
+ * the reference's actors are independent processes, so one actor's slow step never holds up another's).
+ * A launch emulates at most `frame_budget` (>= 4) frames per env: an env whose step needs more — the 12
+ * frames of a life-loss reset (atari_wrappers.py:200-211 + :163-171), a real reset the snapshot cache
+ * cannot serve — parks its wrapper state machine in its state blob and goes on in the following
+ * launches (taking no action, delivering no observation: obs_flags bit 2 set, parlhip_frame_post_*_u8
+ * skips the env) while the other envs keep stepping.  Every env sees exactly the frames and inputs
+ * parlhip_atari_vec_step gives it.  rewards / dones / obs_flags / ep_* [E] are per-launch scratch as in
+ * parlhip_atari_vec_step (ep_* valid for every launch: feed each to parlhip_episode_stats_accum_f64).
+ * Rows: rows_done i32 [E] counts the steps an env has started since the run began; row r of an env
+ * lives at index r % rows_ring of the row tables (rows_ring = a multiple of batch_rows, >= 2 batches);
+ * an env with rows_done >= rows_limit waits (the caller raises the limit as it consumes batches, so
+ * fast envs run ahead into the next batch instead of idling at a batch boundary).
+ *   row_launch i32 [rows_ring,E] = `launch` of the call in which the env started the row: the action
+ *     and policy output of THAT launch belong to the row, its observation is the one the env held;
+ *   rewards_rows f32 / dones_rows u8 [rows_ring,E], written by row; ctl u8 [E] scratch;
+ *   finished i32 [2]: finished[m & 1] += 1 when an env starts the last row of batch m.
+ * Observations: the caller runs parlhip_frame_post_u8(flags = obs_flags) into ring slot `new_slot` after
+ * this call; an env that completed a step gets cur_slot[e] = new_slot, link[new_slot][e] = the slot
+ * of its previous observation (i32 [S,E]; launches an env sat out leave gaps in the ring), since
+ * [new_slot][e] = FrameStack's count of valid older frames (u8 [S,E]); row_slot i32 [rows_ring,E] =
+ * the slot of the observation a row acted on.  Gather stacks with parlhip_stack_gather_ring_u8.   */
 int parlhip_atari_vec_step_elastic(void* states, const uint32_t* rom_table_dev, uint32_t rom_size,
                                    int game, const int64_t* actions, uint8_t* frames, float* rewards,
                                    uint8_t* dones, uint8_t* obs_flags, float* ep_returns,
                                    int32_t* ep_lengths, int E, uint64_t seed, uint64_t env_id0,
                                    int64_t max_episode_steps, const void* reset_cache_dev,
-                                   int32_t* jam_flag_dev, int frame_budget, int rows_target, int launch,
-                                   int32_t* rows_done, int32_t* row_launch, uint8_t* ctl,
-                                   int32_t* last_obs_launch, int32_t* finished, float* rewards_rows,
-                                   uint8_t* dones_rows, parlhip_stream_t stream);
+                                   int32_t* jam_flag_dev, int frame_budget, int launch, int rows_limit,
+                                   int rows_ring, int batch_rows, int32_t* rows_done,
+                                   int32_t* row_launch, int32_t* row_slot, uint8_t* ctl,
+                                   int32_t* finished, float* rewards_rows, uint8_t* dones_rows,
+                                   int new_slot, int32_t* cur_slot, int32_t* link, uint8_t* since,
+                                   parlhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * FrameStack (atari_wrappers.py:270-306) over a rollout ring of SINGLE frames
@@ -315,6 +321,12 @@ int parlhip_stack_since_update_u8(const uint8_t* obs_flags, const uint8_t* since
 int parlhip_stack_gather_u8(const uint8_t* ring, const uint8_t* since, int E, int frame_bytes,
                             const int32_t* slots, const int32_t* envs, int64_t n, uint8_t* out,
                             parlhip_stream_t stream);
+/* the same over a CIRCULAR ring of num_slots slots: slot - k wraps below 0; with link != NULL
+ * (i32 [S,E], parlhip_atari_vec_step_elastic) the older frames are found by following the env's
+ * links instead of stepping one slot back.                                                      */
+int parlhip_stack_gather_ring_u8(const uint8_t* ring, const uint8_t* since, const int32_t* link,
+                                 int num_slots, int E, int frame_bytes, const int32_t* slots,
+                                 const int32_t* envs, int64_t n, uint8_t* out, parlhip_stream_t stream);
 
 /* MonitorEnv.next_episode_results (atari_wrappers.py:88-95) reduced on the device: for the
  * episodes parlhip_atari_vec_step reported closed this step (ep_lengths[e] > 0):

@@ -418,9 +418,13 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
 #endif
 }
 
-// row accounting of an elastic launch, before the emulator: who starts a row, who goes on, who waits
-__global__ void elastic_pre_kernel(const uint8_t* __restrict__ states, int E, int rows_target, int launch,
-                                   int* __restrict__ rows_done, int* __restrict__ row_launch,
+// Row accounting of an elastic launch, before the emulator: who starts a row, who goes on, who waits.
+// Rows are numbered per env from the start of the run (rows_done); row r lives at index r % rows_ring of
+// the row tables; batch m = rows [m * batch_rows, (m + 1) * batch_rows).  An env may run ahead of the
+// slowest one up to rows_limit (the caller raises it as batches complete).
+__global__ void elastic_pre_kernel(const uint8_t* __restrict__ states, int E, int rows_limit, int rows_ring,
+                                   int launch, int* __restrict__ rows_done, int* __restrict__ row_launch,
+                                   int* __restrict__ row_slot, const int* __restrict__ cur_slot,
                                    uint8_t* __restrict__ ctl, uint8_t* __restrict__ obs_flags,
                                    int* __restrict__ ep_lengths) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -428,33 +432,43 @@ __global__ void elastic_pre_kernel(const uint8_t* __restrict__ states, int E, in
   const int susp = ((const int*)(states + (size_t)e * kStateBytes + kOffScalars))[S_SUSP];
   if (susp) { ctl[e] = CTL_CONTINUE; return; }
   const int row = rows_done[e];
-  if (row >= rows_target) { ctl[e] = CTL_IDLE; obs_flags[e] = 4; ep_lengths[e] = 0; return; }
+  if (row >= rows_limit) { ctl[e] = CTL_IDLE; obs_flags[e] = 4; ep_lengths[e] = 0; return; }
   ctl[e] = CTL_STEP;
-  row_launch[(size_t)row * E + e] = launch;
+  row_launch[(size_t)(row % rows_ring) * E + e] = launch;
+  row_slot[(size_t)(row % rows_ring) * E + e] = cur_slot[e];  // the observation this row acts on
   rows_done[e] = row + 1;
 }
 
 // ... and after it: the row's reward / done (a plain step of 4 frames always fits the budget, so they
-// are known in the launch that started the row), completion bookkeeping
-__global__ void elastic_post_kernel(const uint8_t* __restrict__ states, int E, int rows_target, int launch,
-                                    const int* __restrict__ rows_done, const uint8_t* __restrict__ ctl,
-                                    const float* __restrict__ rewards, const uint8_t* __restrict__ dones,
-                                    float* __restrict__ rewards_rows, uint8_t* __restrict__ dones_rows,
-                                    int* __restrict__ last_obs_launch, int* __restrict__ finished) {
+// are known in the launch that started the row); an env that has just started the last row of batch
+// m reports it in finished[m & 1]
+// Frame-stack bookkeeping of the elastic path lives here too: an env that completed its step in this
+// launch gets the ring slot new_slot for its observation; link[new_slot][e] = the slot of its previous
+// observation (launches it sat out leave gaps, so "the slot before" is not it), since = FrameStack's
+// count of valid older frames (0 after a reset: four copies, atari_wrappers.py:290-294).
+__global__ void elastic_post_kernel(int E, int rows_ring, int batch_rows, const int* __restrict__ rows_done,
+                                    const uint8_t* __restrict__ ctl, const float* __restrict__ rewards,
+                                    const uint8_t* __restrict__ dones, float* __restrict__ rewards_rows,
+                                    uint8_t* __restrict__ dones_rows, int* __restrict__ finished,
+                                    const uint8_t* __restrict__ obs_flags, int new_slot,
+                                    int* __restrict__ cur_slot, int* __restrict__ link,
+                                    uint8_t* __restrict__ since) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  const int c = ctl[e];
-  if (c == CTL_IDLE) return;
+  const int fl = obs_flags[e];
+  if (!(fl & 4)) {  // a new observation (frame_post writes it to ring[new_slot] next)
+    const int old = cur_slot[e];
+    const int p = since[(size_t)old * E + e];
+    link[(size_t)new_slot * E + e] = old;
+    since[(size_t)new_slot * E + e] = (fl & 2) ? 0 : (uint8_t)(p + 1 > 3 ? 3 : p + 1);
+    cur_slot[e] = new_slot;
+  }
+  if (ctl[e] != CTL_STEP) return;
   const int rd = rows_done[e];
-  if (c == CTL_STEP) {
-    rewards_rows[(size_t)(rd - 1) * E + e] = rewards[e];
-    dones_rows[(size_t)(rd - 1) * E + e] = dones[e];
-  }
-  const int susp = ((const int*)(states + (size_t)e * kStateBytes + kOffScalars))[S_SUSP];
-  if (!susp) {
-    last_obs_launch[e] = launch;
-    if (rd >= rows_target) atomicAdd(finished, 1);
-  }
+  const size_t at = (size_t)((rd - 1) % rows_ring) * E + e;
+  rewards_rows[at] = rewards[e];
+  dones_rows[at] = dones[e];
+  if (rd % batch_rows == 0) atomicAdd(finished + ((rd / batch_rows - 1) & 1), 1);
 }
 
 }  // namespace atari
@@ -567,28 +581,34 @@ PARLHIP_EXPORT int parlhip_atari_vec_step_elastic(void* states, const uint32_t* 
                                                   uint8_t* dones, uint8_t* obs_flags, float* ep_returns,
                                                   int32_t* ep_lengths, int E, uint64_t seed, uint64_t env_id0,
                                                   int64_t max_episode_steps, const void* reset_cache_dev,
-                                                  int32_t* jam_flag_dev, int frame_budget, int rows_target,
-                                                  int launch, int32_t* rows_done, int32_t* row_launch,
-                                                  uint8_t* ctl, int32_t* last_obs_launch, int32_t* finished,
-                                                  float* rewards_rows, uint8_t* dones_rows,
-                                                  parlhip_stream_t stream) {
+                                                  int32_t* jam_flag_dev, int frame_budget, int launch,
+                                                  int rows_limit, int rows_ring, int batch_rows,
+                                                  int32_t* rows_done, int32_t* row_launch, int32_t* row_slot,
+                                                  uint8_t* ctl, int32_t* finished, float* rewards_rows,
+                                                  uint8_t* dones_rows, int new_slot, int32_t* cur_slot,
+                                                  int32_t* link, uint8_t* since, parlhip_stream_t stream) {
   int rc = check_env_args(states, rom_table_dev, rom_size, game, E);
   if (rc) return rc;
   if (E == 0) return PARLHIP_OK;
   if (!actions || !frames || !rewards || !dones || !obs_flags || !ep_returns || !ep_lengths || !jam_flag_dev ||
-      !rows_done || !row_launch || !ctl || !last_obs_launch || !finished || !rewards_rows || !dones_rows)
+      !rows_done || !row_launch || !row_slot || !ctl || !finished || !rewards_rows || !dones_rows || !cur_slot ||
+      !link || !since || new_slot < 0)
     return PARLHIP_EINVAL;
-  if (frame_budget < 4 || rows_target < 1 || launch < 0) return PARLHIP_EINVAL;  // a plain step (4 frames) must fit
+  // a plain step (4 frames) must fit the budget; the row tables hold two batches
+  if (frame_budget < 4 || launch < 0 || batch_rows < 1 || rows_ring < 2 * batch_rows || rows_ring % batch_rows ||
+      rows_limit < 0)
+    return PARLHIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  elastic_pre_kernel<<<ceil_div(E, 256), 256, 0, s>>>((const uint8_t*)states, E, rows_target, launch, rows_done,
-                                                      row_launch, ctl, obs_flags, ep_lengths);
+  elastic_pre_kernel<<<ceil_div(E, 256), 256, 0, s>>>((const uint8_t*)states, E, rows_limit, rows_ring, launch,
+                                                      rows_done, row_launch, row_slot, cur_slot, ctl, obs_flags,
+                                                      ep_lengths);
   rc = launch_env(MODE_STEP, states, rom_table_dev, rom_size, game, actions, frames, rewards, dones, obs_flags,
                   ep_returns, ep_lengths, E, seed, env_id0, max_episode_steps, (void*)reset_cache_dev,
                   jam_flag_dev, s, frame_budget, ctl);
   if (rc) return rc;
-  elastic_post_kernel<<<ceil_div(E, 256), 256, 0, s>>>((const uint8_t*)states, E, rows_target, launch, rows_done,
-                                                       ctl, rewards, dones, rewards_rows, dones_rows,
-                                                       last_obs_launch, finished);
+  elastic_post_kernel<<<ceil_div(E, 256), 256, 0, s>>>(E, rows_ring, batch_rows, rows_done, ctl, rewards, dones,
+                                                       rewards_rows, dones_rows, finished, obs_flags, new_slot,
+                                                       cur_slot, link, since);
   return check_launch();
 }
 

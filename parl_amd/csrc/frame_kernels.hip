@@ -193,7 +193,9 @@ __global__ __launch_bounds__(512) void frame_post_kernel(
 __global__ __launch_bounds__(256) void stack_gather_kernel(
     const uint8_t* __restrict__ ring, const uint8_t* __restrict__ since, int E, int fsz,
     const int* __restrict__ slots, const int* __restrict__ envs, int64_t n,
-    uint8_t* __restrict__ out) {
+    uint8_t* __restrict__ out, int num_slots /* > 0: the ring is circular, slot - back wraps */,
+    const int* __restrict__ link /* [S,E] or null: slot of the env's PREVIOUS observation (elastic
+                                    launches leave gaps); null = the slot before */) {
   // one workgroup per (sample, channel); 16-byte copies
   const int64_t s = blockIdx.x >> 2;
   const int j = blockIdx.x & 3;
@@ -203,7 +205,14 @@ __global__ __launch_bounds__(256) void stack_gather_kernel(
   int back = 3 - j;
   const int sr = since[(size_t)slot * E + env];
   back = back < sr ? back : sr;
-  const uint8_t* src = ring + ((size_t)(slot - back) * E + env) * fsz;
+  int from = slot;
+  if (link) {
+    for (int k = 0; k < back; ++k) from = link[(size_t)from * E + env];
+  } else {
+    from = slot - back;
+    if (from < 0) from += num_slots;
+  }
+  const uint8_t* src = ring + ((size_t)from * E + env) * fsz;
   uint8_t* dst = out + ((size_t)s * 4 + j) * fsz;
   if ((fsz & 15) == 0) {
     for (int i = threadIdx.x; i < fsz / 16; i += blockDim.x) ((uint4*)dst)[i] = ((const uint4*)src)[i];
@@ -370,7 +379,20 @@ PARLHIP_EXPORT int parlhip_stack_gather_u8(const uint8_t* ring, const uint8_t* s
   if (!ring || !since || !out || !slots || !envs) return PARLHIP_EINVAL;
   if (n * 4 > 0x7fffffffLL) return PARLHIP_ENOSUP;
   stack_gather_kernel<<<(unsigned)(n * 4), 256, 0, (hipStream_t)stream>>>(ring, since, E, frame_bytes, slots,
-                                                                          envs, n, out);
+                                                                          envs, n, out, 0, nullptr);
+  return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_stack_gather_ring_u8(const uint8_t* ring, const uint8_t* since, const int32_t* link,
+                                                int num_slots, int E, int frame_bytes, const int32_t* slots,
+                                                const int32_t* envs, int64_t n, uint8_t* out,
+                                                parlhip_stream_t stream) {
+  if (E <= 0 || frame_bytes <= 0 || (frame_bytes & 3) || n < 0 || num_slots < 4) return PARLHIP_EINVAL;
+  if (n == 0) return PARLHIP_OK;
+  if (!ring || !since || !out || !slots || !envs) return PARLHIP_EINVAL;
+  if (n * 4 > 0x7fffffffLL) return PARLHIP_ENOSUP;
+  stack_gather_kernel<<<(unsigned)(n * 4), 256, 0, (hipStream_t)stream>>>(ring, since, E, frame_bytes, slots,
+                                                                          envs, n, out, num_slots, link);
   return check_launch();
 }
 

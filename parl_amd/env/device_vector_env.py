@@ -91,6 +91,8 @@ class DeviceVectorEnv(object):
         self.ring = torch.zeros((self.slots, E, self.fsz), **u8)
         self.since = torch.zeros((self.slots, E), **u8)
         self.t = 0
+        self.link = None      # elastic launches: [slots, E] slot of the env's previous observation
+        self.cur_slot = None  # elastic launches: [E] slot of the env's current observation
         self._env_idx = torch.arange(E, dtype=torch.int32, device=dev)
         self._slot_const = {}
         # --- O(1) real resets
@@ -120,9 +122,11 @@ class DeviceVectorEnv(object):
         if out is None:
             out = torch.empty((n, 4, self.dim, self.dim), dtype=torch.uint8, device=self.device)
         N.check(
-            N.lib().parlhip_stack_gather_u8(
-                N.ptr(self.ring), N.ptr(self.since), self.envs_num, self.fsz, N.ptr(slots.contiguous()),
-                N.ptr(envs.contiguous()), n, N.ptr(out), N.stream_ptr()), 'parlhip_stack_gather_u8')
+            N.lib().parlhip_stack_gather_ring_u8(
+                N.ptr(self.ring), N.ptr(self.since), N.ptr(self.link) if self.link is not None else None, self.slots,
+                self.envs_num, self.fsz,
+                N.ptr(slots.contiguous()),
+                N.ptr(envs.contiguous()), n, N.ptr(out), N.stream_ptr()), 'parlhip_stack_gather_ring_u8')
         return out
 
     def current_obs(self, out=None):
@@ -171,39 +175,52 @@ class DeviceVectorEnv(object):
         self.t += 1
         self._frame_post(self.t + 3)
 
-    def step_elastic_async(self, actions, launch, rows_target, rows_done, row_launch, last_obs_launch, finished,
-                           rewards_rows, dones_rows, frame_budget=4):
+    # ---------------------------------------------------------------- elastic launches (circular ring)
+    def elastic_begin(self):
+        """switch the ring to the elastic layout (after reset(): every env's observation is in slot 3)"""
+        E = self.envs_num
+        self.link = torch.zeros((self.slots, E), dtype=torch.int32, device=self.device)
+        self.cur_slot = torch.full((E, ), 3, dtype=torch.int32, device=self.device)
+
+    def elastic_obs(self, out=None):
+        """stacked obs every env currently holds (its own ring slot: envs that sat launches out lag behind)"""
+        return self.gather(self.cur_slot, self._env_idx, out)
+
+    def step_elastic_async(self, actions, launch, rows_limit, rows_ring, batch_rows, rows_done, row_launch, row_slot,
+                           finished, rewards_rows, dones_rows, frame_budget=4):
         """Enqueue one ELASTIC launch (parlhip_atari_vec_step_elastic): every env emulates at most
         `frame_budget` frames; an env inside a life-loss / slow reset sequence goes on with it instead of
-        taking `actions[e]`, an env that already started `rows_target` rows waits.  The observation of
-        an env that completed its step lands in ring slot launch + 4 (untouched otherwise)."""
+        taking `actions[e]`, an env with rows_done >= rows_limit waits.  `launch` counts from the
+        reset of the run; the ring is circular: the observation of an env that completed its step lands
+        in slot (launch + 4) % slots (untouched otherwise); cur_slot / link / since follow (elastic_begin)."""
         if actions.dtype != torch.int64:
             raise N.ParlHipError('actions must be int64')
-        if launch != self.t or launch >= self.horizon:
-            raise N.ParlHipError('elastic launch %d: ring position is %d of %d' % (launch, self.t, self.horizon))
         if not hasattr(self, '_ctl'):
             self._ctl = torch.zeros(self.envs_num, dtype=torch.uint8, device=self.device)
+        if self.link is None:
+            raise N.ParlHipError('call elastic_begin() after reset()')
+        slot = (launch + 4) % self.slots
         L = N.lib()
         N.check(
             L.parlhip_atari_vec_step_elastic(
                 N.ptr(self.states), N.ptr(self.rom_table), self.rom_size, self.game, N.ptr(actions.contiguous()),
                 N.ptr(self.raw_frames), N.ptr(self.rewards), N.ptr(self.dones), N.ptr(self.obs_flags),
                 N.ptr(self.ep_returns), N.ptr(self.ep_lengths), self.envs_num, self.seed, self.env_id0,
-                self.max_episode_steps, N.ptr(self.reset_cache), N.ptr(self.jam), int(frame_budget),
-                int(rows_target), int(launch), N.ptr(rows_done), N.ptr(row_launch), N.ptr(self._ctl),
-                N.ptr(last_obs_launch), N.ptr(finished), N.ptr(rewards_rows), N.ptr(dones_rows), N.stream_ptr()),
+                self.max_episode_steps, N.ptr(self.reset_cache), N.ptr(self.jam), int(frame_budget), int(launch),
+                int(rows_limit), int(rows_ring), int(batch_rows), N.ptr(rows_done), N.ptr(row_launch),
+                N.ptr(row_slot), N.ptr(self._ctl), N.ptr(finished), N.ptr(rewards_rows), N.ptr(dones_rows), slot,
+                N.ptr(self.cur_slot), N.ptr(self.link), N.ptr(self.since), N.stream_ptr()),
             'parlhip_atari_vec_step_elastic')
-        self.t += 1
-        self._frame_post(self.t + 3)
+        self._frame_post_elastic(slot)
 
-    def roll_elastic(self, last_obs_launch):
-        """roll() after an elastic batch: each env's newest observation sits in its own slot
-        (last_obs_launch[e] + 4); that slot and the three before it become slots 0..3."""
-        k = torch.arange(-3, 1, device=self.device)[:, None] + (last_obs_launch.long() + 4)[None, :]  # [4, E]
-        ev = self._env_idx.long()[None, :]
-        self.ring[0:4].copy_(self.ring[k, ev])
-        self.since[0:4].copy_(self.since[k, ev])
-        self.t = 0
+    def _frame_post_elastic(self, slot):
+        # max-2 + gray + INTER_AREA into ring[slot] for the envs that completed a step (obs_flags bit 2 clear);
+        # the FrameStack bookkeeping of the elastic path is done by the step call itself
+        N.check(
+            N.lib().parlhip_frame_post_u8(
+                N.ptr(self.raw_frames), self.raw_frames.data_ptr() + 210 * 160, 2 * 210 * 160, 1,
+                N.ptr(self.obs_flags), N.ptr(self.ring[slot]), self.fsz, self.envs_num, self.dim,
+                N.ptr(self.fp_tables), N.stream_ptr()), 'parlhip_frame_post_u8')
 
     def roll(self):
         """Start the next rollout: the last 4 frame slots become the history of obs time 0."""
@@ -233,6 +250,8 @@ class DeviceVectorEnv(object):
         (parl/core/torch/agent.py:100-124 saves the model only — a GPU-resident env has no other
         way to survive a restart)."""
         d = {k: getattr(self, k).detach().cpu().clone() for k in self._STATE_TENSORS}
+        if self.link is not None:  # elastic ring layout
+            d['link'], d['cur_slot'] = self.link.detach().cpu().clone(), self.cur_slot.detach().cpu().clone()
         d['meta'] = {'env_name': self.env_name, 'envs_num': self.envs_num, 'dim': self.dim, 'horizon': self.horizon,
                      'seed': self.seed, 'env_id0': self.env_id0, 'max_episode_steps': self.max_episode_steps,
                      't': self.t}
@@ -246,6 +265,10 @@ class DeviceVectorEnv(object):
                                  (k, getattr(self, k), m[k]))
         for k in self._STATE_TENSORS:
             getattr(self, k).copy_(d[k].to(self.device))
+        if 'link' in d:
+            self.elastic_begin()
+            self.link.copy_(d['link'].to(self.device))
+            self.cur_slot.copy_(d['cur_slot'].to(self.device))
         self.t = int(m['t'])
 
     def check_faults(self):

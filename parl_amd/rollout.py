@@ -124,91 +124,113 @@ class ElasticDeviceRollout(DeviceRollout):
     (EpisodicLifeEnv + FireResetEnv, atari_wrappers.py:200-211, :163-171) in nearly every launch — every
     launch then takes 16 frames instead of 4.  The reference never has this problem: its actors are
     independent processes (examples/IMPALA/train.py:155-194).  Here an env in such a sequence drops out
-    of the next launches (no action consumed, no row produced) and the others go on; an env with T rows
-    waits; the batch closes when every env has T rows (~T + 3 * max life losses per env launches).
+    of the next launches (no action consumed, no row produced) and the others go on — also across the
+    end of a batch: an env that has its T rows starts on the next batch's rows (up to one batch ahead
+    of the slowest env), so nobody idles at a batch boundary.  A batch closes when every env has
+    STARTED its T rows (a row's reward / done are known in the launch that starts it).
     Every env's rows are exactly the ones the synchronous rollout would have produced for the same
     actions; what changes is only in WHICH launch a row was produced, so per-launch outputs (policy
-    logits, sampled actions) are kept launch-major and compacted through row_launch at the end."""
+    logits, sampled actions, frames) live in rings indexed by launch and are compacted through
+    row_launch when the batch closes.  env.horizon + 4 = the ring's slots: it must hold the launches of
+    two batches (the rows of batch k are produced while batches k-1 and k are open)."""
 
     def __init__(self, env, sample_batch_steps, seed=0, n_buffers=1, poll_lag=2):
         super(ElasticDeviceRollout, self).__init__(env, sample_batch_steps, seed=seed, n_buffers=n_buffers)
         E, A, dev, T = env.envs_num, env.act_dim, env.device, self.T
-        self.Lmax = env.horizon
-        assert self.Lmax >= T + 3, 'elastic rollout: env horizon (max launches per batch) must exceed T'
+        self.S = env.slots  # ring slots == launches the rings remember
+        assert self.S >= 2 * T + 16, 'elastic rollout: env horizon must cover the launches of two batches'
         i32 = dict(dtype=torch.int32, device=dev)
-        self.actions_lm = torch.zeros((self.Lmax, E), dtype=torch.int64, device=dev)
-        self.logits_lm = torch.zeros((self.Lmax, E, A), dtype=torch.float32, device=dev)
+        self.actions_lm = torch.zeros((self.S, E), dtype=torch.int64, device=dev)
+        self.logits_lm = torch.zeros((self.S, E, A), dtype=torch.float32, device=dev)
         self.rows_done = torch.zeros(E, **i32)
-        self.row_launch = torch.zeros((T, E), **i32)
-        self.last_obs_launch = torch.zeros(E, **i32)
-        self.finished = torch.zeros(1, **i32)
-        self._fin_host = torch.zeros(self.Lmax, dtype=torch.int32).pin_memory() if dev.type == 'cuda' else \
-            torch.zeros(self.Lmax, dtype=torch.int32)
-        self._fin_events = [None] * self.Lmax
+        self.row_launch = torch.zeros((2 * T, E), **i32)
+        self.row_slot = torch.zeros((2 * T, E), **i32)
+        self.rewards_rows = torch.zeros((2 * T, E), dtype=torch.float32, device=dev)
+        self.dones_rows = torch.zeros((2 * T, E), dtype=torch.uint8, device=dev)
+        self.finished = torch.zeros(2, **i32)
+        self._fin_host = torch.zeros(self.S, dtype=torch.int32)
+        if dev.type == 'cuda':
+            self._fin_host = self._fin_host.pin_memory()
+        self._fin_events = [None] * self.S
         self.poll_lag = int(poll_lag)
-        self.launches = 0  # of the last batch
+        self.launch = 0    # launches since the reset of the run
+        self.batch = 0     # batches closed
+        self.launches = 0  # launches enqueued by the last collect_steps()
+        self._era = [0, 0]  # launch at which the collection of the last two batches began
 
     @torch.no_grad()
     def collect_begin(self):
-        env = self.env
         self._cur = (self._cur + 1) % len(self._bufs)
         self._select(self._cur)
         if not self.started:
-            env.reset()
+            self.env.reset()
+            self.env.elastic_begin()
             self.started = True
-        else:
-            env.roll_elastic(self.last_obs_launch)
-        self.rows_done.zero_()
-        self.finished.zero_()
 
     @torch.no_grad()
-    def collect_launch(self, model, l):
-        env = self.env
-        obs = env.current_obs(self._obs_step)
-        logits = self.logits_lm[l]
+    def collect_launch(self, model):
+        env, l = self.env, self.launch
+        k = l % self.S
+        obs = env.elastic_obs(self._obs_step)
+        logits = self.logits_lm[k]
         if hasattr(model, 'policy_into'):
             model.policy_into(obs, logits)
         else:
             logits.copy_(model.policy(obs))
-        ops.policy_sample_into(logits, self.actions_lm[l], self.seed, self.step_count, env.env_id0)
-        env.step_elastic_async(self.actions_lm[l], l, self.T, self.rows_done, self.row_launch, self.last_obs_launch,
-                               self.finished, self.rewards, self.dones)
+        ops.policy_sample_into(logits, self.actions_lm[k], self.seed, self.step_count, env.env_id0)
+        # envs may start rows of batch `batch + 1` while batch `batch` is still open, not more
+        env.step_elastic_async(self.actions_lm[k], l, (self.batch + 2) * self.T, 2 * self.T, self.T, self.rows_done,
+                               self.row_launch, self.row_slot, self.finished, self.rewards_rows, self.dones_rows)
         env.accumulate_episode_stats(self.ep_stats)
         self.step_count += 1
+        self.launch += 1
 
     @torch.no_grad()
     def collect_steps(self, model):
-        """launches until every env has T rows.  The host runs `poll_lag` launches ahead of the completion
-        counter it polls (no launch can close the batch before launch T-1), so the GPU never waits
-        for the host; at most `poll_lag` all-idle launches are enqueued past the end."""
-        E, T = self.env.envs_num, self.T
+        """launches until every env has started the T rows of the open batch.  The host polls the device's
+        completion counter `poll_lag` launches behind its enqueue position, so the GPU never waits for
+        the host; the launches enqueued past the closing one already work on the next batch."""
+        E, par = self.env.envs_num, self.batch & 1
         st = torch.cuda.current_stream(self.env.device)
-        l = 0
+        first = self.launch
+        self._era = [self._era[1], first]
+        polled = first  # launches < polled have been looked at
         while True:
-            if l >= self.Lmax:
-                raise RuntimeError('elastic rollout: %d launches did not complete %d rows of every env' % (l, T))
-            self.collect_launch(model, l)
-            if l >= T - 1:
-                self._fin_host[l:l + 1].copy_(self.finished, non_blocking=True)
-                ev = self._fin_events[l] or torch.cuda.Event()
-                self._fin_events[l] = ev
-                ev.record(st)
-                k = l - self.poll_lag
-                if k >= T - 1:
-                    self._fin_events[k].synchronize()
-                    if int(self._fin_host[k]) >= E:
-                        break
-            l += 1
-        self.launches = l + 1
+            # the rows of this batch were produced since the previous batch opened: the rings must still hold them
+            if self.launch - self._era[0] >= self.S - 8:
+                raise RuntimeError('elastic rollout: %d launches since the previous batch opened exceed the ring '
+                                   '(%d slots): raise the env horizon' % (self.launch - self._era[0], self.S))
+            self.collect_launch(model)
+            l = self.launch - 1
+            self._fin_host[l % self.S:l % self.S + 1].copy_(self.finished[par:par + 1], non_blocking=True)
+            ev = self._fin_events[l % self.S] or torch.cuda.Event()
+            self._fin_events[l % self.S] = ev
+            ev.record(st)
+            done = False
+            while polled <= l - self.poll_lag:
+                self._fin_events[polled % self.S].synchronize()
+                if int(self._fin_host[polled % self.S]) >= E:
+                    done = True
+                    break
+                polled += 1
+            if done:
+                break
+        self.launches = self.launch - first
 
     @torch.no_grad()
     def collect_end(self):
         env, T = self.env, self.T
         E = env.envs_num
-        idx = self.row_launch.long()  # [T, E]: launch of env e's row r
+        h = (self.batch & 1) * T
+        rl = self.row_launch[h:h + T]
+        idx = (rl % self.S).long()  # [T, E]: ring index of the launch that started env e's row r
         torch.gather(self.actions_lm, 0, idx, out=self.actions)
         torch.gather(self.logits_lm, 0, idx[:, :, None].expand(T, E, self.logits_lm.shape[2]), out=self.behaviour_logits)
-        env.gather((self.row_launch.reshape(-1) + 3), self._envs, self.obs)
+        env.gather(self.row_slot[h:h + T].reshape(-1), self._envs, self.obs)
+        self.rewards.copy_(self.rewards_rows[h:h + T])
+        self.dones.copy_(self.dones_rows[h:h + T])
+        self.finished[self.batch & 1].zero_()  # counts batch + 2 next; no env reaches its last row before the limit moves
+        self.batch += 1
         return {
             'obs': self.obs,
             'actions': self.actions.reshape(T * E),
@@ -224,6 +246,20 @@ class ElasticDeviceRollout(DeviceRollout):
 
     def collect_step(self, model, t):
         raise RuntimeError('ElasticDeviceRollout has no fixed step count: use collect_steps()')
+
+    def state_dict(self):
+        d = super(ElasticDeviceRollout, self).state_dict()
+        d.update({'launch': self.launch, 'batch': self.batch, 'era': list(self._era),
+                  'elastic': {k: getattr(self, k).detach().cpu().clone()
+                              for k in ('actions_lm', 'logits_lm', 'rows_done', 'row_launch', 'row_slot',
+                                        'rewards_rows', 'dones_rows', 'finished')}})
+        return d
+
+    def load_state_dict(self, d):
+        super(ElasticDeviceRollout, self).load_state_dict(d)
+        self.launch, self.batch, self._era = int(d['launch']), int(d['batch']), list(d['era'])
+        for k, v in d['elastic'].items():
+            getattr(self, k).copy_(v.to(getattr(self, k).device))
 
 
 class DeviceA2CRollout(object):

@@ -44,24 +44,36 @@ def test_elastic_rows_replay_through_the_oracle(dev, oracle):
     model = _model(dev, env.act_dim)
     orc = oracle.VecEnv(rom, 'breakout', E, dim, seed=seed)
     o_prev = orc.reset()
-    extra = ndone = 0
-    ep_n = ep_ret = ep_len = 0
+    # MonitorEnv records of every launch, per env in launch order
+    dev_eps = [[] for _ in range(E)]
+    acc = env.accumulate_episode_stats
+
+    def recording(acc3):
+        ln = env.ep_lengths.cpu().numpy()
+        rt = env.ep_returns.cpu().numpy()
+        for e in np.nonzero(ln)[0]:
+            dev_eps[e].append((float(rt[e]), int(ln[e])))
+        return acc(acc3)
+
+    env.accumulate_episode_stats = recording
+    total = ndone = 0
+    orc_eps = [[] for _ in range(E)]
     for b in range(batches):
         batch = ro.collect(model)
         torch.cuda.synchronize()
-        assert ro.launches >= T
-        extra += ro.launches - T
+        total += ro.launches
         obs = batch['obs'].view(T, E, 4, dim, dim).cpu().numpy()
         act = batch['actions'].view(T, E).cpu().numpy()
         rew = batch['rewards'].view(T, E).cpu().numpy()
         don = batch['dones'].view(T, E).cpu().numpy()
-        rl = ro.row_launch.cpu().numpy()
-        assert (np.diff(rl, axis=0) >= 1).all() and rl.max() < ro.launches
+        h = (b & 1) * T
+        rl = ro.row_launch[h:h + T].cpu().numpy()  # launches since the reset, per (row, env)
+        assert (np.diff(rl, axis=0) >= 1).all() and rl.max() < ro.launch and rl.min() >= 0
         # the policy output of the row's launch travels with the row
         lm = ro.logits_lm.cpu().numpy()
         bl = batch['behaviour_logits'].view(T, E, -1).cpu().numpy()
         for e in range(E):
-            assert np.array_equal(bl[:, e], lm[rl[:, e], e])
+            assert np.array_equal(bl[:, e], lm[rl[:, e] % ro.S, e])
         for r in range(T):
             assert np.array_equal(obs[r], o_prev), 'obs, batch %d row %d' % (b, r)
             o_prev, orr, od = orc.step(act[r])
@@ -69,13 +81,19 @@ def test_elastic_rows_replay_through_the_oracle(dev, oracle):
             assert np.array_equal(don[r].astype(np.uint8), od), 'done, batch %d row %d' % (b, r)
             ndone += int(od.sum())
         for e in range(E):
-            for ret, ln in orc.pop_episodes(e):
-                ep_n, ep_ret, ep_len = ep_n + 1, ep_ret + ret, ep_len + ln
+            orc_eps[e] += orc.pop_episodes(e)
     env.check_faults()
+    # fast envs are up to one batch ahead of the rows replayed: the oracle's records are a prefix of the device's
+    n_orc = 0
+    for e in range(E):
+        assert dev_eps[e][:len(orc_eps[e])] == orc_eps[e], e
+        n_orc += len(orc_eps[e])
     n, r, l = ro.pop_episode_stats()
-    assert n == ep_n and (n == 0 or (abs(r * n - ep_ret) < 1e-6 and abs(l * n - ep_len) < 1e-6))
+    assert n == sum(len(x) for x in dev_eps) >= n_orc
     assert ndone >= E, 'test too short: %d life losses' % ndone
-    assert extra > 0, 'no launch was ever elastic'
+    assert total > T * batches, 'no launch was ever elastic'
+    # envs ran ahead: when the last batch closed some had already started rows of the next one
+    assert int(ro.rows_done.max()) > T * batches
 
 
 def test_elastic_equals_synchronous_device_rollout_at_size(dev):
@@ -102,7 +120,7 @@ def test_elastic_equals_synchronous_device_rollout_at_size(dev):
     env.check_faults()
     ref.check_faults()
     # the point of it: far fewer than the 4 launch-times per row a synchronous vector pays when one env resets
-    assert T * batches < launches < 2 * T * batches
+    assert T * batches < launches < 1.35 * T * batches
 
 
 def test_elastic_pong_is_the_synchronous_rollout(dev):
@@ -112,7 +130,7 @@ def test_elastic_pong_is_the_synchronous_rollout(dev):
     E, T, dim = 64, 8, 42
     rom = _rom('pong')
     model = _model(dev, 6)
-    e1 = DeviceVectorEnv('PongNoFrameskip-v4', E, dim=dim, horizon=T + 8, seed=5, device=dev, rom_bytes=rom)
+    e1 = DeviceVectorEnv('PongNoFrameskip-v4', E, dim=dim, horizon=4 * T + 32, seed=5, device=dev, rom_bytes=rom)
     e2 = DeviceVectorEnv('PongNoFrameskip-v4', E, dim=dim, horizon=T, seed=5, device=dev, rom_bytes=rom)
     # poll_lag 0: the host waits for the completion counter after every launch from T-1 on, so no idle
     # launch is enqueued past the end and the Philox offsets (one per launch) stay those of DeviceRollout
@@ -122,11 +140,13 @@ def test_elastic_pong_is_the_synchronous_rollout(dev):
         assert r1.launches == T
         for k in b2:
             assert torch.equal(b1[k], b2[k]), k
-    # the default lagged poll costs poll_lag all-idle launches
-    e3 = DeviceVectorEnv('PongNoFrameskip-v4', E, dim=dim, horizon=T + 8, seed=5, device=dev, rom_bytes=rom)
+    # the default lagged poll: the poll_lag launches enqueued past the closing one already work on the next batch
+    e3 = DeviceVectorEnv('PongNoFrameskip-v4', E, dim=dim, horizon=4 * T + 32, seed=5, device=dev, rom_bytes=rom)
     r3 = ElasticDeviceRollout(e3, T, seed=9)
     r3.collect(model)
     assert r3.launches == T + r3.poll_lag
+    r3.collect(model)
+    assert r3.launches == T
 
 
 def test_async_actor_learner_elastic(dev):
@@ -145,5 +165,5 @@ def test_async_actor_learner_elastic(dev):
         loss, kl = aal.step(1e-4, -0.01)
     aal.synchronize()
     assert np.isfinite(float(loss.total_loss)) and np.isfinite(float(kl))
-    assert aal.rollout.launches >= T
+    assert aal.rollout.launch > 12 * T
     env.check_faults()
