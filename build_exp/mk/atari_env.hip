@@ -1,0 +1,622 @@
+// atari_env.hip — vectorised Atari env step for gfx950: ALE layer + the reference's wrapper
+// chain + VectorEnv auto-reset around the one-env-per-wavefront emulator (atari_core.hpp).
+//
+// Reference call sites this replaces (paths relative to the PARL tree):
+//   parl/env/vector_env.py:41-63            VectorEnv.step (auto-reset, returns the reset obs)
+//   parl/env/atari_wrappers.py:356-385      wrap_deepmind order; :223-240 MaxAndSkipEnv;
+//                                           :177-211 EpisodicLifeEnv; :114-130 NoopResetEnv;
+//                                           :163-171 FireResetEnv; :44-100 MonitorEnv;
+//                                           :149-151 ClipRewardEnv
+//   parl/env/compat_wrappers.py:85-99       CompatWrapper step counter
+//   examples/IMPALA/actor.py:66-67,95-101   the caller (vector_env.step, get_metrics)
+// Third party behind them (ALE via atari-py, gym TimeLimit): restated, see oracle/atari_oracle.h.
+//
+// The wrappers are recursive Python; here they are flattened into a small per-wave state
+// machine whose ONLY action is "emulate one more frame with this input, into that buffer" so
+// that the 6507/TIA code exists once in the kernel (instruction-cache footprint).
+#include "common.hpp"
+#include "atari_core.hpp"
+#include "philox.hpp"
+
+namespace parlhip {
+namespace atari {
+
+constexpr int kNumSnap = 30;  // NoopResetEnv noop_max
+constexpr size_t kSnapBytes = kStateBytes + 2 * (size_t)kFrameBytes;  // 67,712 (16-B multiple)
+static_assert(kSnapBytes % 16 == 0, "snapshot stride must keep 16-byte alignment");
+
+struct EnvParams {
+  int game, rom_size, E, mode;
+  unsigned long long seed, env_id0;
+  long long max_episode_steps;
+  int budget;  // elastic stepping: frames one launch may emulate per env (0: every step runs to its end)
+};
+
+// Elastic stepping (parlhip_atari_vec_step_elastic): a launch emulates at most `budget` frames per
+// env.  An env whose step needs more (the 12 frames of a life-loss reset: EpisodicLifeEnv's NOOP step +
+// FireResetEnv's two steps; the 64+ frames of a real reset when the snapshot cache cannot be used)
+// parks its wrapper state machine in the state blob (S_SUSP*) and goes on in the next launches,
+// taking no action and delivering no observation until its step is complete; the others keep
+// stepping.  Each env still sees exactly the sequence of frames and inputs the synchronous path gives
+// it.  The per-batch row accounting lives in two tiny kernels around the emulator (elastic_pre /
+// elastic_post): anything more that is live across the emulator's frame loop costs it dearly — with
+// the six row pointers as arguments of the env kernel itself its SGPR spills went from 420 to 24,881.
+enum : int { CTL_STEP = 0, CTL_CONTINUE = 1, CTL_IDLE = 2 };
+
+enum : int { MODE_STEP = 0, MODE_RESET = 1, MODE_SNAPSHOT = 2 };
+
+// state-machine phases: what the frame being emulated belongs to
+enum : int {
+  PH_SKIP = 0,  // a MaxAndSkipEnv.step frame (ctx says which caller)
+  PH_ALE,       // ALE reset_game(): 60 NOOP + 4 RESET-switch frames, no wrapper accounting
+  PH_NOOP,      // NoopResetEnv.reset noop frame
+  PH_END
+};
+enum : int { CTX_MAIN = 0, CTX_FIRE1, CTX_FIRE2, CTX_LIFE };  // who called MaxAndSkipEnv.step
+enum : int { TO_B = 0, TO_C, TO_END };                        // continuation after episodic_reset
+
+constexpr int kEnvsPerBlock = 4;   // 4 wavefronts share one LDS copy of the cartridge
+constexpr int kMaxRomWords = 4096;
+
+DEVI int action_code(int idx) {  // ALE minimal action sets (Pong 6, Breakout the first 4)
+  return idx == 0 ? ACT_NOOP : idx == 1 ? ACT_FIRE : idx == 2 ? ACT_RIGHT : idx == 3 ? ACT_LEFT
+         : idx == 4 ? ACT_RIGHTFIRE : ACT_LEFTFIRE;
+}
+
+// ---- state blob <-> registers ----
+struct Wrap {  // ALE + wrapper state (wave-uniform)
+  int paddle, score, terminal, ale_lives, started, frame_number;
+  int lives, was_real_done, has_episode, cur_reward, num_steps, reset_count, obs_single;
+  long long elapsed, compat_count;
+};
+
+DEVI void load_env(Emu& e, Wrap& v, const uint8_t* blob, int lane) {
+  const int* s = (const int*)(blob + kOffScalars);
+  e.ram_lo = blob[kOffRam + lane];
+  e.ram_hi = blob[kOffRam + 64 + lane];
+  e.tia = blob[kOffTia + lane];
+  auto L = [&](int i) { return rfl(s[i]); };
+  e.A = L(S_A); e.X = L(S_X); e.Y = L(S_Y); e.S = L(S_S); e.pset(L(S_P)); e.PC = L(S_PC);
+  e.cyc = L(S_CYC); e.cyc0 = L(S_CYC0); e.last_clock = L(S_LAST_CLOCK);
+  e.vsync_finish = L(S_VSYNC_FINISH); e.dump_dis_cyc = L(S_DUMP_DIS_CYC); e.dump_en = L(S_DUMP_EN);
+  e.timer = L(S_TIMER); e.timer_shift = L(S_TIMER_SHIFT); e.timer_set_cyc = L(S_TIMER_SET_CYC);
+  e.ddra = L(S_DDRA); e.ddrb = L(S_DDRB); e.swcha_out = L(S_SWCHA_OUT); e.swchb_out = L(S_SWCHB_OUT);
+  e.cx = L(S_CX); e.jam = L(S_JAM); e.stop = 0;
+  e.pneed0 = e.pneed1 = Emu::paddle_needed(kPaddleDefault); e.fire0 = e.fire1 = e.sw_reset = 0;
+  e.fb = nullptr;
+  v.paddle = L(S_PADDLE); v.score = L(S_SCORE); v.terminal = L(S_TERMINAL);
+  v.ale_lives = L(S_ALE_LIVES); v.started = L(S_STARTED); v.frame_number = L(S_FRAME_NUMBER);
+  v.lives = L(S_LIVES); v.was_real_done = L(S_WAS_REAL_DONE); v.has_episode = L(S_HAS_EPISODE);
+  v.cur_reward = L(S_CUR_REWARD); v.num_steps = L(S_NUM_STEPS); v.elapsed = L(S_ELAPSED);
+  v.compat_count = L(S_COMPAT_COUNT); v.reset_count = L(S_RESET_COUNT);
+  v.obs_single = L(S_OBS_SINGLE);
+}
+
+DEVI void store_env(const Emu& e, const Wrap& v, uint8_t* blob, int lane) {
+  int* s = (int*)(blob + kOffScalars);
+  blob[kOffRam + lane] = (uint8_t)e.ram_lo;
+  blob[kOffRam + 64 + lane] = (uint8_t)e.ram_hi;
+  blob[kOffTia + lane] = (uint8_t)e.tia;
+  if (lane == 0) {
+    s[S_A] = e.A; s[S_X] = e.X; s[S_Y] = e.Y; s[S_S] = e.S; s[S_P] = e.pfull(); s[S_PC] = e.PC;
+    s[S_BUS] = 0;
+    s[S_CYC] = e.cyc; s[S_CYC0] = e.cyc0; s[S_LAST_CLOCK] = e.last_clock;
+    s[S_VSYNC_FINISH] = e.vsync_finish; s[S_DUMP_DIS_CYC] = e.dump_dis_cyc; s[S_DUMP_EN] = e.dump_en;
+    s[S_TIMER] = e.timer; s[S_TIMER_SHIFT] = e.timer_shift; s[S_TIMER_SET_CYC] = e.timer_set_cyc;
+    s[S_DDRA] = e.ddra; s[S_DDRB] = e.ddrb; s[S_SWCHA_OUT] = e.swcha_out; s[S_SWCHB_OUT] = e.swchb_out;
+    s[S_CX] = e.cx; s[S_JAM] = e.jam;
+    s[S_PADDLE] = v.paddle; s[S_SCORE] = v.score; s[S_TERMINAL] = v.terminal;
+    s[S_ALE_LIVES] = v.ale_lives; s[S_STARTED] = v.started; s[S_FRAME_NUMBER] = v.frame_number;
+    s[S_LIVES] = v.lives; s[S_WAS_REAL_DONE] = v.was_real_done; s[S_HAS_EPISODE] = v.has_episode;
+    s[S_CUR_REWARD] = v.cur_reward; s[S_NUM_STEPS] = v.num_steps; s[S_ELAPSED] = (int)v.elapsed;
+    s[S_COMPAT_COUNT] = (int)v.compat_count; s[S_RESET_COUNT] = v.reset_count;
+    s[S_OBS_SINGLE] = v.obs_single;
+  }
+}
+
+#ifdef PARLHIP_ENV_TIMING  // diagnostic build only (tools/env_wave_times.py): per-wave start / end clocks
+__device__ unsigned long long g_env_t0[8192], g_env_t1[8192];
+#endif
+
+// One wavefront per env.  mode STEP: VectorEnv.step; RESET: VectorEnv.reset; SNAPSHOT: wave k
+// builds reset snapshot k (noops = k+1) for the O(1) real-reset path.
+template <int GAME>
+__global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
+    uint8_t* __restrict__ states, const uint32_t* __restrict__ romw_g, EnvParams prm,
+    const long long* __restrict__ actions, uint8_t* __restrict__ frames,
+    float* __restrict__ rewards, uint8_t* __restrict__ dones, uint8_t* __restrict__ obs_flags,
+    float* __restrict__ ep_returns, int* __restrict__ ep_lengths,
+    uint8_t* __restrict__ snap /* [30][kSnapBytes] or null */, int* __restrict__ jam_out,
+    const uint8_t* __restrict__ ctl /* [E] CTL_* per env, or null */) {
+  __shared__ uint32_t rom_lds[kMaxRomWords];
+  for (int i = threadIdx.x; i < prm.rom_size; i += blockDim.x) rom_lds[i] = romw_g[i];
+  __syncthreads();
+  // One wavefront per env is a long serial dependency chain: when other kernels (the learner's
+  // GEMMs on another stream) share the SIMD, this wave should win every issue arbitration.
+  __builtin_amdgcn_s_setprio(3);
+  const int lane = threadIdx.x & 63;
+  const int wave = rfl((int)(threadIdx.x >> 6));
+  const int e = blockIdx.x * kEnvsPerBlock + wave;
+  if (e >= prm.E) return;
+  // elastic stepping: this env's rows of the batch are complete, it waits for the others (its obs_flags /
+  // ep_lengths were written by elastic_pre_kernel).  The exit must be HERE: the same `return` placed
+  // after the Emu state exists (inside the MODE_STEP arm) took the kernel from 460 to 24,053 SGPR
+  // spills and its compile from 15 s to 190 s.
+  if (ctl && rfl((int)ctl[e]) == CTL_IDLE) return;
+#ifdef PARLHIP_ENV_TIMING
+  if (lane == 0 && e < 8192) g_env_t0[e] = wall_clock64();
+#endif
+  const int mode = prm.mode, game = prm.game;
+  // translated code is only used for the cartridge it was generated from (tag set by
+  // parlhip_atari_rom_table_build after a CRC match)
+  const bool native_ok = NativeCart<GAME>::present && rfl((int)(rom_lds[0] >> 28)) == GAME;
+  const long long max_steps = prm.max_episode_steps;
+
+  Emu emu;
+  Wrap v;
+  emu.romw = rom_lds;
+  emu.rom_mask = prm.rom_size - 1;
+  emu.lane = lane;
+  uint8_t* blob;
+  uint8_t *buf0, *buf1;
+  unsigned long long env_id;
+  if (mode == MODE_SNAPSHOT) {
+    blob = snap + (size_t)e * kSnapBytes;
+    buf0 = blob + kStateBytes;
+    env_id = 0;
+  } else {
+    blob = states + (size_t)e * kStateBytes;
+    buf0 = frames + (size_t)e * 2 * kFrameBytes;
+    env_id = prm.env_id0 + (unsigned long long)e;
+  }
+  buf1 = buf0 + kFrameBytes;
+
+  // ---- machine registers ----
+  int phase, ctx = CTX_MAIN, cont = TO_B, skip_i = 0, skip_total = 0, skip_act = ACT_NOOP;
+  int ale_j = 0, noops_left = 0, no_render = 0;
+  int ep_closed = 0, ep_return = 0, ep_length = 0;
+  int out_total = 0, out_done = 0, did_reset = 0;
+  const int fixed_noops = mode == MODE_SNAPSHOT ? e + 1 : 0;
+
+  // frames this launch may still emulate (a counter, not a loop-invariant `budget &&` test: LLVM
+  // would unswitch the frame loop on it, i.e. duplicate the emulator)
+  int frames_left = (mode == MODE_STEP && prm.budget) ? prm.budget : 0x7fffffff;
+  if (mode == MODE_STEP) {
+    const int c = ctl ? rfl((int)ctl[e]) : CTL_STEP;
+    load_env(emu, v, blob, lane);
+    if (c == CTL_CONTINUE) {  // go on where the previous launch stopped; no action is consumed
+      const int* sc = (const int*)(blob + kOffScalars);
+      const int susp = rfl(sc[S_SUSP]);
+      phase = susp & 3; ctx = (susp >> 2) & 3; cont = (susp >> 4) & 3; skip_i = (susp >> 6) & 7;
+      no_render = (susp >> 9) & 1;
+      skip_total = rfl(sc[S_SUSP_TOTAL]); skip_act = rfl(sc[S_SUSP_ACT]);
+      ale_j = rfl(sc[S_SUSP_ALE_J]); noops_left = rfl(sc[S_SUSP_NOOPS]);
+      did_reset = 1;  // only reset sequences are ever cut
+    } else {
+      int a = rfl((int)actions[e]);
+      const int na = game == GAME_BREAKOUT ? 4 : 6;
+      if (a < 0 || a >= na) a = 0;
+      phase = PH_SKIP; ctx = CTX_MAIN; skip_act = action_code(a);
+    }
+  } else {
+    emu.system_reset();
+    v.paddle = kPaddleDefault; v.score = v.terminal = v.ale_lives = v.started = v.frame_number = 0;
+    v.lives = 0; v.was_real_done = 1; v.has_episode = 0; v.cur_reward = 0; v.num_steps = 0;
+    v.elapsed = 0; v.compat_count = 0; v.reset_count = 0; v.obs_single = 0;
+    // FrameStack.reset -> FireResetEnv.reset -> EpisodicLifeEnv.reset (real) -> NoopResetEnv.reset
+    did_reset = 1;
+    phase = PH_ALE; ale_j = 0; cont = TO_B;
+  }
+
+  // Transitions: none of them emulates a frame — they only choose the next phase.  Macros, not
+  // lambdas: a by-reference closure that is not inlined forces the machine registers into
+  // scratch memory, and private-memory loads are "divergent" to the compiler — the whole 6507
+  // then gets compiled to VALU code.
+#define BEGIN_MONITOR_RESET() do { phase = PH_ALE; ale_j = 0; } while (0)
+#define BEGIN_SKIP(c, a) do { phase = PH_SKIP; ctx = (c); skip_act = (a); skip_i = 0; skip_total = 0; } while (0)
+  // what follows EpisodicLifeEnv.reset inside FireResetEnv.reset (lives: atari_wrappers.py:210)
+#define CONTINUE_AFTER() do {                                              \
+    v.lives = v.ale_lives;                                                 \
+    if (cont == TO_B) BEGIN_SKIP(CTX_FIRE1, ACT_FIRE);                     \
+    else if (cont == TO_C) BEGIN_SKIP(CTX_FIRE2, action_code(2));          \
+    else { no_render = 0; v.obs_single = 0; phase = PH_END; }              \
+  } while (0)
+  // EpisodicLifeEnv.reset :200-211
+#define BEGIN_EPISODIC_RESET(c) do {                                       \
+    cont = (c);                                                            \
+    if (v.was_real_done) BEGIN_MONITOR_RESET();                            \
+    else BEGIN_SKIP(CTX_LIFE, ACT_NOOP);                                   \
+  } while (0)
+
+  while (phase != PH_END) {
+    if (frames_left == 0) break;  // suspended: phase != PH_END at the exit
+    frames_left--;
+    // ------------------------------------------------------------------ choose input + target
+    int act;
+    uint8_t* fbp = nullptr;
+    if (phase == PH_SKIP) {
+      act = skip_act;
+      if (!no_render) fbp = skip_i == 2 ? buf0 : (skip_i == 3 ? buf1 : nullptr);
+    } else if (phase == PH_ALE) {
+      if (ale_j == 0) {  // ALE reset_game(): system reset first
+        v.paddle = kPaddleDefault;
+        const int keep = emu.jam;
+        emu.system_reset();
+        emu.jam = keep;
+      }
+      act = ale_j < 60 ? ACT_NOOP : ACT_RESET;
+    } else {  // PH_NOOP
+      act = ACT_NOOP;
+    }
+    {  // ALEState::applyActionPaddles
+      int delta = 0, fire = 0;
+      emu.sw_reset = act == ACT_RESET;
+      if (act == ACT_RIGHT || act == ACT_RIGHTFIRE) delta = -kPaddleDelta;
+      if (act == ACT_LEFT || act == ACT_LEFTFIRE) delta = kPaddleDelta;
+      if (act == ACT_FIRE || act == ACT_RIGHTFIRE || act == ACT_LEFTFIRE) fire = 1;
+      v.paddle += delta;
+      v.paddle = v.paddle < kPaddleMin ? kPaddleMin : (v.paddle > kPaddleMax ? kPaddleMax : v.paddle);
+      const bool swap = game == GAME_PONG;  // Stella props: Video Olympics SwapPaddles=YES
+      emu.pneed0 = Emu::paddle_needed(swap ? kPaddleDefault : v.paddle);
+      emu.pneed1 = Emu::paddle_needed(swap ? v.paddle : kPaddleDefault);
+      emu.fire0 = swap ? 0 : fire;
+      emu.fire1 = swap ? fire : 0;
+    }
+    // ------------------------------------------------------------------ THE frame
+    emu.frame<GAME>(fbp, native_ok);
+    // ------------------------------------------------------------------ after the frame
+    if (phase == PH_ALE) {
+      ale_j++;
+      if (ale_j == 64) {
+        // RomSettings::reset + the rest of MonitorEnv.reset / TimeLimit.reset
+        v.score = 0; v.terminal = 0; v.started = 0;
+        v.ale_lives = game == GAME_BREAKOUT ? 5 : 0;
+        v.frame_number = 0;
+        v.elapsed = 0;
+        if (v.has_episode) { ep_closed++; ep_return = v.cur_reward; ep_length = v.num_steps; }
+        v.has_episode = 1;
+        v.cur_reward = 0;
+        v.num_steps = 0;
+        if (noops_left > 0) {
+          // monitor_reset fired from inside the noop loop (:127-128): the loop just continues
+          noops_left--;
+          if (noops_left == 0) { v.obs_single = 1; CONTINUE_AFTER(); }
+          else phase = PH_NOOP;
+        } else {
+          int n;
+          if (fixed_noops) {
+            n = fixed_noops;
+          } else {  // np_random.randint(1, 31) restated: philox(seed; reset_count, env_id)
+            uint32_t w[4];
+            philox4x32_10(prm.seed, (unsigned long long)(unsigned)v.reset_count, env_id, w);
+            v.reset_count++;
+            n = 1 + (int)((uint32_t)rfl((int)w[0]) % 30u);
+          }
+          noops_left = n;
+          phase = PH_NOOP;
+        }
+      }
+      continue;
+    }
+    // raw_step accounting: RomSettings::step, TimeLimit, CompatWrapper, MonitorEnv
+    int reward = 0;
+    if (game == GAME_PONG) {
+      const int x = emu.ram_rd(13), y = emu.ram_rd(14);
+      const int sc = y - x;
+      reward = sc - v.score;
+      v.score = sc;
+      v.terminal = (x == 21 || y == 21);
+      v.ale_lives = 0;
+    } else {
+      const int x = emu.ram_rd(77), y = emu.ram_rd(76);
+      const int sc = (x & 0x0f) + 10 * ((x & 0xf0) >> 4) + 100 * (y & 0x0f);
+      reward = sc - v.score;
+      v.score = sc;
+      const int lv = emu.ram_rd(57);
+      if (!v.started && lv == 5) v.started = 1;
+      v.terminal = v.started && lv == 0;
+      v.ale_lives = lv;
+    }
+    v.frame_number++;
+    bool done = v.terminal != 0;
+    v.elapsed++;
+    if (v.elapsed >= max_steps) done = true;
+    v.compat_count++;
+    if (v.compat_count >= max_steps) { done = true; v.compat_count = 0; }
+    v.cur_reward += reward;
+    v.num_steps++;
+
+    if (phase == PH_NOOP) {
+      if (done) {
+        BEGIN_MONITOR_RESET();  // noops_left stays > 0: resume the loop after the ALE reset
+      } else {
+        noops_left--;
+        if (noops_left == 0) { v.obs_single = 1; CONTINUE_AFTER(); }
+      }
+      continue;
+    }
+    // PH_SKIP
+    skip_total += reward;
+    skip_i++;
+    if (!done && skip_i < 4) continue;
+    v.obs_single = 0;
+    if (ctx == CTX_LIFE) {  // the NOOP step of a non-real EpisodicLifeEnv.reset: result ignored
+      CONTINUE_AFTER();
+      continue;
+    }
+    // EpisodicLifeEnv.step :186-198
+    v.was_real_done = done;
+    bool d = done;
+    if (v.ale_lives < v.lives && v.ale_lives > 0) d = true;
+    v.lives = v.ale_lives;
+    if (ctx == CTX_MAIN) {
+      out_total = skip_total;
+      out_done = d;
+      if (!d) { phase = PH_END; continue; }
+      did_reset = 1;
+      if (snap && mode == MODE_STEP && v.was_real_done) {
+        // O(1) real reset: ALE reset + k noops + the two fire steps are a deterministic function
+        // of k, precomputed per k by MODE_SNAPSHOT.  Falls back to the general path when the
+        // never-reset CompatWrapper counter could fire inside the sequence.
+        uint32_t w[4];
+        philox4x32_10(prm.seed, (unsigned long long)(unsigned)v.reset_count, env_id, w);
+        const int k = (int)((uint32_t)rfl((int)w[0]) % 30u);  // noops = k + 1
+        const uint8_t* src = snap + (size_t)k * kSnapBytes;
+        const int* ss = (const int*)(src + kOffScalars);
+        const int delta = rfl(ss[S_COMPAT_COUNT]);
+        const int sjam = rfl(ss[S_JAM]);
+        if (!(sjam & 0x4000) && v.compat_count + delta < max_steps && delta < max_steps) {
+          if (v.has_episode) { ep_closed++; ep_return = v.cur_reward; ep_length = v.num_steps; }
+          const long long cc = v.compat_count + delta;
+          const int rc = v.reset_count + 1;
+          const int jam_keep = emu.jam;
+          load_env(emu, v, src, lane);
+          emu.jam |= jam_keep;
+          v.compat_count = cc;
+          v.reset_count = rc;
+          v.has_episode = 1;
+          const uint4* fs = (const uint4*)(src + kStateBytes);
+          uint4* fd = (uint4*)buf0;
+          for (int i = lane; i < 2 * kFrameBytes / 16; i += 64) fd[i] = fs[i];
+          phase = PH_END;
+          continue;
+        }
+      }
+      BEGIN_EPISODIC_RESET(TO_B);  // VectorEnv auto-reset -> FrameStack.reset -> FireResetEnv.reset
+    } else if (ctx == CTX_FIRE1) {  // FireResetEnv.reset :165-167
+      if (d && mode == MODE_SNAPSHOT) emu.jam |= 0x4000;  // canned sequence deviated
+      if (d) BEGIN_EPISODIC_RESET(TO_C);
+      else BEGIN_SKIP(CTX_FIRE2, action_code(2));
+    } else {  // CTX_FIRE2 :168-171: the obs of step(2) is returned even if a reset follows
+      if (d) { no_render = 1; BEGIN_EPISODIC_RESET(TO_END); }
+      else phase = PH_END;
+    }
+  }
+
+  if (mode == MODE_SNAPSHOT) {
+    // a done / closed episode inside the canned sequence would need the general path
+    if (ep_closed || v.was_real_done) emu.jam |= 0x4000;
+  } else if (lane == 0) {
+    if (mode == MODE_STEP) {
+      rewards[e] = (float)((out_total > 0) - (out_total < 0));  // ClipRewardEnv: np.sign
+      dones[e] = out_done ? 1 : 0;
+      ep_returns[e] = (float)ep_return;
+      ep_lengths[e] = ep_closed ? ep_length : 0;
+    }
+    // bit 2: the env's step is not complete, no observation in this launch (frame_post skips the env)
+    const int suspended = phase != PH_END;
+    obs_flags[e] = (uint8_t)((suspended ? 4 : 0) | (did_reset ? 2 : 0) | (v.obs_single ? 1 : 0));
+    if (emu.jam) atomicOr(jam_out, emu.jam);
+    int* sc = (int*)(blob + kOffScalars);
+    sc[S_SUSP] = suspended ? (0x400 | phase | (ctx << 2) | (cont << 4) | (skip_i << 6) | (no_render << 9)) : 0;
+    sc[S_SUSP_TOTAL] = skip_total; sc[S_SUSP_ACT] = skip_act;
+    sc[S_SUSP_ALE_J] = ale_j; sc[S_SUSP_NOOPS] = noops_left;
+  }
+  store_env(emu, v, blob, lane);
+#ifdef PARLHIP_ENV_TIMING
+  if (lane == 0 && e < 8192) g_env_t1[e] = wall_clock64();
+#endif
+}
+
+// Row accounting of an elastic launch, before the emulator: who starts a row, who goes on, who waits.
+// Rows are numbered per env from the start of the run (rows_done); row r lives at index r % rows_ring of
+// the row tables; batch m = rows [m * batch_rows, (m + 1) * batch_rows).  An env may run ahead of the
+// slowest one up to rows_limit (the caller raises it as batches complete).
+__global__ void elastic_pre_kernel(const uint8_t* __restrict__ states, int E, int rows_limit, int rows_ring,
+                                   int launch, int* __restrict__ rows_done, int* __restrict__ row_launch,
+                                   int* __restrict__ row_slot, const int* __restrict__ cur_slot,
+                                   uint8_t* __restrict__ ctl, uint8_t* __restrict__ obs_flags,
+                                   int* __restrict__ ep_lengths) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int susp = ((const int*)(states + (size_t)e * kStateBytes + kOffScalars))[S_SUSP];
+  if (susp) { ctl[e] = CTL_CONTINUE; return; }
+  const int row = rows_done[e];
+  if (row >= rows_limit) { ctl[e] = CTL_IDLE; obs_flags[e] = 4; ep_lengths[e] = 0; return; }
+  ctl[e] = CTL_STEP;
+  row_launch[(size_t)(row % rows_ring) * E + e] = launch;
+  row_slot[(size_t)(row % rows_ring) * E + e] = cur_slot[e];  // the observation this row acts on
+  rows_done[e] = row + 1;
+}
+
+// ... and after it: the row's reward / done (a plain step of 4 frames always fits the budget, so they
+// are known in the launch that started the row); an env that has just started the last row of batch
+// m reports it in finished[m & 1]
+// Frame-stack bookkeeping of the elastic path lives here too: an env that completed its step in this
+// launch gets the ring slot new_slot for its observation; link[new_slot][e] = the slot of its previous
+// observation (launches it sat out leave gaps, so "the slot before" is not it), since = FrameStack's
+// count of valid older frames (0 after a reset: four copies, atari_wrappers.py:290-294).
+__global__ void elastic_post_kernel(int E, int rows_ring, int batch_rows, const int* __restrict__ rows_done,
+                                    const uint8_t* __restrict__ ctl, const float* __restrict__ rewards,
+                                    const uint8_t* __restrict__ dones, float* __restrict__ rewards_rows,
+                                    uint8_t* __restrict__ dones_rows, int* __restrict__ finished,
+                                    const uint8_t* __restrict__ obs_flags, int new_slot,
+                                    int* __restrict__ cur_slot, int* __restrict__ link,
+                                    uint8_t* __restrict__ since) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int fl = obs_flags[e];
+  if (!(fl & 4)) {  // a new observation (frame_post writes it to ring[new_slot] next)
+    const int old = cur_slot[e];
+    const int p = since[(size_t)old * E + e];
+    link[(size_t)new_slot * E + e] = old;
+    since[(size_t)new_slot * E + e] = (fl & 2) ? 0 : (uint8_t)(p + 1 > 3 ? 3 : p + 1);
+    cur_slot[e] = new_slot;
+  }
+  if (ctl[e] != CTL_STEP) return;
+  const int rd = rows_done[e];
+  const size_t at = (size_t)((rd - 1) % rows_ring) * E + e;
+  rewards_rows[at] = rewards[e];
+  dones_rows[at] = dones[e];
+  if (rd % batch_rows == 0) atomicAdd(finished + ((rd / batch_rows - 1) & 1), 1);
+}
+
+}  // namespace atari
+}  // namespace parlhip
+
+using namespace parlhip;
+using namespace parlhip::atari;
+
+PARLHIP_EXPORT size_t parlhip_atari_state_bytes(void) { return kStateBytes; }
+PARLHIP_EXPORT size_t parlhip_atari_frame_bytes(void) { return 2 * (size_t)kFrameBytes; }
+PARLHIP_EXPORT size_t parlhip_atari_rom_table_bytes(uint32_t rom_size) { return (size_t)rom_size * 4; }
+PARLHIP_EXPORT size_t parlhip_atari_reset_cache_bytes(void) { return kNumSnap * kSnapBytes; }
+
+PARLHIP_EXPORT int parlhip_atari_rom_table_build(const uint8_t* rom_host, uint32_t rom_size,
+                                                 uint32_t* table_host) {
+  if (!rom_host || !table_host) return PARLHIP_EINVAL;
+  if (rom_size != 2048 && rom_size != 4096) return PARLHIP_ENOSUP;  // unbanked 2K/4K carts
+  build_rom_words(rom_host, rom_size, table_host);
+  // tag the table (free top bits of word 0) when this is a cartridge the library carries
+  // natively translated code for
+  uint32_t crc = 0xffffffffu;
+  for (uint32_t i = 0; i < rom_size; ++i) {
+    crc ^= rom_host[i];
+    for (int k = 0; k < 8; ++k) crc = (crc >> 1) ^ (0xedb88320u & (0u - (crc & 1u)));
+  }
+  crc = ~crc;
+  uint32_t tag = 0;
+  if (NativeCart<GAME_PONG>::present && crc == NativeCart<GAME_PONG>::rom_crc32) tag = GAME_PONG;
+  if (NativeCart<GAME_BREAKOUT>::present && crc == NativeCart<GAME_BREAKOUT>::rom_crc32) tag = GAME_BREAKOUT;
+  table_host[0] = (table_host[0] & 0x0fffffffu) | (tag << 28);
+  return PARLHIP_OK;
+}
+
+PARLHIP_EXPORT uint32_t parlhip_atari_native_cart(int game) {
+  if (game == GAME_PONG && NativeCart<GAME_PONG>::present) return NativeCart<GAME_PONG>::rom_crc32;
+  if (game == GAME_BREAKOUT && NativeCart<GAME_BREAKOUT>::present) return NativeCart<GAME_BREAKOUT>::rom_crc32;
+  return 0;
+}
+
+PARLHIP_EXPORT int parlhip_atari_num_actions(int game) {
+  return game == GAME_BREAKOUT ? 4 : (game == GAME_PONG ? 6 : -1);
+}
+
+static int check_env_args(const void* states, const void* romw, uint32_t rom_size, int game, int E) {
+  if (E < 0 || !romw || (E > 0 && !states)) return PARLHIP_EINVAL;
+  if (rom_size != 2048 && rom_size != 4096) return PARLHIP_ENOSUP;
+  if (game != GAME_PONG && game != GAME_BREAKOUT) return PARLHIP_ENOSUP;
+  return PARLHIP_OK;
+}
+
+static int launch_env(int mode, void* states, const uint32_t* romw, uint32_t rom_size, int game,
+                      const int64_t* actions, uint8_t* frames, float* rewards, uint8_t* dones,
+                      uint8_t* obs_flags, float* ep_returns, int32_t* ep_lengths, int E, uint64_t seed,
+                      uint64_t env_id0, int64_t max_steps, void* snap, int32_t* jam, hipStream_t s,
+                      int budget = 0, const uint8_t* ctl = nullptr) {
+  EnvParams prm{game, (int)rom_size, E, mode, seed, env_id0, (long long)max_steps, budget};
+  const dim3 grid(ceil_div(E, kEnvsPerBlock)), block(64 * kEnvsPerBlock);
+#define PARLHIP_LAUNCH_ENV(G)                                                                           \
+  atari_env_kernel<G><<<grid, block, 0, s>>>((uint8_t*)states, romw, prm, (const long long*)actions,     \
+                                             frames, rewards, dones, obs_flags, ep_returns, ep_lengths, \
+                                             (uint8_t*)snap, jam, ctl)
+  if (game == GAME_PONG) PARLHIP_LAUNCH_ENV(GAME_PONG);
+  else PARLHIP_LAUNCH_ENV(GAME_BREAKOUT);
+#undef PARLHIP_LAUNCH_ENV
+  return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_atari_reset_cache_build(const uint32_t* rom_table_dev, uint32_t rom_size,
+                                                   int game, int64_t max_episode_steps, void* cache_dev,
+                                                   int32_t* jam_flag_dev, parlhip_stream_t stream) {
+  int rc = check_env_args((void*)1, rom_table_dev, rom_size, game, 1);
+  if (rc) return rc;
+  if (!cache_dev || !jam_flag_dev) return PARLHIP_EINVAL;
+  return launch_env(MODE_SNAPSHOT, nullptr, rom_table_dev, rom_size, game, nullptr, nullptr, nullptr,
+                    nullptr, nullptr, nullptr, nullptr, kNumSnap, 0, 0, max_episode_steps, cache_dev,
+                    jam_flag_dev, (hipStream_t)stream);
+}
+
+PARLHIP_EXPORT int parlhip_atari_vec_reset(void* states, const uint32_t* rom_table_dev, uint32_t rom_size,
+                                           int game, uint8_t* frames, uint8_t* obs_flags, int E,
+                                           uint64_t seed, uint64_t env_id0, int64_t max_episode_steps,
+                                           int32_t* jam_flag_dev, parlhip_stream_t stream) {
+  int rc = check_env_args(states, rom_table_dev, rom_size, game, E);
+  if (rc) return rc;
+  if (E == 0) return PARLHIP_OK;
+  if (!frames || !obs_flags || !jam_flag_dev) return PARLHIP_EINVAL;
+  return launch_env(MODE_RESET, states, rom_table_dev, rom_size, game, nullptr, frames, nullptr, nullptr,
+                    obs_flags, nullptr, nullptr, E, seed, env_id0, max_episode_steps, nullptr, jam_flag_dev,
+                    (hipStream_t)stream);
+}
+
+PARLHIP_EXPORT int parlhip_atari_vec_step(void* states, const uint32_t* rom_table_dev, uint32_t rom_size,
+                                          int game, const int64_t* actions, uint8_t* frames, float* rewards,
+                                          uint8_t* dones, uint8_t* obs_flags, float* ep_returns,
+                                          int32_t* ep_lengths, int E, uint64_t seed, uint64_t env_id0,
+                                          int64_t max_episode_steps, const void* reset_cache_dev,
+                                          int32_t* jam_flag_dev, parlhip_stream_t stream) {
+  int rc = check_env_args(states, rom_table_dev, rom_size, game, E);
+  if (rc) return rc;
+  if (E == 0) return PARLHIP_OK;
+  if (!actions || !frames || !rewards || !dones || !obs_flags || !ep_returns || !ep_lengths || !jam_flag_dev)
+    return PARLHIP_EINVAL;
+  return launch_env(MODE_STEP, states, rom_table_dev, rom_size, game, actions, frames, rewards, dones,
+                    obs_flags, ep_returns, ep_lengths, E, seed, env_id0, max_episode_steps,
+                    (void*)reset_cache_dev, jam_flag_dev, (hipStream_t)stream);
+}
+
+PARLHIP_EXPORT int parlhip_atari_vec_step_elastic(void* states, const uint32_t* rom_table_dev, uint32_t rom_size,
+                                                  int game, const int64_t* actions, uint8_t* frames, float* rewards,
+                                                  uint8_t* dones, uint8_t* obs_flags, float* ep_returns,
+                                                  int32_t* ep_lengths, int E, uint64_t seed, uint64_t env_id0,
+                                                  int64_t max_episode_steps, const void* reset_cache_dev,
+                                                  int32_t* jam_flag_dev, int frame_budget, int launch,
+                                                  int rows_limit, int rows_ring, int batch_rows,
+                                                  int32_t* rows_done, int32_t* row_launch, int32_t* row_slot,
+                                                  uint8_t* ctl, int32_t* finished, float* rewards_rows,
+                                                  uint8_t* dones_rows, int new_slot, int32_t* cur_slot,
+                                                  int32_t* link, uint8_t* since, parlhip_stream_t stream) {
+  int rc = check_env_args(states, rom_table_dev, rom_size, game, E);
+  if (rc) return rc;
+  if (E == 0) return PARLHIP_OK;
+  if (!actions || !frames || !rewards || !dones || !obs_flags || !ep_returns || !ep_lengths || !jam_flag_dev ||
+      !rows_done || !row_launch || !row_slot || !ctl || !finished || !rewards_rows || !dones_rows || !cur_slot ||
+      !link || !since || new_slot < 0)
+    return PARLHIP_EINVAL;
+  // a plain step (4 frames) must fit the budget; the row tables hold two batches
+  if (frame_budget < 4 || launch < 0 || batch_rows < 1 || rows_ring < 2 * batch_rows || rows_ring % batch_rows ||
+      rows_limit < 0)
+    return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  elastic_pre_kernel<<<ceil_div(E, 256), 256, 0, s>>>((const uint8_t*)states, E, rows_limit, rows_ring, launch,
+                                                      rows_done, row_launch, row_slot, cur_slot, ctl, obs_flags,
+                                                      ep_lengths);
+  rc = launch_env(MODE_STEP, states, rom_table_dev, rom_size, game, actions, frames, rewards, dones, obs_flags,
+                  ep_returns, ep_lengths, E, seed, env_id0, max_episode_steps, (void*)reset_cache_dev,
+                  jam_flag_dev, s, frame_budget, ctl);
+  if (rc) return rc;
+  elastic_post_kernel<<<ceil_div(E, 256), 256, 0, s>>>(E, rows_ring, batch_rows, rows_done, ctl, rewards, dones,
+                                                       rewards_rows, dones_rows, finished, obs_flags, new_slot,
+                                                       cur_slot, link, since);
+  return check_launch();
+}
+
+#ifdef PARLHIP_ENV_TIMING
+PARLHIP_EXPORT int parlhip_debug_env_clocks(unsigned long long* t0_host, unsigned long long* t1_host, int n) {
+  if (n > 8192) return PARLHIP_EINVAL;
+  if (hipMemcpyFromSymbol(t0_host, HIP_SYMBOL(parlhip::atari::g_env_t0), (size_t)n * 8) != hipSuccess) return PARLHIP_EINVAL;
+  if (hipMemcpyFromSymbol(t1_host, HIP_SYMBOL(parlhip::atari::g_env_t1), (size_t)n * 8) != hipSuccess) return PARLHIP_EINVAL;
+  return PARLHIP_OK;
+}
+#endif

@@ -1,0 +1,1119 @@
+// conv_kernels.hip — fused conv1 + conv2 of the IMPALA Atari network on gfx950 MFMA, reading
+// the uint8 observations of the rollout ring directly.
+//
+// Reference: examples/IMPALA/atari_model.py:21-90 (AtariModel): obs / 255 (:66),
+// conv1 4->16 k4 s2 p1 + ReLU (42x42 -> 21x21), conv2 16->32 k4 s2 p2 + ReLU (-> 11x11); in the
+// reference every actor runs these as cuDNN/CPU convs on a batch of 5 per env step
+// (examples/IMPALA/atari_agent.py:25-42).  Here the actor path runs them for all envs of a GPU
+// in ONE kernel per env step: no im2col matrices in HBM (the GEMM-lowered convs write and re-read
+// 115 + 127 MB per step at 1024 envs), no intermediate activations in HBM.
+//
+// One workgroup (4 wavefronts) per observation.  Both convolutions are implicit GEMMs on the
+// f32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32 FMA chains), weights held in registers:
+//   conv1: [441 positions x 64] x [64 x 16]   A gathered from the zero-padded input in LDS
+//   conv2: [121 positions x 256] x [256 x 32] A gathered from the zero-padded conv1 output in LDS
+// with k = c*16 + kh*4 + kw (the order of weight.flatten(1)).  Operand maps (guide: A[l&15][l>>4],
+// B[l>>4][l&15], D col = l&15, row = 4*(l>>4) + reg).
+#include "common.hpp"
+
+namespace parlhip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kD = 42, kP1 = 44;          // input, zero-padded input (pad 1, +1 slack column/row)
+constexpr int kO1 = 21, kC1 = 16;         // conv1 output size / channels
+constexpr int kP2 = 25;                   // zero-padded conv1 output (pad 2)
+constexpr int kO2 = 11, kC2 = 32;         // conv2 output size / channels
+constexpr int kM1 = kO1 * kO1, kM2 = kO2 * kO2;
+constexpr int kK1 = 64, kK2 = 256;
+constexpr int kLdsIn = 4 * kP1 * kP1;     // 7744 floats
+constexpr int kLdsC1 = kC1 * kP2 * kP2;   // 10000
+constexpr int kLdsFloats = kLdsIn + kLdsC1;  // 17,744 floats = 70,976 B: two workgroups per CU
+
+// Both weight matrices live in registers (B operands: 16 + 128 VGPRs per lane, loaded once per
+// workgroup), so an MFMA needs one LDS gather (conv1) or half of one (conv2: both N-tiles reuse
+// the A value); outputs leave the accumulators straight for HBM; the zero borders of the two LDS
+// tiles are written once and never touched again (only interiors are rewritten per observation).
+__global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
+    const uint8_t* __restrict__ obs, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ out, int n_obs) {
+  extern __shared__ float lds[];
+  float* in_pad = lds;                  // [4][44][44]
+  float* c1_pad = in_pad + kLdsIn;      // [16][25][25]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, col = lane & 15;
+  // B[k][n] = w[n][k]: lane (q, col) holds k = 4*ks + q, n = col (+16 for the second N-tile)
+  float bw1[16], bw2[64][2];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) bw1[ks] = w1[col * kK1 + ks * 4 + q];
+#pragma unroll
+  for (int ks = 0; ks < 64; ++ks) {
+    bw2[ks][0] = w2[col * kK2 + ks * 4 + q];
+    bw2[ks][1] = w2[(16 + col) * kK2 + ks * 4 + q];
+  }
+  const float bias1 = b1[col], bias20 = b2[col], bias21 = b2[16 + col];
+  for (int i = tid; i < kLdsFloats; i += 256) lds[i] = 0.0f;
+  for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
+    __syncthreads();  // borders zeroed / the previous observation's conv2 gathers are done
+    // ---- obs u8 -> padded float input (x / 255, the division as in the reference) ----
+    const uint8_t* src = obs + (size_t)n * 4 * kD * kD;
+    if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {  // wave-uniform: 7056 B per observation
+      const uint32_t* src32 = reinterpret_cast<const uint32_t*>(src);
+      for (int wi = tid; wi < kD * kD; wi += 256) {   // 4 * 1764 bytes = 1764 words
+        const uint32_t v = src32[wi];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = wi * 4 + j;
+          const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
+          in_pad[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = (float)((v >> (8 * j)) & 255u) / 255.0f;
+        }
+      }
+    } else {
+      for (int i = tid; i < 4 * kD * kD; i += 256) {
+        const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
+        in_pad[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = (float)src[i] / 255.0f;
+      }
+    }
+    __syncthreads();
+    // ---- conv1: 28 M-tiles of 16 positions, 7 per wave ----
+    for (int t = wave; t < 28; t += 4) {
+      int m = t * 16 + col;
+      m = m < kM1 ? m : kM1 - 1;
+      const int oy = m / kO1, ox = m - oy * kO1;
+      const float* a_base = in_pad + (2 * oy) * kP1 + 2 * ox + q;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const float a = a_base[(ks >> 2) * kP1 * kP1 + (ks & 3) * kP1];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw1[ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mo = t * 16 + q * 4 + r;  // D row
+        if (mo < kM1) {
+          const int y = mo / kO1, x = mo - y * kO1;
+          const float v = acc[r] + bias1;
+          c1_pad[col * kP2 * kP2 + (y + 2) * kP2 + (x + 2)] = v > 0.f ? v : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- conv2: 8 M-tiles, 2 per wave, both N-tiles per A gather; D goes straight to HBM ----
+    float* dst = out + (size_t)n * kC2 * kM2;
+    for (int mt = wave; mt < 8; mt += 4) {
+      int m = mt * 16 + col;
+      m = m < kM2 ? m : kM2 - 1;
+      const int oy = m / kO2, ox = m - oy * kO2;
+      const float* a_base = c1_pad + (2 * oy) * kP2 + 2 * ox + q;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 64; ++ks) {
+        const float a = a_base[(ks >> 2) * kP2 * kP2 + (ks & 3) * kP2];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw2[ks][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw2[ks][1], acc1, 0, 0, 0);
+      }
+      // D: column = channel, rows 4q..4q+3 = 4 consecutive positions of the [32][121] row
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mo = mt * 16 + q * 4 + r;
+        if (mo < kM2) {
+          const float v0 = acc0[r] + bias20, v1 = acc1[r] + bias21;
+          dst[col * kM2 + mo] = v0 > 0.f ? v0 : 0.f;
+          dst[(16 + col) * kM2 + mo] = v1 > 0.f ? v1 : 0.f;
+        }
+      }
+    }
+  }
+}
+
+
+// ----------------------------------------------------------------------------------------
+// Backward of the fused conv1 + conv2 for the LEARNER (IMPALA.learn, impala.py:148-215 runs
+// AtariModel.policy / .value under autograd; the gradient of the two convolutions w.r.t. their
+// weights and biases is what this kernel produces — the observations need no gradient).
+//
+// Inputs per observation: the uint8 stack (7,056 B), the forward output a2 = relu(conv2) and the
+// incoming gradient dY w.r.t. a2 (15,488 B each).  Nothing else crosses HBM: conv1 is recomputed
+// into LDS exactly as the forward kernel computes it (same operand order, bit-identical), so the
+// 28 KB / observation conv1 activation is never stored (1.44 GB per 51,200-observation update),
+// and no im2col / col2im matrix exists (the GEMM-lowered convolutions moved ~30 GB per update and
+// spent 19 ms in two split-K-less dW GEMMs with 16x64 / 32x256 outputs).
+//
+// One workgroup (4 waves) per observation, grid-stride; four implicit GEMMs on the f32 matrix
+// cores per observation, gradients accumulated in registers over all observations of the workgroup:
+//   (1) conv1 forward (recompute)                [441 x 64] x [64 x 16]
+//   (2) dW2[o][k] += sum_p dz2[o][p] patch2[p][k]   [32 x 121] x [121 x 256], dz2 = dY * (a2 > 0)
+//   (3) dA1 = transposed conv of dz2 with w2, as a GATHER per output parity class (stride 2,
+//       kernel 4: a conv1 output (y, x) receives from the 2 x 2 conv2 outputs (iy+1-a, ix+1-b)
+//       through taps (py+2a, px+2b)); one class per wave: [<=121 x 128] x [128 x 16];
+//       dz1 = dA1 * (a1 > 0) overwrites a1 in place in LDS
+//   (4) dW1[c][k] += sum_p dz1[c][p] patch1[p][k]   [16 x 441] x [441 x 64]
+// Bias gradients are the row sums of dz2 / dz1, accumulated per lane on the way.  Every workgroup
+// writes its partial sums; conv12_bwd_reduce_kernel adds them in a fixed order (deterministic).
+// ----------------------------------------------------------------------------------------
+constexpr int kZ2W = 13, kZ2H = 12, kZ2 = kZ2H * kZ2W;   // dz2, zero-padded: row 11 / columns 11-12 stay zero
+constexpr int kBwdDW1 = 0, kBwdDB1 = 1024, kBwdDW2 = 1040, kBwdDB2 = 1040 + 8192;
+constexpr int kBwdPartial = 1040 + 8192 + 32;            // 9264 floats per workgroup
+// LDS: the observation stays uint8 (zero-padded [4][44][44] = 7,744 B) next to a 256-entry table of
+// (float)u / 255.0f — the forward kernel's exact operand values — so the workgroup needs 69 KB instead
+// of 92: two workgroups per CU, and the actors' conv12 kernel (71 KB) can share the CU.
+constexpr int kLdsBwdU8 = 4 * kP1 * kP1;                                   // 7,744 bytes = 1,936 floats
+constexpr int kLdsBwdFloats = kLdsBwdU8 / 4 + 256 + kLdsC1 + 32 * kZ2 + 384;  // 17,568 floats = 70,272 B
+
+__global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
+    const uint8_t* __restrict__ obs, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ a2, const float* __restrict__ dy,
+    float* __restrict__ partial, int n_obs) {
+  extern __shared__ float lds[];
+  uint8_t* in_u8 = reinterpret_cast<uint8_t*>(lds);   // [4][44][44] uint8, zero-padded
+  float* lut = lds + kLdsBwdU8 / 4;                   // [256] (float)u / 255.0f
+  float* c1_pad = lut + 256;                          // [16][25][25]: a1, then dz1 in place
+  float* dz2p = c1_pad + kLdsC1;                      // [32][12][13]
+  float* red = dz2p + 32 * kZ2;                       // [384] bias-gradient staging
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, col = lane & 15;
+  float bw1[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) bw1[ks] = w1[col * kK1 + ks * 4 + q];
+  const float bias1 = b1[col];
+  // (3): this wave's parity class and its B operand  B[k = (o, a, b)][n = c] = w2[o][c][py+2a][px+2b]
+  const int py = wave >> 1, px = wave & 1, ta = q >> 1, tb = q & 1;
+  float bt[32];
+#pragma unroll
+  for (int o = 0; o < 32; ++o) bt[o] = w2[o * kK2 + col * 16 + (py + 2 * ta) * 4 + (px + 2 * tb)];
+  f32x4 acc2[2][4], acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc2[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float db2a0 = 0.f, db2a1 = 0.f, db1a = 0.f;
+  for (int i = tid; i < kLdsBwdFloats; i += 256) lds[i] = 0.0f;
+  __syncthreads();
+  lut[tid] = (float)tid / 255.0f;
+  const int kh = col >> 2, kw = col & 3;   // tap of this lane's k column in (2) and (4)
+#pragma unroll 1
+  for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
+    __syncthreads();
+    // ---- obs u8 -> zero-padded u8 tile ----
+    const uint8_t* src = obs + (size_t)n * 4 * kD * kD;
+    if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+      const uint32_t* src32 = reinterpret_cast<const uint32_t*>(src);
+      for (int wi = tid; wi < kD * kD; wi += 256) {
+        const uint32_t v = src32[wi];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = wi * 4 + j;
+          const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
+          in_u8[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = (uint8_t)(v >> (8 * j));
+        }
+      }
+    } else {
+      for (int i = tid; i < 4 * kD * kD; i += 256) {
+        const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
+        in_u8[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = src[i];
+      }
+    }
+    // ---- dz2 = dY * (a2 > 0) -> zero-padded LDS tile ----
+    const float* a2n = a2 + (size_t)n * kC2 * kM2;
+    const float* dyn = dy + (size_t)n * kC2 * kM2;
+    for (int i = tid; i < kC2 * kM2; i += 256) {
+      const int o = i / kM2, p = i - o * kM2, oy = p / kO2, ox = p - oy * kO2;
+      dz2p[o * kZ2 + oy * kZ2W + ox] = a2n[i] > 0.f ? dyn[i] : 0.f;
+    }
+    __syncthreads();
+    // ---- (1) conv1 forward into c1_pad (operand values and order of conv12_u8_mfma_kernel) ----
+#pragma unroll 1
+    for (int t = wave; t < 28; t += 4) {
+      int m = t * 16 + col;
+      m = m < kM1 ? m : kM1 - 1;
+      const int oy = m / kO1, ox = m - oy * kO1;
+      const uint8_t* a_base = in_u8 + (2 * oy) * kP1 + 2 * ox + q;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const float a = lut[a_base[(ks >> 2) * kP1 * kP1 + (ks & 3) * kP1]];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw1[ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mo = t * 16 + q * 4 + r;
+        if (mo < kM1) {
+          const int y = mo / kO1, x = mo - y * kO1;
+          const float v = acc[r] + bias1;
+          c1_pad[col * kP2 * kP2 + (y + 2) * kP2 + (x + 2)] = v > 0.f ? v : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (2) dW2: this wave owns input channels 4*wave .. 4*wave+3 (k tiles), both o tiles ----
+    // position p = 4*ps + q walks the 11 x 11 outputs; offsets advance incrementally (no divides).
+    // The loop stays ROLLED: unrolled (even by 2) the scheduler hoists the LDS gathers of all
+    // iterations, needs > 256 VGPRs + scratch and the kernel runs 8.0 instead of 5.4 ms.
+    {
+      int ox = q, zoff = q;                                   // oy = 0
+      int boff = (4 * wave) * kP2 * kP2 + kh * kP2 + 2 * q + kw;   // c1_pad[(4w)][2*oy + kh][2*ox + kw]
+#pragma clang loop unroll(disable)
+      for (int ps = 0; ps < 31; ++ps) {
+        const bool valid = (ps < 30) | (q == 0);              // p < 121
+        const int zo = valid ? zoff : 11 * kZ2W;              // row 11 of the padded tile is zero
+        const float a0 = dz2p[col * kZ2 + zo], a1v = dz2p[(16 + col) * kZ2 + zo];
+        db2a0 += a0;
+        db2a1 += a1v;
+        const float* bb = c1_pad + (valid ? boff : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float b = bb[j * kP2 * kP2];
+          acc2[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc2[0][j], 0, 0, 0);
+          acc2[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, b, acc2[1][j], 0, 0, 0);
+        }
+        ox += 4;
+        const bool wrap = ox >= kO2;
+        ox -= wrap ? kO2 : 0;
+        zoff += wrap ? 4 + (kZ2W - kO2) : 4;                  // next row of the 13-wide tile
+        boff += wrap ? 8 + (2 * kP2 - 2 * kO2) : 8;           // two rows down, 22 columns back
+      }
+    }
+    __syncthreads();   // all patch2 gathers done before dz1 overwrites a1
+    // ---- (3) dz1 for this wave's parity class, in place over a1 ----
+    {
+      const int ny = kO2 - py, nx = kO2 - px, M = ny * nx;   // y = 2*iy + py < 21, x = 2*ix + px < 21
+#pragma unroll 1
+      for (int t = 0; t * 16 < M; ++t) {
+        int m = t * 16 + col;
+        m = m < M ? m : M - 1;
+        const int iy = m / nx, ix = m - iy * nx;
+        const float* ab = dz2p + (iy + 1 - ta) * kZ2W + (ix + 1 - tb);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 32; ++o) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[o * kZ2], bt[o], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mo = t * 16 + q * 4 + r;
+          if (mo < M) {
+            const int jy = mo / nx, jx = mo - jy * nx;
+            float* pz = c1_pad + col * kP2 * kP2 + (2 * jy + py + 2) * kP2 + (2 * jx + px + 2);
+            const float v = *pz > 0.f ? acc[r] : 0.f;
+            *pz = v;
+            db1a += v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (4) dW1: this wave owns input channel `wave` (16 taps = one k tile) ----
+    {
+      int x = q;                                              // y = 0
+      int aoff = col * kP2 * kP2 + 2 * kP2 + 2 + q;           // c1_pad[col][y + 2][x + 2]
+      int boff = wave * kP1 * kP1 + kh * kP1 + 2 * q + kw;    // in_u8[wave][2*y + kh][2*x + kw]
+#pragma clang loop unroll(disable)
+      for (int ps = 0; ps < 111; ++ps) {
+        const bool valid = (ps < 110) | (q == 0);             // p < 441
+        const float a = c1_pad[valid ? aoff : col * kP2 * kP2];   // [col][0][0] is border: 0
+        const float b = lut[in_u8[valid ? boff : 0]];
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc1, 0, 0, 0);
+        x += 4;
+        const bool wrap = x >= kO1;
+        x -= wrap ? kO1 : 0;
+        aoff += wrap ? 4 + (kP2 - kO1) : 4;
+        boff += wrap ? 8 + (2 * kP1 - 2 * kO1) : 8;
+      }
+    }
+  }
+  // ---- this workgroup's partial sums ----
+  float* P = partial + (size_t)blockIdx.x * kBwdPartial;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) P[kBwdDW1 + (4 * q + r) * kK1 + 16 * wave + col] = acc1[r];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        P[kBwdDW2 + (16 * t + 4 * q + r) * kK2 + 16 * (4 * wave + j) + col] = acc2[t][j][r];
+  // bias gradients: per-lane partial row sums -> LDS -> fixed-order sums (deterministic)
+  __syncthreads();
+  red[tid] = db1a;                         // [wave][q][col]: db1[c = col] = sum over (wave, q)
+  if (wave == 0) {                         // every wave saw the same dz2 rows; take wave 0's sums
+    red[256 + q * 16 + col] = db2a0;       // [q][col]: db2[o = col]      = sum over q
+    red[256 + 64 + q * 16 + col] = db2a1;  //           db2[o = 16 + col]
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += red[i * 16 + tid];
+    P[kBwdDB1 + tid] = s;
+  } else if (tid < 48) {
+    const int o = tid - 16;                // 0..31
+    const float* r = red + 256 + (o >> 4) * 64 + (o & 15);
+    P[kBwdDB2 + o] = r[0] + r[16] + r[32] + r[48];
+  }
+}
+
+// fixed-order sum of the per-workgroup partials -> dW1 [16,64], db1 [16], dW2 [32,256], db2 [32]
+__global__ __launch_bounds__(256) void conv12_bwd_reduce_kernel(const float* __restrict__ partial, int n_parts,
+                                                                float* __restrict__ dw1, float* __restrict__ db1,
+                                                                float* __restrict__ dw2, float* __restrict__ db2) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= kBwdPartial) return;
+  float s = 0.f;
+  for (int g = 0; g < n_parts; ++g) s += partial[(size_t)g * kBwdPartial + j];
+  if (j < kBwdDB1) dw1[j] = s;
+  else if (j < kBwdDW2) db1[j - kBwdDB1] = s;
+  else if (j < kBwdDB2) dw2[j - kBwdDW2] = s;
+  else db2[j - kBwdDB2] = s;
+}
+
+
+// ----------------------------------------------------------------------------------------
+// conv1 of the A2C Atari network (the 84x84 -> 20x20 contraction) on the f32 matrix cores.
+//
+// Reference: examples/A2C/atari_model.py:21-104 (AtariModel): obs / 255, conv1 4->32 k8 s4 p1
+// + ReLU (84x84 -> 20x20).  Per observation an implicit GEMM [400 positions x 256] x [256 x 32]
+// (6.55 MFLOP), k = c*64 + kh*8 + kw (the order of weight.flatten(1)).
+//
+// One workgroup (4 wavefronts, one per SIMD) per observation, grid-stride over observations:
+//   * the u8 stack is read once with 4-byte loads (28,224 B), divided by 255 and laid out in LDS
+//     shifted by the padding: tile[c][py][px] = obs[c][py-1][px-1] / 255, row 0 / column 0 = 0.
+//     (pad 1 with floor((84+2-8)/4)+1 = 20 outputs: padded rows/columns 84 and 85 are never read,
+//     so the tile is 4 x 84 x 84 floats = 112,896 B);
+//   * the whole B operand (the 32 KB weight matrix) lives in registers: 64 k-steps x 2 N-tiles =
+//     128 VGPRs per lane, loaded once per workgroup (a single wave per SIMD has 512 VGPRs);
+//   * each wave owns M-tiles (16 output positions) and issues 2 MFMAs per A gather (both N-tiles);
+//   * D (col = channel, rows = 4 consecutive positions) + bias + ReLU goes straight to HBM as one
+//     16-byte store per lane in NCHW order — no staging, no im2col matrix in HBM (the GEMM-lowered
+//     conv writes and re-reads 410 KB of patches per observation).
+// Algorithmic bytes per observation: 28,224 read + 51,200 written.
+// ----------------------------------------------------------------------------------------
+constexpr int kD84 = 84;                 // input size = padded-tile size (see above)
+constexpr int kO84 = 20, kC84 = 32;      // conv1 output size / channels
+constexpr int kM84 = kO84 * kO84;        // 400 positions = 25 M-tiles of 16
+constexpr int kK84 = 4 * 8 * 8;          // 256
+constexpr int kPlane84 = kD84 * kD84;    // 7056
+constexpr int kLds84Floats = 4 * kPlane84;
+
+__global__ __launch_bounds__(256) void conv1_84_u8_mfma_kernel(
+    const uint8_t* __restrict__ obs, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, int n_obs) {
+  extern __shared__ float lds[];  // [4][84][84], shifted by the padding
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, col = lane & 15;
+  // B[k][n] = w[n][k]: lane (q, col) holds k = 4*ks + q, n = 16*nt + col
+  float breg[64][2];
+#pragma unroll
+  for (int ks = 0; ks < 64; ++ks) {
+    breg[ks][0] = w[col * kK84 + ks * 4 + q];
+    breg[ks][1] = w[(16 + col) * kK84 + ks * 4 + q];
+  }
+  const float bias0 = bias[col], bias1 = bias[16 + col];
+  // the padding: row 0 and column 0 of every channel plane (never overwritten below)
+  for (int i = tid; i < 4 * kD84; i += 256) {
+    const int c = i / kD84, p = i - c * kD84;
+    lds[c * kPlane84 + p] = 0.0f;
+    lds[c * kPlane84 + p * kD84] = 0.0f;
+  }
+  for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
+    __syncthreads();  // the previous observation's gathers are done before the tile is rewritten
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(obs + (size_t)n * 4 * kPlane84);
+    for (int wi = tid; wi < kPlane84; wi += 256) {  // 4 * 7056 bytes = 7056 words; 84 % 4 == 0
+      const uint32_t v = src[wi];
+      const int i = wi * 4;
+      const int c = i / kPlane84, r = i - c * kPlane84, y = r / kD84, x = r - y * kD84;
+      if (y < kD84 - 1) {  // input row 83 lies outside every window
+        float* d = lds + c * kPlane84 + (y + 1) * kD84 + (x + 1);
+        d[0] = (float)(v & 255u) / 255.0f;
+        d[1] = (float)((v >> 8) & 255u) / 255.0f;
+        d[2] = (float)((v >> 16) & 255u) / 255.0f;
+        if (x + 4 < kD84) d[3] = (float)(v >> 24) / 255.0f;  // input column 83 likewise
+      }
+    }
+    __syncthreads();
+    float* dst = out + (size_t)n * kC84 * kM84;
+    for (int mt = wave; mt < kM84 / 16; mt += 4) {
+      const int m = mt * 16 + col;
+      const int oy = m / kO84, ox = m - oy * kO84;
+      const float* a_base = lds + (4 * oy) * kD84 + 4 * ox + q;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 64; ++ks) {
+        // k = 4*ks + q = c*64 + kh*8 + kw  ->  c = ks>>4, kh = (ks>>1)&7, kw = (ks&1)*4 + q
+        const float a = a_base[(ks >> 4) * kPlane84 + ((ks >> 1) & 7) * kD84 + (ks & 1) * 4];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[ks][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[ks][1], acc1, 0, 0, 0);
+      }
+      // D: column = channel (col), rows 4q..4q+3 = 4 consecutive positions -> one 16 B store
+      f32x4 o0, o1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+        o0[r] = v0 > 0.f ? v0 : 0.f;
+        o1[r] = v1 > 0.f ? v1 : 0.f;
+      }
+      const int mo = mt * 16 + q * 4;
+      *reinterpret_cast<f32x4*>(dst + col * kM84 + mo) = o0;
+      *reinterpret_cast<f32x4*>(dst + (16 + col) * kM84 + mo) = o1;
+    }
+  }
+}
+
+
+// ----------------------------------------------------------------------------------------
+// conv2 + conv3 of the A2C Atari network, fused (examples/A2C/atari_model.py:21-104):
+//   a1 [32,20,20] (the output of conv1_84_u8_mfma_kernel) -> conv2 32->64 k4 s2 p2 + ReLU
+//   -> a2 [64,11,11] (stays in LDS) -> conv3 64->64 k3 s1 + ReLU -> a3 [64,9,9] = the 5184-wide
+//   input of the fc layer.  13.9 MFLOP per observation.
+// One workgroup per observation (grid-stride); a1 zero-padded in LDS ([32][24][24] f32, 73.7 KB),
+// a2 in LDS ([64][121], 31 KB).  The weight matrices (128 KB + 147 KB) fit neither registers nor
+// the remaining LDS: they are STREAMED from L2 in MFMA operand order — `wt2[ks][nt][lane]`,
+// `wt3[ks][nt][lane]` (prepared by the host wrapper: one 256-byte coalesced load per wave and
+// k-step) — each wave owning one 16-channel N tile and all M tiles, so every streamed B value
+// feeds 8 (conv2) / 6 (conv3) MFMAs.  k order: conv2 k = c*16 + kh*4 + kw (natural, kw = lane
+// quarter); conv3 k' = (kh*3 + kw)*64 + c (tap-major, so the tap is uniform per k-step).
+// a2 is also written to HBM when the learner needs it for the backward pass.
+// ----------------------------------------------------------------------------------------
+constexpr int kA1 = 20, kA1P = 24, kA1Plane = kA1P * kA1P;      // conv1 output, padded by 2
+constexpr int kA2 = 11, kM2b = kA2 * kA2;                        // 121 conv2 outputs
+constexpr int kA3 = 9, kM3 = kA3 * kA3;                          // 81 conv3 outputs
+constexpr int kLds23Floats = 32 * kA1Plane + 64 * kM2b;          // 18,432 + 7,744 = 26,176 floats = 104,704 B
+
+__global__ __launch_bounds__(256) void conv23_84_mfma_kernel(
+    const float* __restrict__ a1, const float* __restrict__ wt2, const float* __restrict__ b2,
+    const float* __restrict__ wt3, const float* __restrict__ b3, float* __restrict__ a2_out,
+    float* __restrict__ a3_out, int n_obs) {
+  extern __shared__ float lds[];
+  float* a1p = lds;                       // [32][24][24]
+  float* a2s = lds + 32 * kA1Plane;       // [64][121]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, col = lane & 15;
+  const float bias2 = b2[16 * wave + col], bias3 = b3[16 * wave + col];
+  for (int i = tid; i < 32 * kA1Plane; i += 256) a1p[i] = 0.0f;   // borders stay zero
+  // conv2 gather offsets of this lane's 8 M tiles: position m -> (2*oy)*24 + 2*ox + kw (kw = q)
+  int off2[8];
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    int m = mt * 16 + col;
+    m = m < kM2b ? m : kM2b - 1;
+    const int oy = m / kA2, ox = m - oy * kA2;
+    off2[mt] = (2 * oy) * kA1P + 2 * ox + q;
+  }
+  int off3[6];
+#pragma unroll
+  for (int mt = 0; mt < 6; ++mt) {
+    int m = mt * 16 + col;
+    m = m < kM3 ? m : kM3 - 1;
+    const int oy = m / kA3, ox = m - oy * kA3;
+    off3[mt] = oy * kA2 + ox + q * kM2b;   // + channel (c = 4*(ks&15) + q) and tap offsets per k-step
+  }
+#pragma unroll 1
+  for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
+    __syncthreads();
+    // ---- a1 -> padded LDS tile ----
+    const float4* src = reinterpret_cast<const float4*>(a1 + (size_t)n * 32 * kA1 * kA1);
+    for (int i = tid; i < 32 * kA1 * kA1 / 4; i += 256) {
+      const float4 v = src[i];
+      const int e = i * 4, c = e / (kA1 * kA1), r = e - c * kA1 * kA1, y = r / kA1, x = r - y * kA1;   // 20 % 4 == 0
+      float* d = a1p + c * kA1Plane + (y + 2) * kA1P + (x + 2);
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    // ---- conv2: wave = N tile (channels 16*wave ..), 8 M tiles, 128 k-steps ----
+    {
+      f32x4 acc[8];
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* wp = wt2 + wave * 64 + lane;            // wt2[ks][nt = wave][lane]
+#pragma clang loop unroll_count(2)
+      for (int ks = 0; ks < 128; ++ks) {
+        const float b = wp[ks * 256];
+        const float* ab = a1p + (ks >> 2) * kA1Plane + (ks & 3) * kA1P;   // c = ks >> 2, kh = ks & 3
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[off2[mt]], b, acc[mt], 0, 0, 0);
+      }
+      float* g2 = a2_out ? a2_out + (size_t)n * 64 * kM2b : nullptr;
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mo = mt * 16 + q * 4 + r;
+          if (mo < kM2b) {
+            float v = acc[mt][r] + bias2;
+            v = v > 0.f ? v : 0.f;
+            a2s[(16 * wave + col) * kM2b + mo] = v;
+            if (g2) g2[(16 * wave + col) * kM2b + mo] = v;
+          }
+        }
+    }
+    __syncthreads();
+    // ---- conv3: wave = N tile, 6 M tiles, 144 k-steps in tap-major order ----
+    {
+      f32x4 acc[6];
+#pragma unroll
+      for (int mt = 0; mt < 6; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* wp = wt3 + wave * 64 + lane;
+#pragma clang loop unroll_count(2)
+      for (int ks = 0; ks < 144; ++ks) {
+        const float b = wp[ks * 256];
+        const int tap = ks >> 4, kh = tap / 3, kw = tap - kh * 3;   // k' = tap*64 + c, c = 4*(ks & 15) + q
+        const float* ab = a2s + (4 * (ks & 15)) * kM2b + kh * kA2 + kw;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[off3[mt]], b, acc[mt], 0, 0, 0);
+      }
+      float* g3 = a3_out + (size_t)n * 64 * kM3;
+#pragma unroll
+      for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mo = mt * 16 + q * 4 + r;
+          if (mo < kM3) {
+            const float v = acc[mt][r] + bias3;
+            g3[(16 * wave + col) * kM3 + mo] = v > 0.f ? v : 0.f;
+          }
+        }
+    }
+  }
+}
+
+
+// ----------------------------------------------------------------------------------------
+// Backward of the 84x84 model's convolutions for the learner (A2C.learn / IMPALA.learn on
+// examples/A2C/atari_model.py:21-104), layer by layer, one workgroup per observation, the
+// activations a1 / a2 / a3 saved by the forward kernels (51 + 31 + 21 KB per observation: HBM traffic
+// of the whole backward pass ~0.3 MB per observation against 41 MFLOP of MFMA work).  Weight
+// gradients accumulate in registers across the observations of a workgroup and leave as
+// per-workgroup partials summed in a fixed order (partial_sum_kernel): deterministic.
+//
+// conv3_84_bwd_kernel: dz3 = dy3 * (a3 > 0);
+//   (A) dW3[o][k'] += sum_p dz3[o][p] a2[c][oy+kh][ox+kw]       [64 x 81] x [81 x 576], k' = tap*64 + c
+//       wave w owns the k' tiles {w, w+4, ..} (9 tiles x 4 o tiles = 36 accumulators)
+//   (B) dA2[c][y][x] = sum_{o,kh,kw} dz3[o][y-kh][x-kw] w3[o][c][kh][kw]   (gather from dz3 padded
+//       by 2) = [121 x 576] x [576 x 64] with the B operand streamed (wt3b[ks][nt][lane],
+//       k'' = tap*64 + o); dz2 = dA2 * (a2 > 0) -> HBM
+// ----------------------------------------------------------------------------------------
+constexpr int kZ3P = 13, kZ3Plane = kZ3P * kZ3P;                      // dz3 padded by 2: 13 x 13
+constexpr int kLds3bFloats = 64 * kM2b + 64 * kZ3Plane + 128;          // 7,744 + 10,816 + 128 = 18,688 floats = 74,752 B
+constexpr int kPart3 = 64 * 576 + 64;                                  // dW3 [o][k'] + db3
+
+__global__ __launch_bounds__(256) void conv3_84_bwd_kernel(
+    const float* __restrict__ a2, const float* __restrict__ a3, const float* __restrict__ dy3,
+    const float* __restrict__ wt3b, float* __restrict__ dz2, float* __restrict__ partial, int n_obs) {
+  extern __shared__ float lds[];
+  float* a2s = lds;                         // [64][121]
+  float* z3p = lds + 64 * kM2b;             // [64][13][13], zero border
+  float* red = z3p + 64 * kZ3Plane;         // [128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, col = lane & 15;
+  f32x4 accw[4][9];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) accw[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dba[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 64 * kZ3Plane; i += 256) z3p[i] = 0.0f;
+  // (A) B-operand offsets of this lane's 9 k' tiles: tile nt = wave + 4 j -> tap = nt >> 2, c = 16 (nt & 3) + col
+  int boff[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int nt = wave + 4 * j, tap = nt >> 2, kh = tap / 3, kw = tap - kh * 3;
+    boff[j] = (16 * (nt & 3) + col) * kM2b + kh * kA2 + kw;
+  }
+  // (B) A-operand offsets of the 8 M tiles (positions of the 11 x 11 input): z3p[o][y + 2][x + 2]
+  int aoff[8];
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    int m = mt * 16 + col;
+    m = m < kM2b ? m : kM2b - 1;
+    const int y = m / kA2, x = m - y * kA2;
+    aoff[mt] = (y + 2) * kZ3P + (x + 2) + q * kZ3Plane;    // + o = 4 (ks & 15) + q, - kh * 13 - kw per k-step
+  }
+#pragma unroll 1
+  for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
+    __syncthreads();
+    const float4* s2 = reinterpret_cast<const float4*>(a2 + (size_t)n * 64 * kM2b);   // 7,744 floats: 16-byte multiple
+    for (int i = tid; i < 64 * kM2b / 4; i += 256) reinterpret_cast<float4*>(a2s)[i] = s2[i];
+    const float* a3n = a3 + (size_t)n * 64 * kM3;
+    const float* dyn = dy3 + (size_t)n * 64 * kM3;
+    for (int i = tid; i < 64 * kM3; i += 256) {
+      const int o = i / kM3, p = i - o * kM3, y = p / kA3, x = p - y * kA3;
+      z3p[o * kZ3Plane + (y + 2) * kZ3P + (x + 2)] = a3n[i] > 0.f ? dyn[i] : 0.f;
+    }
+    __syncthreads();
+    // ---- (A) dW3 ----
+    {
+      int oy = 0, ox = q;                                  // p = 4 ks + q
+#pragma clang loop unroll(disable)
+      for (int ks = 0; ks < 21; ++ks) {
+        const bool valid = (ks < 20) | (q == 0);           // p < 81
+        const int zo = valid ? (oy + 2) * kZ3P + (ox + 2) : 0;   // z3p[o][0][0] is border: 0
+        const int po = valid ? oy * kA2 + ox : 0;
+        float av[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          av[mt] = z3p[(16 * mt + col) * kZ3Plane + zo];
+          dba[mt] += av[mt];
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+          const float b = a2s[boff[j] + po];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) accw[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], b, accw[mt][j], 0, 0, 0);
+        }
+        ox += 4;
+        const bool wrap = ox >= kA3;
+        ox -= wrap ? kA3 : 0;
+        oy += wrap ? 1 : 0;
+      }
+    }
+    // ---- (B) dz2 = (transposed conv3 of dz3) * (a2 > 0) ----
+    {
+      f32x4 acc[8];
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* wp = wt3b + wave * 64 + lane;
+#pragma clang loop unroll_count(2)
+      for (int ks = 0; ks < 144; ++ks) {
+        const float b = wp[ks * 256];
+        const int tap = ks >> 4, kh = tap / 3, kw = tap - kh * 3;
+        const float* ab = z3p + (4 * (ks & 15)) * kZ3Plane - kh * kZ3P - kw;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[aoff[mt]], b, acc[mt], 0, 0, 0);
+      }
+      float* g = dz2 + (size_t)n * 64 * kM2b;
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mo = mt * 16 + q * 4 + r;
+          if (mo < kM2b) {
+            const int idx = (16 * wave + col) * kM2b + mo;
+            g[idx] = a2s[idx] > 0.f ? acc[mt][r] : 0.f;
+          }
+        }
+    }
+  }
+  // ---- partials: dW3[o][k'] (o = 16 mt + 4 q + r, k' = 16 (wave + 4 j) + col), db3 ----
+  float* P = partial + (size_t)blockIdx.x * kPart3;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[(16 * mt + 4 * q + r) * 576 + 16 * (wave + 4 * j) + col] = accw[mt][j][r];
+  __syncthreads();
+  if (wave == 0) {   // every wave accumulated the same dz3 row sums
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) red[(mt * 4 + q) * 16 + col] = dba[mt];   // [mt][q][col]
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int mt = tid >> 4, c = tid & 15;
+    P[64 * 576 + tid] = red[(mt * 4 + 0) * 16 + c] + red[(mt * 4 + 1) * 16 + c] + red[(mt * 4 + 2) * 16 + c] +
+                        red[(mt * 4 + 3) * 16 + c];
+  }
+}
+
+// conv2_84_bwd_kernel: given a1 [32,20,20] and dz2 [64,11,11] (already masked by a2 > 0):
+//   (A) dW2[o][k] += sum_p dz2[o][p] a1pad[c][2 oy + kh][2 ox + kw]    [64 x 121] x [121 x 512], k = c*16 + kh*4 + kw
+//       wave w owns the input channels {w, w+4, ..} (8 k tiles x 4 o tiles = 32 accumulators)
+//   (B) dA1 = the transposed convolution as a gather per output parity class (stride 2, kernel 4, as
+//       in conv12_bwd_u8_mfma_kernel): y = 2 iy + py receives from dz2[o][iy+1-a][ix+1-b] through
+//       taps (py+2a, px+2b); one class per wave: [100 x 256] x [256 x 32], B operand (class slice of
+//       w2, 32 KB) streamed: wt2b[class][ks][nt][lane], k = (o, a, b) = 4 ks + q; dz1 = dA1 * (a1 > 0) -> HBM
+constexpr int kLds2bFloats = 32 * kA1Plane + 64 * kM2b + 128;            // 18,432 + 7,744 + 128 = 26,304 floats = 105,216 B
+constexpr int kPart2 = 64 * 512 + 64;
+
+__global__ __launch_bounds__(256) void conv2_84_bwd_kernel(
+    const float* __restrict__ a1, const float* __restrict__ dz2, const float* __restrict__ wt2b,
+    float* __restrict__ dz1, float* __restrict__ partial, int n_obs) {
+  extern __shared__ float lds[];
+  float* a1p = lds;                       // [32][24][24], zero border
+  float* z2s = lds + 32 * kA1Plane;       // [64][11][11]
+  float* red = z2s + 64 * kM2b;           // [128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, col = lane & 15;
+  f32x4 accw[4][8];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) accw[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dba[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 32 * kA1Plane; i += 256) a1p[i] = 0.0f;
+  const int kh = col >> 2, kw = col & 3;
+  // (B) this wave's parity class; A-operand offsets of its 7 M tiles (100 positions iy, ix < 10)
+  const int py = wave >> 1, px = wave & 1, ta = q >> 1, tb = q & 1;
+  int aoff[7];
+#pragma unroll
+  for (int mt = 0; mt < 7; ++mt) {
+    int m = mt * 16 + col;
+    m = m < 100 ? m : 99;
+    const int iy = m / 10, ix = m - iy * 10;
+    aoff[mt] = (iy + 1 - ta) * kA2 + (ix + 1 - tb);        // z2s[o][iy+1-a][ix+1-b], + o * 121 per k-step
+  }
+#pragma unroll 1
+  for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
+    __syncthreads();
+    const float4* src = reinterpret_cast<const float4*>(a1 + (size_t)n * 32 * kA1 * kA1);
+    for (int i = tid; i < 32 * kA1 * kA1 / 4; i += 256) {
+      const float4 v = src[i];
+      const int e = i * 4, c = e / (kA1 * kA1), r = e - c * kA1 * kA1, y = r / kA1, x = r - y * kA1;
+      float* d = a1p + c * kA1Plane + (y + 2) * kA1P + (x + 2);
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    const float4* sz = reinterpret_cast<const float4*>(dz2 + (size_t)n * 64 * kM2b);
+    for (int i = tid; i < 64 * kM2b / 4; i += 256) reinterpret_cast<float4*>(z2s)[i] = sz[i];
+    __syncthreads();
+    // ---- (A) dW2 ----
+    {
+      int ox = q, zoff = q, boff = kh * kA1P + 2 * q + kw;   // p = 4 ks + q: (oy, ox) = (0, q)
+#pragma clang loop unroll(disable)
+      for (int ks = 0; ks < 31; ++ks) {
+        const bool valid = (ks < 30) | (q == 0);             // p < 121
+        float av[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const float v = z2s[(16 * mt + col) * kM2b + (valid ? zoff : 0)];
+          av[mt] = valid ? v : 0.f;
+          dba[mt] += av[mt];
+        }
+        const float* bb = a1p + wave * kA1Plane + (valid ? boff : 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float b = bb[(4 * j) * kA1Plane];            // input channel c = wave + 4 j
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) accw[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], b, accw[mt][j], 0, 0, 0);
+        }
+        ox += 4;
+        const bool wrap = ox >= kA2;
+        ox -= wrap ? kA2 : 0;
+        zoff += 4;                                           // z2s rows are contiguous: p itself
+        boff += wrap ? 8 + (2 * kA1P - 2 * kA2) : 8;         // two rows down, 22 columns back
+      }
+    }
+    // ---- (B) dz1 for this wave's parity class ----
+    {
+      f32x4 acc[7][2];
+#pragma unroll
+      for (int mt = 0; mt < 7; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      const float* wp = wt2b + (size_t)wave * 64 * 2 * 64 + lane;   // wt2b[class][ks][nt][lane]
+#pragma clang loop unroll_count(2)
+      for (int o = 0; o < 64; ++o) {
+        const float b0 = wp[(o * 2 + 0) * 64], b1v = wp[(o * 2 + 1) * 64];
+        const float* ab = z2s + o * kM2b;
+#pragma unroll
+        for (int mt = 0; mt < 7; ++mt) {
+          const float a = ab[aoff[mt]];
+          acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[mt][0], 0, 0, 0);
+          acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1v, acc[mt][1], 0, 0, 0);
+        }
+      }
+      float* g = dz1 + (size_t)n * 32 * kA1 * kA1;
+#pragma unroll
+      for (int mt = 0; mt < 7; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mo = mt * 16 + q * 4 + r;
+          if (mo < 100) {
+            const int jy = mo / 10, jx = mo - jy * 10, y = 2 * jy + py, x = 2 * jx + px;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const int c = 16 * nt + col;
+              g[c * kA1 * kA1 + y * kA1 + x] = a1p[c * kA1Plane + (y + 2) * kA1P + (x + 2)] > 0.f ? acc[mt][nt][r] : 0.f;
+            }
+          }
+        }
+    }
+  }
+  // ---- partials: dW2[o][k] (o = 16 mt + 4 q + r, k = 16 (wave + 4 j) + col), db2 ----
+  float* P = partial + (size_t)blockIdx.x * kPart2;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[(16 * mt + 4 * q + r) * 512 + 16 * (wave + 4 * j) + col] = accw[mt][j][r];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) red[(mt * 4 + q) * 16 + col] = dba[mt];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int mt = tid >> 4, c = tid & 15;
+    P[64 * 512 + tid] = red[(mt * 4 + 0) * 16 + c] + red[(mt * 4 + 1) * 16 + c] + red[(mt * 4 + 2) * 16 + c] +
+                        red[(mt * 4 + 3) * 16 + c];
+  }
+}
+
+// conv1_84_bwd_kernel: dW1[c][k] += sum_p dz1[c][p] x[ci][4 oy + kh - 1][4 ox + kw - 1] / 255
+//   [32 x 400] x [400 x 256], k = ci*64 + kh*8 + kw; the observation stays uint8 in LDS (the shifted
+//   tile of conv1_84_u8_mfma_kernel) next to the (float)u / 255.0f table; wave w owns the k tiles
+//   {w, w+4, w+8, w+12} x 2 c tiles.
+constexpr int kLds1bFloats = (4 * kPlane84) / 4 + 256 + 32 * kM84 + 64;   // 7,056 + 256 + 12,800 + 64 floats = 80,704 B
+constexpr int kPart1 = 32 * 256 + 32;
+
+__global__ __launch_bounds__(256) void conv1_84_bwd_kernel(
+    const uint8_t* __restrict__ obs, const float* __restrict__ dz1, float* __restrict__ partial, int n_obs) {
+  extern __shared__ float lds[];
+  uint8_t* tile = reinterpret_cast<uint8_t*>(lds);        // [4][84][84] uint8, shifted by the padding
+  float* lut = lds + kPlane84;                            // [256]
+  float* z1s = lut + 256;                                 // [32][400]
+  float* red = z1s + 32 * kM84;                           // [64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, col = lane & 15;
+  f32x4 accw[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accw[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dba[2] = {0.f, 0.f};
+  for (int i = tid; i < kPlane84; i += 256) lds[i] = 0.0f;   // the tile incl. its zero row 0 / column 0
+  __syncthreads();
+  lut[tid] = (float)tid / 255.0f;
+  // B-operand offsets of this lane's 4 k tiles: nt = wave + 4 j -> ci = nt >> 2, kh = 2 (nt & 3) + (col >> 3), kw = col & 7
+  int boff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int nt = wave + 4 * j;
+    boff[j] = (nt >> 2) * kPlane84 + (2 * (nt & 3) + (col >> 3)) * kD84 + (col & 7);
+  }
+#pragma unroll 1
+  for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
+    __syncthreads();
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(obs + (size_t)n * 4 * kPlane84);
+    for (int wi = tid; wi < kPlane84; wi += 256) {
+      const uint32_t v = src[wi];
+      const int i = wi * 4;
+      const int c = i / kPlane84, r = i - c * kPlane84, y = r / kD84, x = r - y * kD84;
+      if (y < kD84 - 1) {
+        uint8_t* d = tile + c * kPlane84 + (y + 1) * kD84 + (x + 1);
+        d[0] = (uint8_t)v; d[1] = (uint8_t)(v >> 8); d[2] = (uint8_t)(v >> 16);
+        if (x + 4 < kD84) d[3] = (uint8_t)(v >> 24);
+      }
+    }
+    const float4* sz = reinterpret_cast<const float4*>(dz1 + (size_t)n * 32 * kM84);
+    for (int i = tid; i < 32 * kM84 / 4; i += 256) reinterpret_cast<float4*>(z1s)[i] = sz[i];
+    __syncthreads();
+    int ox = q, poff = q * 4;                               // p = 4 ks + q: (oy, ox) = (0, q); tile offset (4 oy) * 84 + 4 ox
+#pragma clang loop unroll(disable)
+    for (int ks = 0; ks < 100; ++ks) {
+      const float a0 = z1s[col * kM84 + ks * 4 + q], a1v = z1s[(16 + col) * kM84 + ks * 4 + q];
+      dba[0] += a0;
+      dba[1] += a1v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float b = lut[tile[boff[j] + poff]];
+        accw[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, accw[0][j], 0, 0, 0);
+        accw[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, b, accw[1][j], 0, 0, 0);
+      }
+      ox += 4;
+      const bool wrap = ox >= kO84;
+      ox -= wrap ? kO84 : 0;
+      poff += wrap ? 16 + (4 * kD84 - 4 * kO84) : 16;       // four rows down, 80 columns back
+    }
+  }
+  float* P = partial + (size_t)blockIdx.x * kPart1;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[(16 * mt + 4 * q + r) * 256 + 16 * (wave + 4 * j) + col] = accw[mt][j][r];
+  __syncthreads();
+  if (wave == 0) { red[(0 * 4 + q) * 16 + col] = dba[0]; red[(1 * 4 + q) * 16 + col] = dba[1]; }
+  __syncthreads();
+  if (tid < 32) {
+    const int mt = tid >> 4, c = tid & 15;
+    P[32 * 256 + tid] = red[(mt * 4 + 0) * 16 + c] + red[(mt * 4 + 1) * 16 + c] + red[(mt * 4 + 2) * 16 + c] +
+                        red[(mt * 4 + 3) * 16 + c];
+  }
+}
+
+// out[j] = sum over parts of partial[part][j], fixed order (deterministic)
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ partial, int n_parts, int len,
+                                                          float* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= len) return;
+  float s = 0.f;
+  for (int g = 0; g < n_parts; ++g) s += partial[(size_t)g * len + j];
+  out[j] = s;
+}
+
+}  // namespace parlhip
+
+using namespace parlhip;
+
+PARLHIP_EXPORT int parlhip_atari42_conv12_u8_f32(const uint8_t* obs, const float* w1, const float* b1,
+                                                 const float* w2, const float* b2, float* out, int n_obs,
+                                                 parlhip_stream_t stream) {
+  if (n_obs < 0) return PARLHIP_EINVAL;
+  if (n_obs == 0) return PARLHIP_OK;
+  if (!obs || !w1 || !b1 || !w2 || !b2 || !out) return PARLHIP_EINVAL;
+  static bool attr_set = false;
+  const size_t lds_bytes = kLdsFloats * sizeof(float);
+  if (!attr_set) {
+    int rc = check(hipFuncSetAttribute((const void*)conv12_u8_mfma_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int grid = n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU;  // 71 KB of LDS: two workgroups per CU
+  conv12_u8_mfma_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(obs, w1, b1, w2, b2, out, n_obs);
+  return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_atari84_conv1_u8_f32(const uint8_t* obs, const float* w1, const float* b1,
+                                                float* out, int n_obs, parlhip_stream_t stream) {
+  if (n_obs < 0) return PARLHIP_EINVAL;
+  if (n_obs == 0) return PARLHIP_OK;
+  if (!obs || !w1 || !b1 || !out) return PARLHIP_EINVAL;
+  // 4-byte input loads / 16-byte output stores (torch allocations are 256 B aligned; a view
+  // starting at an observation boundary keeps both: 28,224 and 51,200 are multiples of 16)
+  if (((uintptr_t)obs & 3u) || ((uintptr_t)out & 15u)) return PARLHIP_EINVAL;
+  static bool attr_set = false;
+  const size_t lds_bytes = kLds84Floats * sizeof(float);
+  if (!attr_set) {
+    int rc = check(hipFuncSetAttribute((const void*)conv1_84_u8_mfma_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int grid = n_obs < kNumCU ? n_obs : kNumCU;  // 113 KB of LDS: one workgroup per CU
+  conv1_84_u8_mfma_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(obs, w1, b1, out, n_obs);
+  return check_launch();
+}
+
+static int conv12_bwd_grid(int n_obs) { return n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU; }  // 69 KB of LDS: two per CU
+
+PARLHIP_EXPORT size_t parlhip_atari42_conv12_bwd_workspace_bytes(int n_obs) {
+  return n_obs <= 0 ? 0 : (size_t)conv12_bwd_grid(n_obs) * kBwdPartial * sizeof(float);
+}
+
+PARLHIP_EXPORT int parlhip_atari42_conv12_bwd_f32(const uint8_t* obs, const float* w1, const float* b1,
+                                                  const float* w2, const float* a2, const float* dy, int n_obs,
+                                                  float* workspace, float* dw1, float* db1, float* dw2, float* db2,
+                                                  parlhip_stream_t stream) {
+  if (n_obs < 0) return PARLHIP_EINVAL;
+  if (!dw1 || !db1 || !dw2 || !db2) return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (n_obs == 0) {
+    int rc = check(hipMemsetAsync(dw1, 0, 1024 * 4, s));
+    if (!rc) rc = check(hipMemsetAsync(db1, 0, 16 * 4, s));
+    if (!rc) rc = check(hipMemsetAsync(dw2, 0, 8192 * 4, s));
+    if (!rc) rc = check(hipMemsetAsync(db2, 0, 32 * 4, s));
+    return rc;
+  }
+  if (!obs || !w1 || !b1 || !w2 || !a2 || !dy || !workspace) return PARLHIP_EINVAL;
+  static bool attr_set = false;
+  const size_t lds_bytes = kLdsBwdFloats * sizeof(float);
+  if (!attr_set) {
+    int rc = check(hipFuncSetAttribute((const void*)conv12_bwd_u8_mfma_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int grid = conv12_bwd_grid(n_obs);
+  conv12_bwd_u8_mfma_kernel<<<grid, 256, lds_bytes, s>>>(obs, w1, b1, w2, a2, dy, workspace, n_obs);
+  int rc = check_launch();
+  if (rc) return rc;
+  conv12_bwd_reduce_kernel<<<(kBwdPartial + 255) / 256, 256, 0, s>>>(workspace, grid, dw1, db1, dw2, db2);
+  return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_atari84_conv23_f32(const float* a1, const float* wt2, const float* b2, const float* wt3,
+                                              const float* b3, float* a2_out, float* a3_out, int n_obs,
+                                              parlhip_stream_t stream) {
+  if (n_obs < 0) return PARLHIP_EINVAL;
+  if (n_obs == 0) return PARLHIP_OK;
+  if (!a1 || !wt2 || !b2 || !wt3 || !b3 || !a3_out) return PARLHIP_EINVAL;
+  if ((uintptr_t)a1 & 15u) return PARLHIP_EINVAL;   // 16-byte loads of the conv1 activation
+  static bool attr_set = false;
+  const size_t lds_bytes = kLds23Floats * sizeof(float);
+  if (!attr_set) {
+    int rc = check(hipFuncSetAttribute((const void*)conv23_84_mfma_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int grid = n_obs < kNumCU ? n_obs : kNumCU;   // 105 KB of LDS: one workgroup per CU
+  conv23_84_mfma_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(a1, wt2, b2, wt3, b3, a2_out, a3_out, n_obs);
+  return check_launch();
+}
+
+static int bwd84_grid(int n_obs) { return n_obs < kNumCU ? n_obs : kNumCU; }
+
+PARLHIP_EXPORT size_t parlhip_atari84_conv3_bwd_workspace_bytes(int n_obs) {
+  return n_obs <= 0 ? 0 : (size_t)bwd84_grid(n_obs) * kPart3 * sizeof(float);
+}
+
+PARLHIP_EXPORT int parlhip_atari84_conv3_bwd_f32(const float* a2, const float* a3, const float* dy3, const float* wt3b,
+                                                 int n_obs, float* workspace, float* dz2, float* dw3_db3,
+                                                 parlhip_stream_t stream) {
+  if (n_obs <= 0) return n_obs < 0 ? PARLHIP_EINVAL : PARLHIP_OK;
+  if (!a2 || !a3 || !dy3 || !wt3b || !workspace || !dz2 || !dw3_db3) return PARLHIP_EINVAL;
+  if ((uintptr_t)a2 & 15u) return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  const size_t lds_bytes = kLds3bFloats * sizeof(float);
+  if (!attr_set) {
+    int rc = check(hipFuncSetAttribute((const void*)conv3_84_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes));
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int grid = bwd84_grid(n_obs);
+  conv3_84_bwd_kernel<<<grid, 256, lds_bytes, s>>>(a2, a3, dy3, wt3b, dz2, workspace, n_obs);
+  int rc = check_launch();
+  if (rc) return rc;
+  partial_sum_kernel<<<(kPart3 + 255) / 256, 256, 0, s>>>(workspace, grid, kPart3, dw3_db3);
+  return check_launch();
+}
+
+PARLHIP_EXPORT size_t parlhip_atari84_conv2_bwd_workspace_bytes(int n_obs) {
+  return n_obs <= 0 ? 0 : (size_t)bwd84_grid(n_obs) * kPart2 * sizeof(float);
+}
+
+PARLHIP_EXPORT int parlhip_atari84_conv2_bwd_f32(const float* a1, const float* dz2, const float* wt2b, int n_obs,
+                                                 float* workspace, float* dz1, float* dw2_db2, parlhip_stream_t stream) {
+  if (n_obs <= 0) return n_obs < 0 ? PARLHIP_EINVAL : PARLHIP_OK;
+  if (!a1 || !dz2 || !wt2b || !workspace || !dz1 || !dw2_db2) return PARLHIP_EINVAL;
+  if (((uintptr_t)a1 | (uintptr_t)dz2) & 15u) return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  const size_t lds_bytes = kLds2bFloats * sizeof(float);
+  if (!attr_set) {
+    int rc = check(hipFuncSetAttribute((const void*)conv2_84_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes));
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int grid = bwd84_grid(n_obs);
+  conv2_84_bwd_kernel<<<grid, 256, lds_bytes, s>>>(a1, dz2, wt2b, dz1, workspace, n_obs);
+  int rc = check_launch();
+  if (rc) return rc;
+  partial_sum_kernel<<<(kPart2 + 255) / 256, 256, 0, s>>>(workspace, grid, kPart2, dw2_db2);
+  return check_launch();
+}
+
+PARLHIP_EXPORT size_t parlhip_atari84_conv1_bwd_workspace_bytes(int n_obs) {
+  return n_obs <= 0 ? 0 : (size_t)bwd84_grid(n_obs) * kPart1 * sizeof(float);
+}
+
+PARLHIP_EXPORT int parlhip_atari84_conv1_bwd_f32(const uint8_t* obs, const float* dz1, int n_obs, float* workspace,
+                                                 float* dw1_db1, parlhip_stream_t stream) {
+  if (n_obs <= 0) return n_obs < 0 ? PARLHIP_EINVAL : PARLHIP_OK;
+  if (!obs || !dz1 || !workspace || !dw1_db1) return PARLHIP_EINVAL;
+  if (((uintptr_t)obs & 3u) || ((uintptr_t)dz1 & 15u)) return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  const size_t lds_bytes = kLds1bFloats * sizeof(float);
+  if (!attr_set) {
+    int rc = check(hipFuncSetAttribute((const void*)conv1_84_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes));
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int grid = bwd84_grid(n_obs);
+  conv1_84_bwd_kernel<<<grid, 256, lds_bytes, s>>>(obs, dz1, workspace, n_obs);
+  int rc = check_launch();
+  if (rc) return rc;
+  partial_sum_kernel<<<(kPart1 + 255) / 256, 256, 0, s>>>(workspace, grid, kPart1, dw1_db1);
+  return check_launch();
+}

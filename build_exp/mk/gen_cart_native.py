@@ -450,12 +450,12 @@ class Cart(object):
                     return ['if (e.tia_store_is_nop(0x%02x, %s)) e.cyc += %d;' % (reg, val, dc),
                             'else { e.cyc += %d; if (!e.pf_enqueue(0x%02x, %s)) { --n; e.pend = 0x%02x | ((%s) << 8); '
                             'e.PC = 0x%04x; return; } }' % (dc - 1, reg, val, static, val, nxt)]
-                return ['if (__builtin_expect(!e.tia_store_quiet(0x%02x, %s), 0)) %s' % (reg, val, pend % ('0x%02x' % static)),
+                return ['if (__builtin_expect(!e.tia_store_is_nop(0x%02x, %s), 0)) %s' % (reg, val, pend % ('0x%02x' % static)),
                         'e.cyc += %d;' % dc]
             generic = [
                 'const int ea = %s;' % ea,
                 'if (ea & 0x80) e.ram_wr(ea & 0x7f, %s);' % val,
-                'else if (__builtin_expect(!e.tia_store_quiet(ea & 0x3f, %s), 0)) %s' % (val, pend % 'ea'),
+                'else if (__builtin_expect(!e.tia_store_is_nop(ea & 0x3f, %s), 0)) %s' % (val, pend % 'ea'),
                 ('%s e.cyc += %d;' % (dec_s, dc)).strip()
             ]
             h = self.s_hint.get(a) if mode == M_PUSH else None
@@ -465,7 +465,7 @@ class Cart(object):
             if h & 0x80:
                 fast = ['e.ram_wr(0x%02x, %s);' % (h & 0x7f, val)]
             else:
-                fast = ['if (__builtin_expect(!e.tia_store_quiet(0x%02x, %s), 0)) %s' % (h & 0x3f, val, pend % ('0x%02x' % h))]
+                fast = ['if (__builtin_expect(!e.tia_store_is_nop(0x%02x, %s), 0)) %s' % (h & 0x3f, val, pend % ('0x%02x' % h))]
             fast.append('e.S = 0x%02x; e.cyc += %d;' % ((h - 1) & 0xff, dc))
             return ['if (__builtin_expect(e.S == 0x%02x, 1)) { %s } else { %s }' % (h, ' '.join(fast), ' '.join(generic))]
         # K_RMW

@@ -129,6 +129,14 @@ struct Emu {
       default: return false;
     }
   }
+  // atari_core.hpp tia_store_quiet: ENAMx / ENABL bytes whose D1 does not change are stored without the
+  // interpreter (the oracle's own write would render first; with D1 unchanged that changes no pixel)
+  bool tia_store_quiet(int reg, int v) {
+    if (tia_store_is_nop(reg, v)) return true;
+    uint8_t* f = reg == 0x1d ? &a->enam0 : (reg == 0x1e ? &a->enam1 : (reg == 0x1f ? &a->enabl : nullptr));
+    if (f && !((*f ^ v) & 0x02)) { *f = (uint8_t)v; return true; }
+    return false;
+  }
 };
 
 template <int GAME> struct NativeCart { static constexpr bool present = false; static constexpr uint32_t rom_crc32 = 0; };
