@@ -283,7 +283,7 @@ class Cart(object):
                 # on every line of its kernel); collision latches go to the interpreter
                 pre = ['const int ea = (0x%02x + %s) & 0xff;' % (b1, idx), 'int dc = 4, m;',
                        'if (ea & 0x80) m = e.ram_rd(ea & 0x7f);',
-                       'else if ((ea & 0x0f) >= 8) { e.cyc += 4; dc = 0; m = e.tia_read(ea, 0x%02x); }' % b1,
+                       'else if ((ea & 0x0f) >= 8) { e.cyc += 4; dc = 0; m = e.inpt_read(ea, 0x%02x); }' % b1,
                        'else { --n; e.PC = 0x%04x; %sreturn; }' % (a, '' if self.name in ZPX_LATCH_GAMES else '/*rare*/ ')]
                 dc = None
             elif mode == M_ABS:
@@ -321,7 +321,13 @@ class Cart(object):
                     if can_riot:
                         arms.append('if ((ea & 0x%x) == 0x280) { e.cyc += dc; dc = 0; m = e.riot_read(ea); }' %
                                     (0x1280 if not can_rom else 0x280))
-                    arms.append('if ((ea & 0x0f) >= 8) { e.cyc += dc; dc = 0; m = e.tia_read(ea, 0x%02x); }' % b2)
+                    inpt = 'if ((ea & 0x0f) >= 8) { e.cyc += dc; dc = 0; m = e.inpt_read(ea, 0x%02x); }' % b2
+                    if not (base & 0x1280) and (base & 0x0f) >= 8:
+                        # the base itself is an input port (Pong: `LDA $0038,Y` / `$003a,Y` on every line pair):
+                        # that arm first, as the fall-through path
+                        arms.insert(0, 'if (__builtin_expect(!(ea & 0x1280) && (ea & 0x08), 1)) { e.cyc += dc; dc = 0; '
+                                       'm = e.inpt_read(ea, 0x%02x); }' % b2)
+                    arms.append(inpt)
                     pre += [arms[0]] + ['else ' + x for x in arms[1:]] + ['else { --n; e.PC = 0x%04x; /*rare*/ return; }' % a]
             elif mode == M_IZY:
                 if b1 < 0x80 or b1 == 0xff:

@@ -131,6 +131,7 @@ struct Emu {
   }
   // atari_core.hpp tia_store_quiet: ENAMx / ENABL bytes whose D1 does not change are stored without the
   // interpreter (the oracle's own write would render first; with D1 unchanged that changes no pixel)
+  int inpt_read(int reg, int noise) { return tia_read(reg, noise); }
   bool tia_store_quiet(int reg, int v) {
     if (tia_store_is_nop(reg, v)) return true;
     uint8_t* f = reg == 0x1d ? &a->enam0 : (reg == 0x1e ? &a->enam1 : (reg == 0x1f ? &a->enabl : nullptr));
