@@ -42,6 +42,13 @@ ZPX_LATCH_GAMES = ('pong', )
 # stored without the interpreter): Pong writes them with PHP.  Breakout never does and only pays for
 # the extra test at every store site (PMC: 158.6 k -> 161.3 k instructions per frame with it on).
 QUIET_STORE_GAMES = ('pong', )
+# games whose innermost 6507 loops get ONE way in (Cart.find_loops).  MEASURED AND SWITCHED OFF: it does
+# what it says — the guard-flag chains disappear from the hot path (Pong: 113.0 k -> 106.4 k instructions
+# per frame, SALU 79 k -> 71 k) — but the branch count does not move (14.1 k), SGPR spills go 580 -> 920,
+# every re-entry after a hand-over now takes dispatch -> loop head -> second switch, and the kernel is
+# bound by fetch latency after taken branches, not by instruction count: SQ_WAVE_CYCLES -1.9 % in the
+# reset-phase micro-benchmark, but the whole pipeline in steady play 2.66 -> 2.59 M frames/s.
+LOOP_REENTRY_GAMES = ()
 
 # ---- mirrors atari_defs.hpp (decode_opcode) ------------------------------------------------------
 M_IMP, M_IMM, M_ZP, M_ZPX, M_ZPY, M_ABS, M_ABX, M_ABY, M_IZX, M_IZY, M_REL, M_PUSH, M_PULL = range(13)
@@ -112,6 +119,12 @@ class Cart(object):
         self.code = {}  # 16-bit address -> (mode, kind, op, b1, b2)
         self.discover()
         self.s_hint = self.stack_hints()
+        self.cur = None       # block being emitted (goto() needs the source of an edge)
+        self.loops = self.find_loops() if name in LOOP_REENTRY_GAMES else []
+        self.loop_of = {}     # instruction start inside a re-entry loop -> index of the loop
+        for i, (h, stream) in enumerate(self.loops):
+            for x in stream:
+                self.loop_of[x] = i
 
     def byte(self, a):
         return self.rom[a & self.mask]
@@ -145,6 +158,62 @@ class Cart(object):
                 if op in ('JAM', 'BRK', 'RTS', 'RTI', 'JMPI', 'JMP'):
                     break
                 a = (a + length(mode)) & 0xffff
+
+    def find_loops(self):
+        """Innermost 6507 loops that get a single way in.  The dispatch switch of native_run enters the
+        code at every instruction that follows a possible hand-over — a dozen places inside Pong's
+        62-instruction scanline loop.  A loop that can be entered in the middle is irreducible control
+        flow; LLVM repairs it (FixIrreducible) by routing EVERY edge into such a block, also the
+        fall-through from the instruction before it, through a guard header: ~15 flag moves, a chain of
+        flag tests and several taken branches per edge, a dozen times per loop iteration (ISA of the
+        block after Pong's `PHP` at $F629).  Here such a loop is entered only at its head: the dispatch
+        case of an inner instruction sets `sel` and jumps to the head, whose first statement is
+        `if (sel) switch (sel) { ... goto inner; }` — forward edges inside the loop, reducible.  Edges
+        into the loop's interior from blocks outside it (overlapping decodes, jumps into the middle)
+        become returns to the dispatcher.
+        A loop qualifies if the linear decode from the target of a backward branch reaches the branch
+        (one instruction stream), every other backward branch inside targets the same head, and the
+        stream has no BRK / RTS / RTI / JMP () / JAM."""
+        heads = {}
+        for a in self.code:
+            mode, kind, op, b1, b2 = self.code[a]
+            if mode == M_REL:
+                t = (a + 2 + (b1 - 256 if b1 & 0x80 else b1)) & 0xffff
+                if t <= a and t in self.code:
+                    heads.setdefault(t, []).append(a)
+        cands = []
+        for h, latches in heads.items():
+            for end in sorted(latches, reverse=True):  # the widest region whose stream is aligned
+                stream, a, ok = [], h, True
+                while a <= end:
+                    if a not in self.code:
+                        ok = False
+                        break
+                    mode, kind, op, b1, b2 = self.code[a]
+                    stream.append(a)
+                    if op in ('BRK', 'RTS', 'RTI', 'JMPI', 'JAM', 'JMP'):
+                        ok = False
+                        break
+                    a = (a + length(mode)) & 0xffff
+                if not ok or stream[-1] != end:
+                    continue
+                sset = set(stream)
+                for x in stream:  # innermost: no backward branch to another head
+                    mode, kind, op, b1, b2 = self.code[x]
+                    if mode == M_REL:
+                        t = (x + 2 + (b1 - 256 if b1 & 0x80 else b1)) & 0xffff
+                        if t <= x and t != h:
+                            ok = False
+                if ok and len(stream) >= 4:
+                    cands.append((len(stream), h, stream))
+                    break
+        # overlapping decodes produce overlapping candidates: the longer stream wins, disjoint ones only
+        taken, out = set(), []
+        for _, h, stream in sorted(cands, reverse=True):
+            if not (set(range(stream[0], stream[-1] + 3)) & taken):
+                taken |= set(range(stream[0], stream[-1] + 3))
+                out.append((h, stream))
+        return out
 
     def stack_hints(self):
         """Likely value of the stack pointer BEFORE each instruction, by an optimistic forward dataflow
@@ -246,10 +315,20 @@ class Cart(object):
     def label(self, a):
         return 'L_%04X' % a
 
+    def inside_edge_ok(self, dst):
+        """may the block being emitted jump straight to `dst`?  Not into the interior of a re-entry loop
+        from outside its instruction stream (find_loops): that goes back through the dispatcher."""
+        i = self.loop_of.get(dst)
+        if i is None or dst == self.loops[i][0]:
+            return True
+        return self.loop_of.get(self.cur) == i
+
     def goto(self, a):
-        if a in self.code:
+        if a not in self.code:
+            return '{ e.PC = 0x%04x; return; }' % a
+        if self.inside_edge_ok(a):
             return 'goto %s;' % self.label(a)
-        return '{ e.PC = 0x%04x; return; }' % a
+        return '{ e.PC = 0x%04x; /*rare*/ return; }' % a
 
     def fallback(self, a):
         return ['{ e.PC = 0x%04x; return; }' % a]
@@ -264,6 +343,7 @@ class Cart(object):
         }[op]
 
     def emit(self, a):
+        self.cur = a
         mode, kind, op, b1, b2 = self.code[a]
         L = []
         nxt = (a + length(mode)) & 0xffff
@@ -504,12 +584,25 @@ class Cart(object):
                    'static constexpr uint32_t rom_crc32 = 0x%08xu; };' % (game_const, crc))
         out.append('template <> DEVI void native_run<%s>(Emu& e, int& n) {' % game_const)
         out.append('  if (n > kNativeInstrLimit) return;')
+        if self.loops:
+            out.append('  int sel = 0;  // re-entry into the middle of a loop goes through its head (find_loops)')
         out.append('  switch (e.PC) {')
         entries = self.entries()
+        sel_cases = {}  # loop index -> [(sel value, address)]
         for a in sorted(entries):
-            out.append('    case 0x%04x: goto %s;' % (a, self.label(a)))
+            i = self.loop_of.get(a)
+            if i is not None and a != self.loops[i][0]:
+                lst = sel_cases.setdefault(i, [])
+                lst.append((len(lst) + 1, a))
+                out.append('    case 0x%04x: sel = %d; goto %s;' % (a, len(lst), self.label(self.loops[i][0])))
+            else:
+                out.append('    case 0x%04x: goto %s;' % (a, self.label(a)))
         out.append('    default: return;')
         out.append('  }')
+        head_switch = {}
+        for i, lst in sel_cases.items():
+            head_switch[self.loops[i][0]] = ('    if (__builtin_expect(sel != 0, 0)) { const int s_ = sel; sel = 0; switch (s_) { %s default: break; } }'
+                                             % ' '.join('case %d: goto %s;' % (k, self.label(a)) for k, a in lst))
         native = 0
         for i, a in enumerate(addrs):
             mode, kind, op, b1, b2 = self.code[a]
@@ -517,6 +610,8 @@ class Cart(object):
             is_fb = len(body) == 1 and body[0].startswith('{ e.PC')
             native += 0 if is_fb else 1
             out.append('  %s: {  // %s mode %d' % (self.label(a), op, mode))
+            if a in head_switch:
+                out.append(head_switch[a])
             if MARKERS:
                 out.append('    asm volatile("; @@BLK %04x");' % a)
             if is_fb:
@@ -529,8 +624,11 @@ class Cart(object):
             out.append('  }')
             nxt = (a + length(mode)) & 0xffff
             terminal = op in ('JMP', 'JAM', 'BRK', 'RTS', 'RTI', 'JMPI', 'JSR') or is_fb
+            self.cur = a
             if not terminal and nxt not in self.code:
                 out.append('  { e.PC = 0x%04x; return; }' % nxt)
+            elif not terminal and not self.inside_edge_ok(nxt):
+                out.append('  { e.PC = 0x%04x; return; }' % nxt)  # fall-through into a loop's interior from outside it
             elif not terminal and (i + 1 >= len(addrs) or addrs[i + 1] != nxt):
                 out.append('  goto %s;' % self.label(nxt))
         out.append('}')
