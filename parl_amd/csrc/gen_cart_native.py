@@ -48,7 +48,7 @@ QUIET_STORE_GAMES = ('pong', )
 # every re-entry after a hand-over now takes dispatch -> loop head -> second switch, and the kernel is
 # bound by fetch latency after taken branches, not by instruction count: SQ_WAVE_CYCLES -1.9 % in the
 # reset-phase micro-benchmark, but the whole pipeline in steady play 2.66 -> 2.59 M frames/s.
-LOOP_REENTRY_GAMES = ()
+LOOP_REENTRY_GAMES = tuple(x for x in os.environ.get('PARLHIP_LOOP_REENTRY', '').split(',') if x)  # default: none
 
 # ---- mirrors atari_defs.hpp (decode_opcode) ------------------------------------------------------
 M_IMP, M_IMM, M_ZP, M_ZPX, M_ZPY, M_ABS, M_ABX, M_ABY, M_IZX, M_IZY, M_REL, M_PUSH, M_PULL = range(13)
