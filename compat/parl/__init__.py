@@ -1,7 +1,7 @@
 """`import parl` for scripts written against PaddlePaddle/PARL, served by parl_amd.
 
 Put this directory (compat/) on PYTHONPATH and the reference's own example scripts run unchanged
-on the MI355X path (tests/test_gpu_reference_scripts.py executes
+on the MI355X path (tests/test_reference_scripts.py executes
 /root/reference/benchmark/torch/a2c/{train,actor,atari_agent,atari_model}.py by path):
 
     parl.Model / Algorithm / Agent, parl.algorithms.{A2C, IMPALA, PPO}, parl.remote_class / connect,

@@ -38,6 +38,9 @@ typedef void* parlhip_stream_t;
 
 /* library version (major*10000 + minor*100 + patch) and error text */
 int parlhip_version(void);
+/* sha256[:16] over the sources the library was built from (csrc/srchash.py): build hygiene, lets a
+ * test notice a library that does not match the tree */
+const char* parlhip_source_hash(void);
 const char* parlhip_strerror(int code);
 /* hipError_t (as int) of the last failing runtime call on this thread, 0 if none */
 int parlhip_last_hip_error(void);

@@ -5,7 +5,7 @@
  *
  * Formulation: deliberately the simplest one — the CPU ticks one bus cycle at a time and the
  * TIA is advanced one colour clock (one pixel) at a time up to the clock of each register
- * access.  The HIP emulator (parl_amd/csrc/atari_emu.hip) uses a different formulation
+ * access.  The HIP emulator (parl_amd/csrc/atari_core.hpp + atari_env.hip) uses a different formulation
  * (whole-instruction cycle counts, 64-lane segment rendering with bit masks); the two must
  * agree bit-for-bit on frame buffers, RAM and rewards.
  */

@@ -31,6 +31,7 @@ _d = ctypes.c_double
 # and exported by the .so).
 SIGNATURES = {
     'parlhip_version': (_i, []),
+    'parlhip_source_hash': (ctypes.c_char_p, []),
     'parlhip_strerror': (ctypes.c_char_p, [_i]),
     'parlhip_last_hip_error': (_i, []),
     'parlhip_consume_device_errors': (_i, [_p]),

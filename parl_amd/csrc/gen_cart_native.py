@@ -656,6 +656,7 @@ def main():
     text = '\n'.join(parts) + '\n'
     try:
         if open(out_path).read() == text:
+            os.utime(out_path)  # make must see the target as remade, or it stays stale for ever
             return
     except OSError:
         pass

@@ -2,7 +2,9 @@
 own torch ActorCritic model (benchmark/torch/a2c/atari_model.py:23-104), imported from
 /root/reference with the 5-stub shim of SURVEY.md A4 and run on CPU: initial state_dict, two
 batches (uint8 observations, actions, advantages, target values), the four losses of each
-learn() call, the parameters after the two updates, and prob_and_value / predict outputs.
+learn() call, every parameter's GRADIENT as Adam consumed it (captured at optimizer.step(), i.e.
+after clip_grad_norm_(…, 40.0), a2c.py:66-68), the parameters after the two updates,
+and prob_and_value / predict outputs.
 To keep the fixture small the initial parameters are drawn from a seeded numpy generator
 (`init_weights`, xavier-normal scale like the reference's _init_parameters) and loaded into the
 reference model — the test regenerates them — and the 2.65 M-element fc weight is stored after
@@ -59,6 +61,14 @@ if __name__ == '__main__':
     alg = A2C(model, {'vf_loss_coeff': 0.5, 'learning_rate': 0.001})
     rng = np.random.default_rng(11)
     out = {'dims': np.array([A, N])}
+    grads = {}
+    opt_step = alg.optimizer.step
+
+    def recording_step(*a, **kw):  # learn() zeroes the gradients right after the step (a2c.py:69)
+        grads.update({k: prm.grad.detach().clone().numpy() for k, prm in model.named_parameters()})
+        return opt_step(*a, **kw)
+
+    alg.optimizer.step = recording_step
     for step, (lr, ec) in enumerate([(1e-3, -0.01), (7e-4, -0.02)]):
         # block-structured observations (like frames), not white noise
         obs = np.repeat(np.repeat(rng.integers(0, 256, (N, 4, 12, 12), dtype=np.uint8), 7, 2), 7, 3)
@@ -76,6 +86,12 @@ if __name__ == '__main__':
         out['step%d/advantages' % step], out['step%d/target_values' % step] = adv, tgt
         out['step%d/lr_ec' % step] = np.array([lr, ec])
         out['step%d/losses' % step] = np.array([float(x) for x in losses])
+        for k, g in grads.items():
+            if k == 'fc.weight':
+                out['step%d/grad_sample/%s' % (step, k)] = g.reshape(-1)[::FC_STRIDE].copy()
+                out['step%d/grad_stats/%s' % (step, k)] = np.array([np.abs(g).max(), np.sqrt((g.astype(np.float64) ** 2).sum())])
+            else:
+                out['step%d/grad/%s' % (step, k)] = g.copy()
     for k, v in model.state_dict().items():
         w = v.detach().numpy()
         if k == 'fc.weight':

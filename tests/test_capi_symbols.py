@@ -102,3 +102,18 @@ def test_native_cartridge_translation_is_built_and_tagged(built_lib):
         assert lib.parlhip_atari_rom_table_build(rom.ctypes.data, len(rom), table.ctypes.data) == 0
         assert int(table[0] >> 28) == 0
     assert lib.parlhip_atari_native_cart(0) == 0
+
+
+def test_library_matches_the_tree(built_lib):
+    """build hygiene: the library carries the hash of the sources it was built from
+    (csrc/srchash.py); a stale or half-rebuilt .so does not match the tree"""
+    import sys
+    from parl_amd import _native
+    csrc = os.path.join(ROOT, 'parl_amd', 'csrc')
+    sys.path.insert(0, csrc)
+    try:
+        import srchash
+    finally:
+        sys.path.remove(csrc)
+    assert _native.lib().parlhip_source_hash().decode() == srchash.source_hash(), \
+        'libparl_hip.so is stale: run python __graft_entry__.py'

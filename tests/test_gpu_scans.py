@@ -390,8 +390,10 @@ def test_impala_learn_in_row_chunks_equals_one_pass(dev):
 @pytest.mark.parametrize('T,B,A', [(50, 1024, 6), (50, 37, 4), (10, 5, 6), (64, 9, 4), (2, 3, 6)])
 def test_impala_heads_loss_matches_heads_plus_fused_loss(dev, T, B, A):
     """parlhip_impala_heads_loss_f32 (policy_fc + value_fc + loss + the heads' backward, one kernel) against
-    torch heads in float64 + the float64 autograd of the reference formulas' kernel twin (ops.impala_loss
-    applied to float32 heads): sums, V-trace outputs, gradients w.r.t. the trunk output and the heads."""
+    its two-kernel twin: torch float32 heads (rocBLAS) + ops.impala_loss behind them + torch autograd through
+    the heads.  A consistency check between two HIP paths (hence the looser tolerance: two float32 head
+    GEMMs with different summation orders); the check against the CPU oracle / float64 is
+    test_impala_heads_loss_vs_oracle_and_f64_autograd below."""
     from parl_amd import ops
     torch.manual_seed(T * 1000 + B)
     H = 256
@@ -431,6 +433,62 @@ def test_impala_heads_loss_matches_heads_plus_fused_loss(dev, T, B, A):
     out2 = ops.impala_heads_loss(hd, wp, bp, wv, bv, bl, act, rew, dn, 0.99, 1.0, 1.0, 0.5, -0.01)
     for a, b in zip(out[:7], out2[:7]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('T,B,A', [(50, 1024, 6), (50, 1024, 4), (50, 37, 6), (7, 5, 4)])
+def test_impala_heads_loss_vs_oracle_and_f64_autograd(dev, T, B, A):
+    """The kernel the bench's learner runs, checked directly against the CPU path at north_star's 1e-5:
+      * heads (policy_fc / value_fc, atari_model.py:44-57,73-90) evaluated on the HOST in float64 from the same
+        h, W, b, rounded to float32 (what a float32 framework hands to the loss);
+      * V-trace targets from the C oracle (vtrace.py:99-137 + impala.py:59,167-194) on those logits / values:
+        vs / pg_adv rtol = atol = 1e-5;
+      * the loss sums and KL (impala.py:59-79, 151-162) in float64 on the host: 1e-5 relative;
+      * d total / d h, d W, d b by float64 autograd through float64 heads with the oracle's targets as constants
+        (vtrace.py:36 @no_grad): 1e-5 of each gradient's scale."""
+    import torch.nn.functional as F
+    from parl_amd import ops
+    from oracle import c_oracle
+    torch.manual_seed(T * 1000 + B + A)
+    H = 256
+    hd = torch.relu(torch.randn(T, B, H))
+    wp, bp = torch.randn(A, H) * 0.1, torch.randn(A) * 0.1
+    wv, bv = torch.randn(1, H) * 0.05, torch.randn(1) * 0.1
+    bl = torch.randn(T, B, A)
+    act = torch.randint(0, A, (T, B))
+    rew = torch.randint(-1, 2, (T, B)).float()
+    dn = torch.rand(T, B) < 0.05
+    gamma, crho, cpg, vf_c, ent_c = 0.99, 1.0, 1.0, 0.5, -0.01
+    d = lambda x: x.to(dev)
+    out = ops.impala_heads_loss(d(hd), d(wp), d(bp), d(wv), d(bv), d(bl), d(act), d(rew), d(dn), gamma, crho, cpg,
+                                vf_c, ent_c)
+    assert out is not None
+    vs, pg, gh, gwp, gbp, gwv, gbv, sums = [x.cpu() for x in out]
+    # host, float64
+    h64 = hd.double().requires_grad_(True)
+    prm = [x.double().requires_grad_(True) for x in (wp, bp, wv, bv)]
+    logits64 = F.linear(h64, prm[0], prm[1])
+    values64 = F.linear(h64, prm[2], prm[3]).squeeze(-1)
+    ovs, opg, _, _ = c_oracle.vtrace_from_logits(bl.numpy(), logits64.detach().float().numpy(), act.numpy(),
+                                                 rew.numpy(), dn.numpy(), values64.detach().float().numpy(), gamma,
+                                                 crho, cpg)
+    np.testing.assert_allclose(vs.numpy(), ovs, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(pg.numpy(), opg, rtol=1e-5, atol=1e-5)
+    logp = F.log_softmax(logits64, dim=-1)
+    p = logp.exp()
+    ent = -(p * logp).sum(-1)
+    tlp = logp.gather(-1, act.unsqueeze(-1)).squeeze(-1)
+    pi_loss = -(tlp[:-1] * torch.from_numpy(opg).double()).sum()
+    vf_loss = 0.5 * ((values64[:-1] - torch.from_numpy(ovs).double())**2).sum()
+    entropy = ent[:-1].sum()
+    kl = (p * (logp - F.log_softmax(bl.double(), dim=-1))).sum()
+    (pi_loss + vf_c * vf_loss + ent_c * entropy).backward()
+    ref = np.array([float(pi_loss), float(vf_loss), float(entropy), float(kl)])
+    np.testing.assert_allclose(sums.numpy(), ref, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()))
+    for mine, want, name in ((gh, h64.grad, 'd h'), (gwp, prm[0].grad, 'd W_policy'), (gbp, prm[1].grad, 'd b_policy'),
+                             (gwv.reshape(1, H), prm[2].grad, 'd W_value'), (gbv, prm[3].grad, 'd b_value')):
+        scale = float(want.abs().max()) + 1e-30
+        err = float((mine.double() - want).abs().max())
+        assert err <= 1e-5 * scale, (name, err, scale)
 
 
 def test_impala_learn_fused_heads_equals_framework_heads(dev):

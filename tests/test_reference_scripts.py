@@ -15,12 +15,10 @@ Two variants of the same body:
     replaced by TEST DOUBLES backed by the CPU oracle — DeviceVectorEnv by the oracle's VecEnv and
     calc_gae by the oracle's scan — so the script, the host layer (handles, VectorEnv, MonitorEnv
     bookkeeping, remote proxies, Agent / Algorithm / Model, A2C.learn) run for real;
-  * -m gpu: the real device path (env kernel, frame_post, GAE kernel) — runs wherever a GPU and
-    /root/reference exist together.  The GPU boxes of this project have no /root/reference and
-    reference sources are never copied into the repo, so there the variant skips; the device side
-    of the same boundary (gym.make -> wrap_deepmind -> VectorEnv on the real kernels, parity with
-    the oracle, MonitorEnv statistics) is covered by
-    tests/test_gpu_env.py::test_reference_style_vector_env_on_device.
+  * -m gpu: the real device path (env kernel, frame_post, GAE kernel).  The GPU boxes have no
+    /root/reference, and reference sources are never committed: build() (oracle/make_ref.py) stages
+    the five scripts byte for byte into the git-ignored oracle/_ref/a2c/, which travels with the
+    snapshot like the built .so files, and this test runs them from there.
 """
 import importlib
 import os
@@ -33,13 +31,24 @@ import torch
 from conftest import ROOT
 
 REF_DIR = '/root/reference/benchmark/torch/a2c'
+STAGED_DIR = os.path.join(ROOT, 'oracle', '_ref', 'a2c')  # oracle/make_ref.py, git-ignored
 SCRIPTS = ['train.py', 'actor.py', 'atari_agent.py', 'atari_model.py', 'a2c_config.py']
 
 
-def _script_dir(tmp_path):
-    if os.path.isdir(REF_DIR):
-        return REF_DIR
-    pytest.skip('needs /root/reference (reference sources are never copied into this repo)')
+def _script_dir():
+    for d in (REF_DIR, STAGED_DIR):
+        if all(os.path.exists(os.path.join(d, s)) for s in SCRIPTS):
+            return d
+    pytest.skip('needs the reference a2c scripts (/root/reference or oracle/_ref/a2c staged by build())')
+
+
+def test_staged_scripts_are_the_reference_files_byte_for_byte():
+    if not os.path.isdir(REF_DIR):
+        pytest.skip('needs /root/reference (build container)')
+    if not os.path.isdir(STAGED_DIR):
+        pytest.skip('oracle/_ref/a2c not staged (python __graft_entry__.py)')
+    for s in SCRIPTS:
+        assert open(os.path.join(STAGED_DIR, s), 'rb').read() == open(os.path.join(REF_DIR, s), 'rb').read(), s
 
 
 def _run_reference_a2c(script_dir, monkeypatch, steps, env_num, actor_num, T):
@@ -47,7 +56,7 @@ def _run_reference_a2c(script_dir, monkeypatch, steps, env_num, actor_num, T):
     monkeypatch.syspath_prepend(script_dir)
     for m in ['gym', 'parl', 'train', 'actor', 'atari_agent', 'atari_model', 'a2c_config']:
         monkeypatch.delitem(sys.modules, m, raising=False)
-    monkeypatch.chdir(os.path.dirname(script_dir) if os.access(script_dir, os.W_OK) else '/tmp')
+    monkeypatch.chdir('/tmp')  # the script's logger may create train_log/ in the cwd
     import parl_amd
     import gym  # compat/gym
     import parl  # compat/parl
@@ -129,7 +138,7 @@ def test_reference_torch_a2c_scripts_run_unmodified_on_cpu_doubles(tmp_path, mon
 
 @pytest.mark.gpu
 def test_reference_torch_a2c_scripts_run_unmodified_on_the_device(dev, tmp_path, monkeypatch):
-    d = _script_dir(tmp_path)
+    d = _script_dir()
     # the script's own ActorCritic uses nn.Conv2d; this image has no MIOpen kernel database for
     # gfx950 (every new shape would JIT for minutes): use torch's native convolution instead
     monkeypatch.setattr(torch.backends.cudnn, 'enabled', False)
