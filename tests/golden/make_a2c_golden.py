@@ -92,6 +92,35 @@ if __name__ == '__main__':
                 out['step%d/grad_stats/%s' % (step, k)] = np.array([np.abs(g).max(), np.sqrt((g.astype(np.float64) ** 2).sum())])
             else:
                 out['step%d/grad/%s' % (step, k)] = g.copy()
+    # a second, INDEPENDENT gradient check at regenerable weights (init_weights(seed=4)): the second update's
+    # gradient above is taken at parameters that already went through one Adam step, whose sign-like first
+    # step amplifies float32 rounding of near-zero gradients into +-lr — a test against it cannot be tight
+    model2 = mod.ActorCritic(A)
+    model2.load_state_dict({k: torch.from_numpy(v) for k, v in init_weights(A, seed=4).items()})
+    alg2 = A2C(model2, {'vf_loss_coeff': 0.5, 'learning_rate': 0.001})
+    grads2 = {}
+    opt_step2 = alg2.optimizer.step
+
+    def recording_step2(*a, **kw):
+        grads2.update({k: prm.grad.detach().clone().numpy() for k, prm in model2.named_parameters()})
+        return opt_step2(*a, **kw)
+
+    alg2.optimizer.step = recording_step2
+    obs = np.repeat(np.repeat(rng.integers(0, 256, (N, 4, 12, 12), dtype=np.uint8), 7, 2), 7, 3)
+    act = rng.integers(0, A, N).astype(np.int64)
+    adv = rng.standard_normal(N).astype(np.float32)
+    tgt = rng.standard_normal(N).astype(np.float32)
+    losses = alg2.learn(torch.from_numpy(obs).float(), torch.from_numpy(act), torch.from_numpy(adv),
+                        torch.from_numpy(tgt), 5e-4, -0.01)
+    out['indep/obs'], out['indep/actions'], out['indep/advantages'], out['indep/target_values'] = obs, act, adv, tgt
+    out['indep/lr_ec'] = np.array([5e-4, -0.01])
+    out['indep/losses'] = np.array([float(x) for x in losses])
+    for k, g in grads2.items():
+        if k == 'fc.weight':
+            out['indep/grad_sample/' + k] = g.reshape(-1)[::FC_STRIDE].copy()
+            out['indep/grad_stats/' + k] = np.array([np.abs(g).max(), np.sqrt((g.astype(np.float64) ** 2).sum())])
+        else:
+            out['indep/grad/' + k] = g.copy()
     for k, v in model.state_dict().items():
         w = v.detach().numpy()
         if k == 'fc.weight':

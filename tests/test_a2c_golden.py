@@ -58,10 +58,41 @@ class TwinModel(parl.Model):
         return self.policy_and_value(obs)[1]
 
 
-def _check(model, make_alg, dev, rtol_loss, tol_w, tol_g):
+def _check_grads(model, z, prefix, tol_g):
+    """the gradients Adam consumed (after clip_grad_norm_(40), a2c.py:66-68), per parameter, against the
+    reference's: tol_g of each gradient's own scale"""
+    mine = {k: prm.grad.detach().cpu().numpy() for k, prm in model.named_parameters()}
+    for k in init_weights(6):
+        g = mine[_ours(k)]
+        if k == 'fc.weight':
+            ref, (gmax, gl2) = z[prefix + '/grad_sample/' + k], z[prefix + '/grad_stats/' + k]
+            assert np.abs(g.reshape(-1)[::FC_STRIDE] - ref).max() <= tol_g * gmax, (prefix, k)
+            np.testing.assert_allclose([np.abs(g).max(), np.sqrt((g.astype(np.float64)**2).sum())], [gmax, gl2],
+                                       rtol=10 * tol_g)
+        else:
+            ref = z[prefix + '/grad/' + k]
+            err = np.abs(g - ref).max()
+            assert err <= tol_g * np.abs(ref).max(), (prefix, k, err, np.abs(ref).max())
+
+
+def _check_independent_gradient(model, make_alg, dev, rtol_loss, tol_g):
+    """one learn() at the regenerable weights init_weights(seed=4): losses + gradients, no Adam history"""
+    z = load_golden('a2c_learn.npz')
+    model.load_state_dict({_ours(k): torch.from_numpy(v) for k, v in init_weights(int(z['dims'][0]), seed=4).items()})
+    model.to(dev)
+    alg = make_alg(model)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    lr, ec = z['indep/lr_ec']
+    out = alg.learn(t(z['indep/obs']), t(z['indep/actions']), t(z['indep/advantages']), t(z['indep/target_values']),
+                    float(lr), float(ec))
+    np.testing.assert_allclose(np.array([float(x.detach()) for x in out]), z['indep/losses'], rtol=rtol_loss,
+                               atol=rtol_loss)
+    _check_grads(model, z, 'indep', tol_g)
+
+
+def _check(model, make_alg, dev, rtol_loss, tol_w, tol_g, tol_g1=None):
     z = load_golden('a2c_learn.npz')
     lr_total = float(z['step0/lr_ec'][0] + z['step1/lr_ec'][0])
-    ref_names = [k for k, _ in init_weights(6).items()]
     A = int(z['dims'][0])
     model.load_state_dict({_ours(k): torch.from_numpy(v) for k, v in init_weights(A).items()})
     model.to(dev)
@@ -77,20 +108,12 @@ def _check(model, make_alg, dev, rtol_loss, tol_w, tol_g):
                         t(z['step%d/target_values' % step]), float(lr), float(ec))
         got = np.array([float(x) for x in out])
         np.testing.assert_allclose(got, z['step%d/losses' % step], rtol=rtol_loss, atol=rtol_loss)
-        # the gradients Adam consumed (after clip_grad_norm_(40), a2c.py:66-68), per parameter, against the
-        # reference's: tol_g of each gradient's own scale
-        mine = {k: prm.grad.detach().cpu().numpy() for k, prm in model.named_parameters()}
-        for k in ref_names:
-            g = mine[_ours(k)]
-            if k == 'fc.weight':
-                ref, (gmax, gl2) = z['step%d/grad_sample/%s' % (step, k)], z['step%d/grad_stats/%s' % (step, k)]
-                assert np.abs(g.reshape(-1)[::FC_STRIDE] - ref).max() <= tol_g * gmax, (step, k)
-                np.testing.assert_allclose([np.abs(g).max(), np.sqrt((g.astype(np.float64)**2).sum())], [gmax, gl2],
-                                           rtol=10 * tol_g)
-            else:
-                ref = z['step%d/grad/%s' % (step, k)]
-                err = np.abs(g - ref).max()
-                assert err <= tol_g * np.abs(ref).max(), (step, k, err, np.abs(ref).max())
+        # the second update's gradient is taken at parameters that went through one Adam step (sign-like: a
+        # near-zero gradient whose float32 rounding differs moves its weight by +lr instead of -lr); measured
+        # on the MI355X: 2.7e-4 of scale on conv1.weight, 2.1e-3 on fc.weight at step 1 with step 0 inside 1e-4 —
+        # hence tol_g1;
+        # the tight second gradient check is _check_independent_gradient
+        _check_grads(model, z, 'step%d' % step, tol_g if step == 0 or tol_g1 is None else tol_g1)
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
 
     def adam_slack(k, sample=False):
@@ -128,6 +151,7 @@ def test_a2c_learn_host_logic_matches_reference_torch_a2c(style):
     mk = (lambda m: parl.algorithms.A2C(m, vf_loss_coeff=0.5)) if style == 'paddle' else \
         (lambda m: parl.algorithms.A2C(m, {'vf_loss_coeff': 0.5, 'learning_rate': 0.001}))
     _check(TwinModel(6), mk, torch.device('cpu'), 1e-5, 1e-4, 1e-5)
+    _check_independent_gradient(TwinModel(6), mk, torch.device('cpu'), 1e-5, 1e-5)
 
 
 @pytest.mark.gpu
@@ -136,4 +160,5 @@ def test_a2c_learn_on_device_matches_reference_torch_a2c(dev, style):
     from parl_amd.models import AtariModel84
     mk = (lambda m: parl.algorithms.A2C(m, vf_loss_coeff=0.5)) if style == 'paddle' else \
         (lambda m: parl.algorithms.A2C(m, {'vf_loss_coeff': 0.5, 'learning_rate': 0.001}))
-    _check(AtariModel84(6), mk, dev, 1e-4, 2e-4, 1e-4)
+    _check(AtariModel84(6), mk, dev, 1e-4, 2e-4, 1e-4, tol_g1=5e-3)
+    _check_independent_gradient(AtariModel84(6), mk, dev, 1e-4, 1e-4)
