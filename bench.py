@@ -303,6 +303,10 @@ def main():
                     'whole batch; 0: the whole batch in one pass).  The backward kernels are persistent and '
                     'share no CU with the actors\' conv kernels, so shorter passes stall the rollout less: '
                     '2.54 M frames/s in one pass, 2.61-2.64 M at 6400 rows')
+    ap.add_argument('--train-batch', type=int, default=0,
+                    help='rows per learner update (0: ONE update per step on the whole T*E rollout).  1000 = the '
+                    'reference\'s train_batch_size (impala_config.py:31): the rollout is consumed as E // 20 updates of '
+                    '20 sequences, each one hipGraph replay (GraphedLearn)')
     ap.add_argument('--elastic', choices=('auto', 'on', 'off'), default='auto',
                     help='elastic launches (ElasticDeviceRollout): auto = games with lives (Breakout)')
     ap.add_argument('--quick', action='store_true',
@@ -381,14 +385,17 @@ def main():
     else:
         # IMPALA's actor/learner decoupling on one GPU: the learner update on batch i-1 runs on its
         # own stream while the actors collect batch i (behaviour policy lags by one update)
-        pipe = AsyncActorLearner(alg, envs, T, seed=99, elastic=elastic)
+        pipe = AsyncActorLearner(alg, envs, T, seed=99, elastic=elastic, train_batch_size=args.train_batch or None)
         rollout = pipe.rollout
         pipe.prime()  # untimed: every timed step = one rollout + one learner update
 
         pipe.gather_small = pdist.active()  # small-tensor trajectory all-gather on the learner stream
 
         def step():
-            loss, kl = pipe.step(lr_s.step(), ent_s.step())
+            if args.train_batch:  # the schedulers step once per update, as the reference's learner does
+                loss, kl = pipe.step(lr_s, ent_s)
+            else:
+                loss, kl = pipe.step(lr_s.step(), ent_s.step())
             return loss
 
     for _ in range(args.warmup):
@@ -396,6 +403,7 @@ def main():
     pdist.barrier()
     torch.cuda.synchronize()
     vt_timer.enabled = hl_timer.enabled = env_timer.enabled = fp_timer.enabled = True
+    updates0 = pipe.updates if pipe is not None else 0
     t0 = time.time()
     for _ in range(args.steps):
         loss = step()
@@ -433,7 +441,7 @@ def main():
                             ('gloo, ranks SHARE GPUs (fewer devices than ranks: functional run, not a scaling number)'
                              if shared else 'RCCL: flat-gradient all-reduce + small-tensor all-gather per update')),
         },
-        'learner_updates_per_sec': K / dt,
+        'learner_updates_per_sec': ((pipe.updates - updates0) if pipe is not None else K) / dt,
         'agent_steps_per_sec': K * T * E * world / dt,
     }
     if rank == 0:
@@ -448,15 +456,28 @@ def main():
         kname = ('impala_loss_wave_kernel (V-trace + log-prob gather + entropy + KL + loss sums + gradient, '
                  if fused else 'vtrace_logits_wave_kernel (fused log-prob gather + V-trace, ')
         hl = hl_timer.mean_seconds()
+        Bl = E if G == 1 else Eg
+        if args.train_batch and pipe is not None and pipe.sub_batches:
+            # the updates are hipGraph replays (no host call to time around): the same kernel, same shape
+            # (T x 20 sequences), timed standalone on this stream
+            Bl = pipe.sub_batches[0][1]
+            hd = torch.relu(torch.randn(T, Bl, 256, device=dev))
+            hw = [torch.randn(A, 256, device=dev) * 0.1, torch.zeros(A, device=dev), torch.randn(1, 256, device=dev) * 0.05,
+                  torch.zeros(1, device=dev)]
+            hb = [torch.randn(T, Bl, A, device=dev), torch.randint(0, A, (T, Bl), device=dev), torch.randn(T, Bl, device=dev),
+                  torch.rand(T, Bl, device=dev) < 0.01]
+            hl = _event_time(lambda: _native.lib().parlhip_impala_heads_loss_f32 and
+                             ops.impala_heads_loss(hd, *hw, *hb, 0.99, 1.0, 1.0, 0.5, -0.01), iters=30)
         if hl is not None:
             # the heads + loss + heads' backward kernel: per (t, b) row the trunk output in (1024 B),
             # its gradient out (1024 B), behaviour logits, action, reward, done in; vs, pg_adv out for T-1 rows
-            Bl = E if G == 1 else Eg
             by = T * Bl * (2 * 256 * 4 + A * 4 + 8 + 4 + 1) + (T - 1) * Bl * 8
             out['roofline'] = {
                 'kernel': 'impala_heads_loss_kernel (policy_fc + value_fc + log-softmax / entropy / KL + V-trace + loss '
                           'sums + gradient w.r.t. the trunk output and the heads, wave per sequence, T=%d B=%d A=%d, '
-                          'one launch per update; timed with its 1,799-thread partial-sum kernel)' % (T, Bl, A),
+                          'one launch per update; timed with its partial-sum kernel%s)' %
+                          (T, Bl, A, '; train_batch mode: standalone timing incl. the wrapper\'s output allocations, '
+                           '%.1f MB per launch is launch-latency-bound by construction' % (by / 1e6) if args.train_batch else ''),
                 'bound': 'hbm', 'achieved': by / hl / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                 'frac': by / hl / 1e9 / HBM_PEAK_GBPS, 'bytes_per_launch': by,
                 'note': 'the V-trace scan at the WORKLOAD shape, fused with the two heads so that the 52 MB trunk '

@@ -197,25 +197,42 @@ class IMPALA(Algorithm):
             vs.append(v)
         return torch.cat(ls, 0), torch.cat(vs, 0)
 
+    def _can_fuse_heads(self, obs, time_major):
+        """the one-kernel heads + loss path (ops.impala_heads_loss) applies: time-major batch on the device, T <= 64,
+        a model that exposes its trunk and two biased float32 Linear heads on 256 hidden units, A in {4, 6}"""
+        m, T = self.model, self.sample_batch_steps
+        pf, vf = getattr(m, 'policy_fc', None), getattr(m, 'value_fc', None)
+        return bool(self.fused_loss and self.fused_heads and time_major and T <= 64 and obs.is_cuda
+                    and hasattr(m, '_trunk') and isinstance(pf, torch.nn.Linear) and isinstance(vf, torch.nn.Linear)
+                    and pf.in_features == 256 and vf.in_features == 256 and pf.out_features in (4, 6)
+                    and vf.out_features == 1 and pf.bias is not None and vf.bias is not None
+                    and pf.weight.dtype == torch.float32 and vf.weight.dtype == torch.float32
+                    and not torch.is_autocast_enabled())
+
     def _vtrace_loss(self, obs, actions, behaviour_logits, rewards, dones, entropy_coeff, time_major):
         """forward pass + fused V-trace + loss terms for one flat batch (no parameter update)"""
         T = self.sample_batch_steps
         N = obs.shape[0]
         B = N // T
         m = self.model
-        if (self.fused_loss and self.fused_heads and time_major and T <= 64 and obs.is_cuda and hasattr(m, '_trunk')
-                and isinstance(getattr(m, 'policy_fc', None), torch.nn.Linear)
-                and isinstance(getattr(m, 'value_fc', None), torch.nn.Linear) and m.policy_fc.in_features == 256
-                and m.policy_fc.out_features in (4, 6)):
+        hidden = None
+        if self._can_fuse_heads(obs, time_major):
             hidden = self._heads_in_chunks(obs, True, trunk_only=True)
-            A = m.policy_fc.out_features
-            total, sums, vs, pg_adv = _FusedHeadsLossFn.apply(
-                hidden.reshape(T, B, 256), m.policy_fc.weight, m.policy_fc.bias, m.value_fc.weight, m.value_fc.bias,
-                behaviour_logits.reshape(T, B, A), actions.reshape(T, B), rewards.reshape(T, B), dones.reshape(T, B),
-                (self.gamma, self.clip_rho_threshold, self.clip_pg_rho_threshold, self.vf_loss_coeff,
-                 float(entropy_coeff)))
-            return _KernelVTraceLoss(total, sums, vs, pg_adv), (sums[3] / N).float()
-        target_logits, values = self._heads_in_chunks(obs, time_major)
+            if hidden.dtype == torch.float32:
+                A = m.policy_fc.out_features
+                try:
+                    total, sums, vs, pg_adv = _FusedHeadsLossFn.apply(
+                        hidden.reshape(T, B, 256), m.policy_fc.weight, m.policy_fc.bias, m.value_fc.weight,
+                        m.value_fc.bias, behaviour_logits.reshape(T, B, A), actions.reshape(T, B), rewards.reshape(T, B),
+                        dones.reshape(T, B), (self.gamma, self.clip_rho_threshold, self.clip_pg_rho_threshold,
+                                              self.vf_loss_coeff, float(entropy_coeff)))
+                    return _KernelVTraceLoss(total, sums, vs, pg_adv), (sums[3] / N).float()
+                except NotImplementedError:  # no instantiation for this shape: heads by the framework, below
+                    pass
+        if hidden is not None:  # the fused path declined: the framework's heads on the trunk output we already have
+            target_logits, values = m.policy_fc(hidden), m.value_fc(hidden).squeeze(1)
+        else:
+            target_logits, values = self._heads_in_chunks(obs, time_major)
         A = target_logits.shape[-1]
         if self.fused_loss and T <= 256 and A in (2, 3, 4, 6, 9, 18):
             # log-softmax gather, entropy, KL, V-trace, the three sums AND their gradient: one kernel
@@ -250,8 +267,8 @@ class IMPALA(Algorithm):
     def _apply_gradients(self, learning_rate):
         if self.grad_hook is not None:
             self.grad_hook(self.model)  # e.g. RCCL all-reduce (sum) of the flattened gradient
-        for g in self.optimizer.param_groups:
-            g['lr'] = learning_rate
+        from .graphed import set_lr
+        set_lr(self.optimizer, learning_rate)  # a device scalar once a GraphedLearn made the optimizer capturable
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.grad_clip_norm)
         self.optimizer.step()
 

@@ -353,10 +353,10 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
 __global__ __launch_bounds__(256) void conv12_bwd_reduce_kernel(const float* __restrict__ partial, int n_parts,
                                                                 float* __restrict__ dw1, float* __restrict__ db1,
                                                                 float* __restrict__ dw2, float* __restrict__ db2) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= kBwdPartial) return;
-  float s = 0.f;
-  for (int g = 0; g < n_parts; ++g) s += partial[(size_t)g * kBwdPartial + j];
+  __shared__ float red[256];
+  const int j = blockIdx.x * 16 + (threadIdx.x & 15);
+  const float s = partial_sum16(partial, n_parts, kBwdPartial, j, red);
+  if (threadIdx.x >= 16 || j >= kBwdPartial) return;
   if (j < kBwdDB1) dw1[j] = s;
   else if (j < kBwdDW2) db1[j - kBwdDB1] = s;
   else if (j < kBwdDB2) dw2[j - kBwdDW2] = s;
@@ -929,11 +929,10 @@ __global__ __launch_bounds__(256) void conv1_84_bwd_kernel(
 // out[j] = sum over parts of partial[part][j], fixed order (deterministic)
 __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ partial, int n_parts, int len,
                                                           float* __restrict__ out) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= len) return;
-  float s = 0.f;
-  for (int g = 0; g < n_parts; ++g) s += partial[(size_t)g * len + j];
-  out[j] = s;
+  __shared__ float red[256];
+  const int j = blockIdx.x * 16 + (threadIdx.x & 15);
+  const float s = partial_sum16(partial, n_parts, len, j, red);
+  if (threadIdx.x < 16 && j < len) out[j] = s;
 }
 
 }  // namespace parlhip
@@ -1013,7 +1012,7 @@ PARLHIP_EXPORT int parlhip_atari42_conv12_bwd_f32(const uint8_t* obs, const floa
   conv12_bwd_u8_mfma_kernel<<<grid, 256, lds_bytes, s>>>(obs, w1, b1, w2, a2, dy, workspace, n_obs);
   int rc = check_launch();
   if (rc) return rc;
-  conv12_bwd_reduce_kernel<<<(kBwdPartial + 255) / 256, 256, 0, s>>>(workspace, grid, dw1, db1, dw2, db2);
+  conv12_bwd_reduce_kernel<<<(kBwdPartial + 15) / 16, 256, 0, s>>>(workspace, grid, dw1, db1, dw2, db2);
   return check_launch();
 }
 
@@ -1062,7 +1061,7 @@ PARLHIP_EXPORT int parlhip_atari84_conv3_bwd_f32(const float* a2, const float* a
   conv3_84_bwd_kernel<<<grid, 256, lds_bytes, s>>>(a2, a3, dy3, wt3b, dz2, workspace, n_obs);
   int rc = check_launch();
   if (rc) return rc;
-  partial_sum_kernel<<<(kPart3 + 255) / 256, 256, 0, s>>>(workspace, grid, kPart3, dw3_db3);
+  partial_sum_kernel<<<(kPart3 + 15) / 16, 256, 0, s>>>(workspace, grid, kPart3, dw3_db3);
   return check_launch();
 }
 
@@ -1088,7 +1087,7 @@ PARLHIP_EXPORT int parlhip_atari84_conv2_bwd_f32(const float* a1, const float* d
   conv2_84_bwd_kernel<<<grid, 256, lds_bytes, s>>>(a1, dz2, wt2b, dz1, workspace, n_obs);
   int rc = check_launch();
   if (rc) return rc;
-  partial_sum_kernel<<<(kPart2 + 255) / 256, 256, 0, s>>>(workspace, grid, kPart2, dw2_db2);
+  partial_sum_kernel<<<(kPart2 + 15) / 16, 256, 0, s>>>(workspace, grid, kPart2, dw2_db2);
   return check_launch();
 }
 
@@ -1114,6 +1113,6 @@ PARLHIP_EXPORT int parlhip_atari84_conv1_bwd_f32(const uint8_t* obs, const float
   conv1_84_bwd_kernel<<<grid, 256, lds_bytes, s>>>(obs, dz1, workspace, n_obs);
   int rc = check_launch();
   if (rc) return rc;
-  partial_sum_kernel<<<(kPart1 + 255) / 256, 256, 0, s>>>(workspace, grid, kPart1, dw1_db1);
+  partial_sum_kernel<<<(kPart1 + 15) / 16, 256, 0, s>>>(workspace, grid, kPart1, dw1_db1);
   return check_launch();
 }

@@ -1340,26 +1340,10 @@ __global__ __launch_bounds__(256, 2) void impala_heads_loss_kernel(
 // out[k] = sum over workgroup partials, fixed order: 16 outputs x 16 slices of the partials per block
 __global__ __launch_bounds__(256) void heads_partial_sum_kernel(const float* __restrict__ wpart, int nblk, int n,
                                                                 float* __restrict__ out) {
-  __shared__ float red[16][16];
-  const int kk = threadIdx.x & 15, qs = threadIdx.x >> 4;
-  const int k = blockIdx.x * 16 + kk;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (k < n) {
-    int q = qs;
-    for (; q + 48 < nblk; q += 64) {
-      s0 += wpart[(size_t)q * n + k]; s1 += wpart[(size_t)(q + 16) * n + k];
-      s2 += wpart[(size_t)(q + 32) * n + k]; s3 += wpart[(size_t)(q + 48) * n + k];
-    }
-    for (; q < nblk; q += 16) s0 += wpart[(size_t)q * n + k];
-  }
-  red[qs][kk] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (qs == 0 && k < n) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t += red[i][kk];
-    out[k] = t;
-  }
+  __shared__ float red[256];
+  const int k = blockIdx.x * 16 + (threadIdx.x & 15);
+  const float t = partial_sum16(wpart, nblk, n, k, red);
+  if (threadIdx.x < 16 && k < n) out[k] = t;
 }
 
 PARLHIP_EXPORT size_t parlhip_impala_heads_loss_workspace_bytes(int B, int A) {

@@ -327,6 +327,14 @@ class DeviceA2CRollout(object):
         self.ep_stats.copy_(d['ep_stats'].to(self.ep_stats.device))
 
 
+class _GraphedLoss(object):
+    """the VTraceLoss attributes of the last graphed update (views of GraphedLearn.out, float64 on the device)"""
+
+    def __init__(self, out):
+        self.total_loss, self.pi_loss, self.vf_loss, self.entropy = out[0], out[1], out[2], out[3]
+        self.vtrace_returns = None
+
+
 class AsyncActorLearner(object):
     """IMPALA's actor / learner decoupling (examples/IMPALA/train.py:155-194: sample threads fill a
     queue while the learn thread drains it; actors act with parameters that lag the learner by up
@@ -346,8 +354,13 @@ class AsyncActorLearner(object):
     the role of the reference actor's `set_weights` (actor.py:103-104): it is refreshed from the
     learner before every rollout, so the behaviour policy lags the learner by exactly one update."""
 
-    def __init__(self, alg, envs, sample_batch_steps, seed=0, elastic=False):
-        """elastic: ElasticDeviceRollout (one env group; the env's horizon is the launch bound of a batch)"""
+    def __init__(self, alg, envs, sample_batch_steps, seed=0, elastic=False, train_batch_size=None):
+        """elastic: ElasticDeviceRollout (one env group; the env's horizon is the launch bound of a batch).
+        train_batch_size: the reference's learner batch in ROWS (impala_config.py:31: 1000 = 20 sequences of
+        T = 50; the learner concatenates actor batches until it holds at least that many, train.py:98).  None:
+        one update per step() on the whole T*E rollout.  Otherwise step() runs E // (train_batch_size // T)
+        updates, each on the next `train_batch_size // T` sequences of the rollout (the last one takes the
+        remainder as well), every update one hipGraph replay (algorithms.impala.graphed.GraphedLearn)."""
         import copy
         self.alg = alg
         self.envs = list(envs) if isinstance(envs, (list, tuple)) else [envs]
@@ -379,6 +392,15 @@ class AsyncActorLearner(object):
         self.gather_small = False
         self.gathered = None
         self.step_done = torch.cuda.Event()  # recorded after every update on the learner stream
+        self.sub_batches = None
+        self.updates = 0  # parameter updates enqueued so far
+        if train_batch_size:
+            if len(self.envs) != 1:
+                raise ValueError('train_batch_size takes one env group')
+            E = self.env.envs_num
+            seqs = max(1, int(train_batch_size) // self.T)
+            n = max(1, E // seqs)
+            self.sub_batches = [(i * seqs, seqs if i < n - 1 else E - i * seqs) for i in range(n)]
         self._src = [p for p in alg.model.parameters()] + [b for b in alg.model.buffers()]
         self._dst = [p for p in self.actor_model.parameters()] + [b for b in self.actor_model.buffers()]
         cur = torch.cuda.current_stream(dev)
@@ -388,6 +410,45 @@ class AsyncActorLearner(object):
         self.weights_ready.record(cur)
         for e in self.batch_free:
             e.record(cur)
+        self.graphed = {}
+        if self.sub_batches:
+            from .algorithms.impala.graphed import GraphedLearn
+            pool = None
+            with torch.cuda.stream(self.learn_stream):
+                for _, nb in self.sub_batches:
+                    if nb not in self.graphed:
+                        self.graphed[nb] = GraphedLearn(alg, nb, (4, self.env.dim, self.env.dim), self.env.act_dim,
+                                                        pool=pool)
+                        pool = self.graphed[nb].pool
+            self.learn_stream.synchronize()
+
+    def _learn_sub_batches(self, batch, learning_rate, entropy_coeff):
+        """the rollout as E // seqs updates of the reference's train_batch_size (on the learner stream);
+        learning_rate / entropy_coeff: floats, or schedulers whose step() is called once per update as the
+        reference's learner does (train.py:111-112)"""
+        E = self.env.envs_num
+        gl = None
+        for b0, nb in self.sub_batches:
+            gl = self.graphed[nb]
+            gl.load(batch, b0, E)
+            lr = learning_rate.step() if hasattr(learning_rate, 'step') else learning_rate
+            ec = entropy_coeff.step() if hasattr(entropy_coeff, 'step') else entropy_coeff
+            gl.replay(lr, ec)
+            self.updates += 1
+        return _GraphedLoss(gl.out), gl.out[4]
+
+    def pop_learn_stats(self):
+        """train_batch_size mode: means of (total_loss, pi_loss, vf_loss, entropy, kl) over the updates since the
+        last call and their number (one D2H per log interval; the reference's agent.learn returns them per
+        update, atari_agent.py:40-41).  Waits for the learner stream."""
+        self.learn_stream.synchronize()
+        tot, n = [0.0] * 5, 0
+        for gl in self.graphed.values():
+            m, k = gl.pop_stats()
+            if k:
+                tot = [a + b * k for a, b in zip(tot, m)]
+                n += k
+        return ([x / n for x in tot] if n else None), n
 
     def _snapshot(self):
         """actor parameters <- learner parameters (the reference actor's set_weights)"""
@@ -446,11 +507,15 @@ class AsyncActorLearner(object):
             ls.wait_event(self.snapshot_done)
             for g in range(len(batches)):
                 ls.wait_event(self.batch_ready[g][k])
-            if len(batches) == 1:
+            if self.sub_batches:
+                out = self._learn_sub_batches(batches[0], learning_rate, entropy_coeff)
+            elif len(batches) == 1:
                 b = batches[0]
+                self.updates += 1
                 out = self.alg.learn(b['obs'], b['actions'], b['behaviour_logits'], b['rewards'], b['dones'],
                                      learning_rate, entropy_coeff, time_major=True)
             else:
+                self.updates += 1
                 out = self.alg.learn_batches(batches, learning_rate, entropy_coeff, time_major=True)
             if self.gather_small:  # per-step scalars of the batch just learned, for global statistics
                 from . import dist as pdist

@@ -1,0 +1,105 @@
+"""IMPALA.learn at the reference's learner batch (train_batch_size = 1000 rows, impala_config.py:31) as a
+hipGraph replay (parl_amd.algorithms.impala.graphed.GraphedLearn): the same update as the eager call."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(dev, T, B, A, dim, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    N = T * B
+    return {'obs': torch.randint(0, 256, (N, 4, dim, dim), dtype=torch.uint8, device=dev, generator=g),
+            'actions': torch.randint(0, A, (N, ), device=dev, generator=g),
+            'behaviour_logits': torch.randn((N, A), device=dev, generator=g),
+            'rewards': torch.randint(-1, 2, (N, ), device=dev, generator=g).float(),
+            'dones': torch.rand(N, device=dev, generator=g) < 0.02}
+
+
+@pytest.mark.parametrize('dim,B', [(42, 20), (42, 24), (84, 4)])
+def test_graphed_learn_equals_eager_learn(dev, dim, B):
+    """three updates with a changing learning rate (the piecewise schedule is a device scalar, no re-capture) on
+    three different batches: same losses, same parameters as IMPALA.learn(time_major=True) issued eagerly; the
+    warm-up iterations of the capture leave parameters and optimizer state untouched"""
+    import parl_amd as parl
+    from parl_amd.algorithms.impala.graphed import GraphedLearn
+    from parl_amd.models import AtariModel42, AtariModel84
+    torch.manual_seed(3)
+    T, A = 50, 6
+    base = (AtariModel42 if dim == 42 else AtariModel84)(A).to(dev)
+    with torch.no_grad():
+        base.policy_fc.weight.mul_(0.05)
+        base.value_fc.weight.mul_(0.05)
+    mk = lambda m: parl.algorithms.IMPALA(m, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,  # noqa: E731
+                                          clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+    m_e, m_g = copy.deepcopy(base), copy.deepcopy(base)
+    alg_e, alg_g = mk(m_e), mk(m_g)
+    gl = GraphedLearn(alg_g, B, (4, dim, dim), A, entropy_coeff=-0.01)
+    for a, b in zip(m_g.parameters(), base.parameters()):
+        assert torch.equal(a, b), 'capture changed the parameters'
+    E = B + 3  # the graph takes a [T, b0:b0+B] slice of a wider rollout
+    for i, lr in enumerate((1e-3, 1e-3, 5e-4)):
+        wide = _batch(dev, T, E, A, dim, 10 + i)
+        b0 = i
+        cut = lambda x: x.view((T, E) + tuple(x.shape[1:]))[:, b0:b0 + B].reshape((T * B, ) + tuple(x.shape[1:]))  # noqa: E731
+        loss, kl = alg_e.learn(cut(wide['obs']), cut(wide['actions']), cut(wide['behaviour_logits']),
+                               cut(wide['rewards']), cut(wide['dones']), lr, -0.01, time_major=True)
+        gl.load(wide, b0, E)
+        gl.replay(lr, -0.01)
+        want = np.array([float(loss.total_loss), float(loss.pi_loss), float(loss.vf_loss), float(loss.entropy),
+                         float(kl)])
+        got = gl.out.cpu().numpy()
+        # pi_loss is a sum of 1000 signed terms that nearly cancels: absolute tolerance on the terms' scale
+        np.testing.assert_allclose(got[:5], want, rtol=1e-5, atol=1e-5 * float(np.abs(want).max()))
+        assert got[5] == 1.0
+        for (n, a), b in zip(m_g.named_parameters(), m_e.parameters()):
+            # same kernels, same gradients; fused capturable Adam vs the foreach implementation differ by rounding,
+            # which Adam's normalised step turns into a small fraction of lr = 1e-3 per update (measured: 2.5e-6)
+            assert float((a - b).abs().max()) <= 2e-5 + 1e-5 * float(b.abs().max()), (i, n)
+    means, n = gl.pop_stats()
+    assert n == 3 and len(means) == 5 and np.isfinite(means).all()
+    assert gl.pop_stats()[1] == 0
+
+
+def test_async_pipeline_with_reference_train_batch(dev):
+    """AsyncActorLearner(train_batch_size=...): a 16-env rollout consumed as 16 // 3 = 5 updates (3, 3, 3, 3, 4
+    sequences), schedulers stepped once per update; parameters equal the same sub-batches learned eagerly"""
+    import parl_amd as parl
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel42
+    from parl_amd.rollout import AsyncActorLearner
+    from parl_amd.utils import PiecewiseScheduler
+    torch.manual_seed(5)
+    T, E = 8, 16
+    env = DeviceVectorEnv('PongNoFrameskip-v4', E, dim=42, horizon=T, seed=3, device=dev)
+    model = AtariModel42(env.act_dim).to(dev)
+    with torch.no_grad():
+        model.policy_fc.weight.mul_(0.05)
+        model.value_fc.weight.mul_(0.05)
+    twin = copy.deepcopy(model)
+    mk = lambda m: parl.algorithms.IMPALA(m, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,  # noqa: E731
+                                          clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+    alg, alg_t = mk(model), mk(twin)
+    pipe = AsyncActorLearner(alg, [env], T, seed=9, train_batch_size=3 * T)
+    assert pipe.sub_batches == [(0, 3), (3, 3), (6, 3), (9, 3), (12, 4)]
+    lr_s = PiecewiseScheduler([(0, 1e-3), (3, 5e-4)])
+    pipe.prime()
+    pipe.actor_stream.synchronize()
+    batch = {k: v.clone() for k, v in pipe.pending[0][0].items()}
+    torch.cuda.synchronize()
+    loss, kl = pipe.step(lr_s, -0.01)
+    pipe.synchronize()
+    assert pipe.updates == 5 and np.isfinite(float(loss.total_loss))
+    lr_t = PiecewiseScheduler([(0, 1e-3), (3, 5e-4)])
+    for b0, nb in pipe.sub_batches:
+        cut = lambda x: x.view((T, E) + tuple(x.shape[1:]))[:, b0:b0 + nb].reshape((T * nb, ) + tuple(x.shape[1:]))  # noqa: E731
+        alg_t.learn(cut(batch['obs']), cut(batch['actions']), cut(batch['behaviour_logits']), cut(batch['rewards']),
+                    cut(batch['dones']), lr_t.step(), -0.01, time_major=True)
+    for (n, a), b in zip(model.named_parameters(), twin.parameters()):
+        assert float((a - b).abs().max()) <= 5e-5 + 2e-5 * float(b.abs().max()), n
+    means, n = pipe.pop_learn_stats()
+    assert n == 5 and np.isfinite(means).all()
+    env.check_faults()
