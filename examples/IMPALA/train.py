@@ -1,7 +1,12 @@
 """IMPALA learner — the structure of examples/IMPALA/train.py:34-258 (Learner with a sample
 queue, a learn thread, actor threads, schedulers, WindowStat metrics) on the device path.
 
-    python examples/IMPALA/train.py [--updates N] [--env-num E] [--minutes M]
+    python examples/IMPALA/train.py [--env-num E] [--minutes M] [--train-batch-size 1000] [--pipeline]
+
+--pipeline: the same learner hyper-parameters on parl_amd.rollout.AsyncActorLearner — actor and learner
+on two HIP streams of one host thread, every `train_batch_size`-row update one hipGraph replay
+(train_batch_size 1000 = the reference's, impala_config.py:31) — instead of the thread-per-actor
+structure below.
 
 The reference file imports paddle (`paddle.io.DataLoader.from_generator`, train.py:129-130); this
 twin feeds `agent.learn` directly from the queue."""
@@ -170,6 +175,58 @@ class Learner(object):
         return metric
 
 
+class PipelineLearner(object):
+    """the Learner's hyper-parameters, schedulers and metrics on AsyncActorLearner(train_batch_size=...)"""
+
+    def __init__(self, config):
+        from parl_amd.env import DeviceVectorEnv
+        from parl_amd.rollout import AsyncActorLearner
+        self.config = config
+        dev = torch.device('cuda')
+        E, T = config['env_num'] * config['actor_num'], config['sample_batch_steps']
+        elastic = config.get('elastic_launches', 'Breakout' in config['env_name'])
+        self.env = DeviceVectorEnv(config['env_name'], E, dim=config['env_dim'], horizon=4 * T + 32 if elastic else T,
+                                   seed=config.get('seed', 0), device=dev)
+        model = AtariModel(self.env.act_dim).to(dev)
+        self.alg = parl.algorithms.IMPALA(
+            model, sample_batch_steps=T, gamma=config['gamma'], vf_loss_coeff=config['vf_loss_coeff'],
+            clip_rho_threshold=config['clip_rho_threshold'], clip_pg_rho_threshold=config['clip_pg_rho_threshold'])
+        self.pipe = AsyncActorLearner(self.alg, [self.env], T, seed=config.get('seed', 0) + 1000, elastic=elastic,
+                                      train_batch_size=config['train_batch_size'])
+        self.lr_scheduler = PiecewiseScheduler(config['lr_scheduler'])
+        self.entropy_coeff_scheduler = PiecewiseScheduler(config['entropy_coeff_scheduler'])
+        self.sample_total_steps = 0
+        self.start_time = time.time()
+        self.T, self.E = T, E
+        self.pipe.prime()
+
+    def step(self):
+        self.pipe.step(self.lr_scheduler, self.entropy_coeff_scheduler)
+        self.sample_total_steps += self.T * self.E
+
+    def log_metrics(self):
+        stats, n_upd = self.pipe.pop_learn_stats()
+        n, mean_r, mean_l = self.pipe.pop_episode_stats()
+        elapsed = time.time() - self.start_time
+        metric = {
+            'sample_steps': self.sample_total_steps,
+            'mean_episode_rewards': mean_r, 'mean_episode_steps': mean_l, 'episodes': int(n),
+            'learn_steps': self.pipe.updates,
+            'elapsed_time_s': int(elapsed),
+            'env_frames_per_s': 4 * self.sample_total_steps / max(elapsed, 1e-9),
+            'learner_updates_per_s': self.pipe.updates / max(elapsed, 1e-9),
+            'lr': self.lr_scheduler.cur_value, 'entropy_coeff': self.entropy_coeff_scheduler.cur_value,
+        }
+        if stats:
+            metric.update(dict(zip(('total_loss', 'pi_loss', 'vf_loss', 'entropy', 'kl'), stats)))
+        logger.info(metric)
+        return metric
+
+    def shutdown(self):
+        self.pipe.synchronize()
+        self.env.check_faults()
+
+
 if __name__ == '__main__':
     from impala_config import config
     ap = argparse.ArgumentParser()
@@ -178,6 +235,8 @@ if __name__ == '__main__':
     ap.add_argument('--env-name', default=None, help='PongNoFrameskip-v4 (config default) or BreakoutNoFrameskip-v4')
     ap.add_argument('--train-batch-size', type=int, default=None)
     ap.add_argument('--log-interval', type=float, default=None)
+    ap.add_argument('--pipeline', action='store_true',
+                    help='AsyncActorLearner with hipGraph updates of train_batch_size rows (see module docstring)')
     args = ap.parse_args()
     if args.env_name:
         config['env_name'] = args.env_name
@@ -188,6 +247,17 @@ if __name__ == '__main__':
         config['train_batch_size'] = args.train_batch_size
     if args.log_interval:
         config['log_metrics_interval_s'] = args.log_interval
+    if args.pipeline:
+        learner = PipelineLearner(config)
+        t0 = t_log = time.time()
+        while args.minutes is None or time.time() - t0 < args.minutes * 60:
+            learner.step()
+            if time.time() - t_log >= config['log_metrics_interval_s']:
+                learner.log_metrics()
+                t_log = time.time()
+        learner.shutdown()
+        sys.stdout.flush()
+        os._exit(0)
     learner = Learner(config)
     assert config['log_metrics_interval_s'] > 0
     t0 = time.time()

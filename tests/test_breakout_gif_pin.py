@@ -25,8 +25,24 @@ tolerances, while GEOMETRY is compared exactly):
   left (Stella 2.x delays them by one pixel); both were fixed in the commit that added it;
 * ball: 2 x 4 pixels.
 
+* the ALE game layer (oracle/atari_oracle.c ale_rom_step: reward / lives / terminal decoded from
+  cartridge RAM, what EpisodicLifeEnv and the reward stream depend on — parl/env/atari_wrappers.py:
+  186-211, benchmark/fluid/DQN_variant/atari.py:134-165): the recording shows the end of one game
+  (184, 191) and then a WHOLE new game from "000 5 1" to 331 with the lives digit going 5 -> 1.
+  For every frame the score the picture shows is written as BCD into RAM 76 / 77 and the lives into
+  RAM 57 — the bytes the ALE layer decodes — with the five glyph pointers poisoned; the cartridge
+  itself turns those bytes into glyph pointers and draws them: the five digit slots must equal the
+  recording pixel for pixel, and the oracle's ALE layer must report exactly that score delta as
+  the reward, that lives count, and terminal only at lives 0.  So the decode reads the same RAM
+  cells, nibbles and digit order the cartridge displays (and the recording shows);
+* the reward stream against the bricks: between consecutive frames of the recording
+  the score grows by exactly the row values (1, 1, 4, 4, 7, 7 from the bottom row) of the brick
+  cells that vanished from the picture.
+
 What this does not pin: frame-by-frame dynamics (the GIF keeps roughly every 30th ALE frame,
-consecutive GIF frames are not consecutive emulator frames), sound, the other cartridge.
+consecutive GIF frames are not consecutive emulator frames), sound.  PONG HAS NO REFERENCE-HELD
+GROUND TRUTH AT ALL: the reference tree holds no picture, recording or known-answer vector of
+the Pong cartridge — only its ROM bytes.
 """
 import ctypes
 import os
@@ -235,3 +251,93 @@ def test_ball_is_two_by_four(gif):
         ale.act(1 if i < 8 else 0)
     bb = _ball_box(ale.fb != 0)
     assert (bb[3] - bb[2] + 1, bb[1] - bb[0] + 1) == (2, 4)
+
+
+def _digits(gif, digit_templates):
+    """per frame the five digits the recording shows (exact glyph matches only)"""
+    out = []
+    for f in range(gif.shape[0]):
+        lit = gif[f].astype(np.float32).sum(-1) > BRIGHT
+        row = []
+        for a, x0, x1 in SLOTS:
+            errs = [int((digit_templates[(a, d)] != lit[0:17, x0:x1 + 1]).sum()) for d in range(10)]
+            d = int(np.argmin(errs))
+            assert errs[d] == 0
+            row.append(d)
+        out.append(row)
+    return np.array(out)
+
+
+def test_ale_score_lives_decode_is_what_the_cartridge_displays(gif, surgeon, digit_templates):
+    digs = _digits(gif, digit_templates)
+    score = digs[:, 0] * 100 + digs[:, 1] * 10 + digs[:, 2]
+    lives = digs[:, 3]
+    # the recording: the tail of one game, then a whole game from 0 with 5 lives
+    assert list(score[:3]) == [184, 191, 0] and lives[2] == 5 and score[-1] == 331 and lives[-1] == 1
+    assert (np.diff(score[2:]) >= 0).all() and (np.diff(lives[2:]) <= 0).all() and set(lives) == {1, 2, 3, 4, 5}
+    assert (digs[:, 4] == 1).all()  # player number
+    L = surgeon.L
+    prev = None
+    for f in range(gif.shape[0]):
+        lit = gif[f].astype(np.float32).sum(-1) > BRIGHT
+        ram = surgeon.base.copy()
+        ram[:36] = brick_ram_from_picture(lit)
+        ram[77] = ((score[f] // 10) % 10) << 4 | (score[f] % 10)   # ALE Breakout: ones / tens nibbles of RAM 77,
+        ram[76] = (score[f] // 100) % 10                            # hundreds in the low nibble of RAM 76
+        ram[57] = lives[f]                                          # lives in RAM 57
+        for a, _, _ in SLOTS:
+            ram[a] = 5 * 8 if a != 88 else ram[a]                   # poison the glyph pointers (an "8" everywhere)
+        L.oracle_ale_set_ram(surgeon.ale.h, ram.ctypes.data_as(ctypes.c_void_p))
+        reward = surgeon.ale.act(0)
+        after = surgeon.ale.ram()
+        # the cartridge derived the glyph pointers from the bytes the ALE layer decodes ...
+        assert [int(after[a]) // 5 for a, _, _ in SLOTS[:4]] == list(digs[f, :4]), f
+        surgeon.ale.act(0)
+        olit = surgeon.ale.fb != 0
+        # ... and draws the recording's digits with them, pixel for pixel
+        for a, x0, x1 in SLOTS:
+            assert np.array_equal(olit[0:17, x0:x1 + 1], lit[0:17, x0:x1 + 1]), (f, a)
+        # and the ALE layer reads the same bytes the same way: reward = score delta, lives, terminal
+        if prev is not None:
+            assert reward == score[f] - prev, (f, reward, score[f], prev)
+        prev = score[f]
+        assert L.oracle_ale_lives(surgeon.ale.h) == lives[f]
+        assert L.oracle_ale_terminal(surgeon.ale.h) == 0
+    # game over is lives == 0 once the game has started (5 lives seen)
+    ram = surgeon.base.copy()
+    ram[57] = 0
+    L.oracle_ale_set_ram(surgeon.ale.h, ram.ctypes.data_as(ctypes.c_void_p))
+    surgeon.ale.act(0)
+    assert L.oracle_ale_terminal(surgeon.ale.h) == 1 and L.oracle_ale_lives(surgeon.ale.h) == 0
+
+
+ROW_VALUE = [1, 1, 4, 4, 7, 7]  # bottom row first (Breakout's scoring); a brick is TWO playfield cells (8 pixels) wide
+
+
+def test_score_grows_by_the_value_of_the_vanished_bricks(gif, digit_templates):
+    digs = _digits(gif, digit_templates)
+    score = digs[:, 0] * 100 + digs[:, 1] * 10 + digs[:, 2]
+
+    def cells(f):
+        lit = gif[f].astype(np.float32).sum(-1) > BRIGHT
+        return np.array([[lit[87 - 6 * r:93 - 6 * r, 8 + 4 * k:12 + 4 * k].mean() > 0.5 for k in range(36)]
+                         for r in range(6)])
+
+    start = 2  # the new game ("000 5 1"): a full wall
+    c0 = cells(start)
+    assert c0.all()
+    lagging = []
+    prev = c0
+    for f in range(start + 1, gif.shape[0]):
+        c = cells(f)
+        assert not (c & ~prev).any(), 'frame %d: a brick came back' % f
+        want = sum(ROW_VALUE[r] * int((c0[r] & ~c[r]).sum()) for r in range(6)) / 2
+        lag = want - (score[f] - score[start])
+        # a brick disappears from the picture in the frame of the hit; the cartridge adds its value to the score
+        # a moment later: a recorded frame may fall in between (score short by exactly that ONE brick)
+        assert lag == 0 or lag in ROW_VALUE, (f, score[f], want)
+        if lag:
+            lagging.append(f)
+        prev = prev & c
+    assert len(lagging) <= 5 and all(b - a > 1 for a, b in zip(lagging, lagging[1:])), lagging
+    assert gif.shape[0] - 1 not in lagging and score[-1] - score[start] == 331
