@@ -209,6 +209,41 @@ def extra_legs(dev):
                             'and learner on the MFMA kernels (conv1_84 / conv23_84 forward, three backward kernels)',
                 'env_frames_per_s': K * T * E * 4 / dt, 'updates_per_s': K / dt, 'ms_per_step': dt / K * 1e3, 'steps': K}
 
+    # ---- configs[2] at the REFERENCE's learner batch: train_batch_size = 1000 rows per update ----
+    def impala_ref_batch():
+        E, T, K = 1024, 50, 5
+        env = DeviceVectorEnv('PongNoFrameskip-v4', E, dim=42, horizon=T, seed=10, device=dev)
+        model = AtariModel42(env.act_dim).to(dev)
+        alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
+                                     clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+        pipe = AsyncActorLearner(alg, [env], T, seed=6, train_batch_size=1000)
+        lr_s = parl.utils.PiecewiseScheduler([(0, 0.001), (20000, 0.0005), (40000, 0.0001)])
+        ent_s = parl.utils.PiecewiseScheduler([(0, -0.01)])
+        pipe.prime()
+        pipe.step(lr_s, ent_s)
+        pipe.synchronize()
+        u0, t0 = pipe.updates, time.time()
+        for _ in range(K):
+            loss, kl = pipe.step(lr_s, ent_s)
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        assert np.isfinite(float(loss.total_loss))
+        stats, n = pipe.pop_learn_stats()
+        env.check_faults()
+        # one update alone on the device (the graph replay, inputs loaded): what the learner costs the GPU
+        gl = pipe.graphed[pipe.sub_batches[0][1]]
+        rep = _event_time(lambda: gl.replay(1e-4), iters=30)
+        return {'workload': 'BASELINE configs[2] with the reference\'s LEARNER batch: PongNoFrameskip-v4 IMPALA, 1024 actors, '
+                            'T=50, 42x42, actor/learner overlapped; every 51,200-row rollout is consumed as %d updates of '
+                            'train_batch_size = 1000 rows (20 sequences; the last one takes the remaining %d: impala_config.py:31, '
+                            'train.py:98), each update ONE hipGraph replay (trunk fwd, heads + V-trace loss kernel, bwd, '
+                            'global-norm clip, Adam; lr a device scalar stepped per update)' %
+                            (len(pipe.sub_batches), pipe.sub_batches[-1][1]),
+                'env_frames_per_s': K * T * E * 4 / dt, 'updates_per_s': (pipe.updates - u0) / dt,
+                'updates_per_rollout': len(pipe.sub_batches), 'rows_per_update': 1000, 'ms_per_step': dt / K * 1e3,
+                'steps': K, 'update_alone_ms': rep * 1e3, 'mean_losses_total_pi_vf_entropy_kl': stats}
+
     # ---- configs[3] per GPU: Breakout IMPALA, 1024 of the 8192 actors, A=4 ----
     def breakout_c4():
         E, T, K = 1024, 50, 3
@@ -258,6 +293,7 @@ def extra_legs(dev):
                                'traffic_key': 'profiles/r01e_scan_hbm_traffic.json:gae_T2048_B4096_f32'},
                 'adv_normalize_kernel': {'us': a * 1e6, 'bytes': aby, 'GBps': aby / a / 1e9}}
 
+    guarded('impala_ref_batch', impala_ref_batch)
     guarded('a2c_c2', a2c_c2)
     guarded('impala_84', impala_84)
     guarded('breakout_c4_per_gpu', breakout_c4)
