@@ -50,18 +50,27 @@ class Agent(object):
         dirname = os.sep.join(save_path.split(os.sep)[:-1])
         if dirname != '' and not os.path.exists(dirname):
             os.makedirs(dirname)
-        torch.save(model.state_dict(), save_path)
         extra = getattr(self, '_stateful', None)
+        # the attached objects' state first: their state_dict() drains the streams that write it (and the
+        # learner stream that writes the parameters), so the model saved next is not torn either
+        blob = {k: v.state_dict() for k, v in extra.items()} if extra else None
+        torch.save(model.state_dict(), save_path)
         if extra:
-            torch.save({k: v.state_dict() for k, v in extra.items()}, save_path + '.env')
+            torch.save(blob, save_path + '.env')
+        elif os.path.exists(save_path + '.env'):
+            os.remove(save_path + '.env')  # an older run's env state must not pair up with these weights
 
     def restore(self, save_path, model=None, map_location=None):
         if model is None:
             model = self.alg.model
         model.load_state_dict(torch.load(save_path, map_location=map_location))
         extra = getattr(self, '_stateful', None)
-        if extra and os.path.exists(save_path + '.env'):
-            blob = torch.load(save_path + '.env', map_location='cpu', weights_only=False)
+        if extra:
+            if not os.path.exists(save_path + '.env'):
+                raise FileNotFoundError('%s.env: env / sampler state is attached to this agent but the checkpoint '
+                                        'holds none (a model-only checkpoint would silently restart the envs)' % save_path)
+            # tensors, numbers, strings, lists, dicts only: no arbitrary unpickling
+            blob = torch.load(save_path + '.env', map_location='cpu', weights_only=True)
             for k, v in extra.items():
                 if k not in blob:
                     raise KeyError('%s.env holds no state for %r' % (save_path, k))

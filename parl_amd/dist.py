@@ -20,7 +20,7 @@ def init(backend=None, force=False):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    force = force or bool(os.environ.get('PARL_AMD_FORCE_DIST'))
+    force = force or os.environ.get('PARL_AMD_FORCE_DIST', '').strip().lower() in ('1', 'true', 'yes', 'on')
     if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             # PARL_AMD_DIST_BACKEND=gloo: test hook (e.g. two ranks sharing the one GPU of a test box)
@@ -95,15 +95,23 @@ class FlatGradAllReduce(object):
             self.flat.div_(world_size())
 
 
+_gather_bufs = {}
+
+
 def all_gather_small(tensors):
-    """All-gather a dict of small per-step tensors along a new leading rank dim."""
+    """All-gather a dict of small per-step tensors along a new leading rank dim.  The [world, ...] receive
+    buffers are allocated once per (key, shape, dtype, device) and reused: one call per learner update.
+    The result of a call is valid until the next call with the same keys."""
     w = world_size()
     if not active():
         return {k: v.unsqueeze(0) for k, v in tensors.items()}
     out = {}
     for k, v in tensors.items():
         v = v.contiguous()
-        buf = torch.empty((w, ) + tuple(v.shape), dtype=v.dtype, device=v.device)
+        key = (k, w, tuple(v.shape), v.dtype, v.device)
+        buf = _gather_bufs.get(key)
+        if buf is None:
+            buf = _gather_bufs[key] = torch.empty((w, ) + tuple(v.shape), dtype=v.dtype, device=v.device)
         if v.is_cuda and dist.get_backend() == 'nccl':
             dist.all_gather_into_tensor(buf, v)
         else:

@@ -46,27 +46,36 @@ class DeviceAtariEnv(object):
 
 
 class MonitorEnv(object):
-    """parl/env/atari_wrappers.py:44-100: per-env (unclipped return, length in raw frames) of the
-    episodes closed since the last call.  Filled by the VectorEnv that owns the env."""
+    """parl/env/atari_wrappers.py:44-100: per-env (unclipped return, length in raw frames) of the closed
+    episodes.  Same bookkeeping as the reference: CUMULATIVE `_episode_rewards` / `_episode_lengths` lists
+    plus the `_num_returned` cursor of next_episode_results() (:97-100), so get_episode_rewards() /
+    get_episode_lengths() keep returning every episode of the run.  Filled by the VectorEnv that owns the
+    env: the device reports an episode when it closes, so get_total_steps() counts the frames of closed
+    episodes (the reference also counts the running episode's frames, which live on the device here)."""
 
     def __init__(self):
-        self._episodes = []
+        self._episode_rewards = []
+        self._episode_lengths = []
+        self._num_episodes = 0
+        self._num_returned = 0
         self._total_steps = 0
 
     def _push(self, ret, length):
-        self._episodes.append((float(ret), int(length)))
+        self._episode_rewards.append(float(ret))
+        self._episode_lengths.append(int(length))
+        self._num_episodes += 1
         self._total_steps += int(length)
 
     def next_episode_results(self):
-        eps, self._episodes = self._episodes, []
-        for e in eps:
-            yield e
+        for i in range(self._num_returned, len(self._episode_rewards)):
+            yield (self._episode_rewards[i], self._episode_lengths[i])
+        self._num_returned = len(self._episode_rewards)
 
     def get_episode_rewards(self):
-        return [e[0] for e in self._episodes]
+        return self._episode_rewards
 
     def get_episode_lengths(self):
-        return [e[1] for e in self._episodes]
+        return self._episode_lengths
 
     def get_total_steps(self):
         return self._total_steps

@@ -248,7 +248,11 @@ class DeviceVectorEnv(object):
         the reset stream), the raw frame pair MaxAndSkip still needs, the frame-stack ring with its
         `since` counters and the ring position.  Host tensors; pairs with Agent.save
         (parl/core/torch/agent.py:100-124 saves the model only — a GPU-resident env has no other
-        way to survive a restart)."""
+        way to survive a restart).  The state may have been written on another HIP stream than the caller's
+        (AsyncActorLearner steps the envs on its actor streams, launches ahead of the host): the whole
+        device is synchronised first, so the snapshot is never torn."""
+        if self.device.type == 'cuda':
+            torch.cuda.synchronize(self.device)
         d = {k: getattr(self, k).detach().cpu().clone() for k in self._STATE_TENSORS}
         if self.link is not None:  # elastic ring layout
             d['link'], d['cur_slot'] = self.link.detach().cpu().clone(), self.cur_slot.detach().cpu().clone()
@@ -263,6 +267,8 @@ class DeviceVectorEnv(object):
             if m[k] != getattr(self, k):
                 raise ValueError('DeviceVectorEnv.load_state_dict: %s is %r here but %r in the checkpoint' %
                                  (k, getattr(self, k), m[k]))
+        if self.device.type == 'cuda':
+            torch.cuda.synchronize(self.device)  # nothing in flight on any stream may still read / write the state
         for k in self._STATE_TENSORS:
             getattr(self, k).copy_(d[k].to(self.device))
         if 'link' in d:
@@ -270,6 +276,8 @@ class DeviceVectorEnv(object):
             self.link.copy_(d['link'].to(self.device))
             self.cur_slot.copy_(d['cur_slot'].to(self.device))
         self.t = int(m['t'])
+        if self.device.type == 'cuda':
+            torch.cuda.synchronize(self.device)  # visible to every stream that steps the envs next
 
     def check_faults(self):
         """Raise if any env hit an emulator fault (undocumented opcode, ...). Synchronises."""

@@ -73,11 +73,9 @@ class DeviceRollout(object):
         env.accumulate_episode_stats(self.ep_stats)
         self.step_count += 1
 
-    @torch.no_grad()
-    def collect_end(self):
-        env = self.env
-        env.gather(self._slots, self._envs, self.obs)
-        E = env.envs_num
+    def _batch_view(self):
+        """the time-major batch over the selected trajectory buffer"""
+        E = self.env.envs_num
         return {
             'obs': self.obs,
             'actions': self.actions.reshape(self.T * E),
@@ -85,6 +83,11 @@ class DeviceRollout(object):
             'rewards': self.rewards.reshape(self.T * E),
             'dones': self.dones.reshape(self.T * E).bool(),
         }
+
+    @torch.no_grad()
+    def collect_end(self):
+        self.env.gather(self._slots, self._envs, self.obs)
+        return self._batch_view()
 
     def collect_steps(self, model):
         for t in range(self.T):
@@ -98,9 +101,20 @@ class DeviceRollout(object):
 
     def state_dict(self):
         """the sampler's own state: the Philox offset (one uniform per global step and env), the
-        buffer cursor, the episode statistics not yet popped.  The env is saved separately."""
+        buffer cursor, the episode statistics not yet popped.  The env is saved separately.  The device is
+        synchronised first: the statistics may be accumulated on another stream than the caller's."""
+        if self.ep_stats.is_cuda:
+            torch.cuda.synchronize(self.ep_stats.device)
         return {'step_count': self.step_count, 'started': self.started, 'cur': self._cur, 'seed': self.seed,
                 'ep_stats': self.ep_stats.detach().cpu().clone()}
+
+    def buffer_state(self, k):
+        """the trajectory slabs of buffer k (a collected batch somebody still has to learn from)"""
+        return {n: v.detach().cpu().clone() for n, v in self._bufs[k].items()}
+
+    def load_buffer_state(self, k, d):
+        for n, v in self._bufs[k].items():
+            v.copy_(d[n].to(v.device))
 
     def load_state_dict(self, d):
         if d['seed'] != self.seed:
@@ -138,7 +152,7 @@ class ElasticDeviceRollout(DeviceRollout):
         super(ElasticDeviceRollout, self).__init__(env, sample_batch_steps, seed=seed, n_buffers=n_buffers)
         E, A, dev, T = env.envs_num, env.act_dim, env.device, self.T
         self.S = env.slots  # ring slots == launches the rings remember
-        assert self.S >= 2 * T + 16, 'elastic rollout: env horizon must cover the launches of two batches'
+        assert self.S >= 3 * T + 16, 'elastic rollout: env horizon + 4 must cover the launches of three batches (see collect_steps)'
         i32 = dict(dtype=torch.int32, device=dev)
         self.actions_lm = torch.zeros((self.S, E), dtype=torch.int64, device=dev)
         self.logits_lm = torch.zeros((self.S, E, A), dtype=torch.float32, device=dev)
@@ -156,7 +170,7 @@ class ElasticDeviceRollout(DeviceRollout):
         self.launch = 0    # launches since the reset of the run
         self.batch = 0     # batches closed
         self.launches = 0  # launches enqueued by the last collect_steps()
-        self._era = [0, 0]  # launch at which the collection of the last two batches began
+        self._era = [0, 0, 0]  # launch at which the collection of the last three batches began
 
     @torch.no_grad()
     def collect_begin(self):
@@ -193,13 +207,19 @@ class ElasticDeviceRollout(DeviceRollout):
         E, par = self.env.envs_num, self.batch & 1
         st = torch.cuda.current_stream(self.env.device)
         first = self.launch
-        self._era = [self._era[1], first]
+        self._era = [self._era[1], self._era[2], first]
         polled = first  # launches < polled have been looked at
         while True:
-            # the rows of this batch were produced since the previous batch opened: the rings must still hold them
+            # What the rings must still hold: the rows of this batch were STARTED since the previous batch opened
+            # (an env runs at most one batch ahead), but the observation a row acts on — and its three linked
+            # FrameStack predecessors — can be older: an env that finished this batch's rows early idled at
+            # rows_limit with an observation produced while the batch BEFORE the previous one was collected.
+            # So the oldest slot still referenced is younger than era[0] - 3 - (launches an env sat out in a
+            # reset sequence, <= 4): three eras + 8 slots of margin.
             if self.launch - self._era[0] >= self.S - 8:
-                raise RuntimeError('elastic rollout: %d launches since the previous batch opened exceed the ring '
-                                   '(%d slots): raise the env horizon' % (self.launch - self._era[0], self.S))
+                raise RuntimeError('elastic rollout: %d launches since the batch before the previous one opened '
+                                   'exceed the ring (%d slots): raise the env horizon' %
+                                   (self.launch - self._era[0], self.S))
             self.collect_launch(model)
             l = self.launch - 1
             self._fin_host[l % self.S:l % self.S + 1].copy_(self.finished[par:par + 1], non_blocking=True)
@@ -231,13 +251,7 @@ class ElasticDeviceRollout(DeviceRollout):
         self.dones.copy_(self.dones_rows[h:h + T])
         self.finished[self.batch & 1].zero_()  # counts batch + 2 next; no env reaches its last row before the limit moves
         self.batch += 1
-        return {
-            'obs': self.obs,
-            'actions': self.actions.reshape(T * E),
-            'behaviour_logits': self.behaviour_logits.reshape(T * E, -1),
-            'rewards': self.rewards.reshape(T * E),
-            'dones': self.dones.reshape(T * E).bool(),
-        }
+        return self._batch_view()
 
     def collect(self, model):
         self.collect_begin()
@@ -257,7 +271,7 @@ class ElasticDeviceRollout(DeviceRollout):
 
     def load_state_dict(self, d):
         super(ElasticDeviceRollout, self).load_state_dict(d)
-        self.launch, self.batch, self._era = int(d['launch']), int(d['batch']), list(d['era'])
+        self.launch, self.batch, self._era = int(d['launch']), int(d['batch']), ([0] + list(d['era']))[-3:]
         for k, v in d['elastic'].items():
             getattr(self, k).copy_(v.to(getattr(self, k).device))
 
@@ -529,6 +543,42 @@ class AsyncActorLearner(object):
                 v.record_stream(ls)
         self.pending = self._collect()
         return out
+
+    def state_dict(self):
+        """Everything of the PIPELINE a resumed run needs next to the model / optimizer the caller saves
+        (Agent.save): the envs, the samplers, the actors' weight snapshot, and the batch that was collected
+        but not learned yet (`pending`: the learner is always one batch behind the actors).  All actor and
+        learner streams are drained first — they run launches ahead of the host — so nothing is torn."""
+        self.synchronize()
+        torch.cuda.synchronize(self.env.device)
+        d = {'envs': [e.state_dict() for e in self.envs], 'rollouts': [r.state_dict() for r in self.rollouts],
+             'actor_model': {k: v.detach().cpu().clone() for k, v in self.actor_model.state_dict().items()},
+             'updates': self.updates, 'pending': None}
+        if self.pending is not None:
+            k = self.pending[1]
+            d['pending'] = {'k': k, 'buffers': [r.buffer_state(k) for r in self.rollouts]}
+        return d
+
+    def load_state_dict(self, d):
+        self.synchronize()
+        torch.cuda.synchronize(self.env.device)
+        for e, s in zip(self.envs, d['envs']):
+            e.load_state_dict(s)
+        for r, s in zip(self.rollouts, d['rollouts']):
+            r.load_state_dict(s)
+        self.actor_model.load_state_dict(d['actor_model'])
+        self.updates = int(d['updates'])
+        self.pending = None
+        if d['pending'] is not None:
+            k = int(d['pending']['k'])
+            for r, b in zip(self.rollouts, d['pending']['buffers']):
+                r.load_buffer_state(k, b)
+                r._select(k)
+            self.pending = ([r._batch_view() for r in self.rollouts], k)
+        torch.cuda.synchronize(self.env.device)
+        cur = torch.cuda.current_stream(self.env.device)
+        for ev in self.batch_free + [self.weights_ready, self.snapshot_done] + [e for pair in self.batch_ready for e in pair]:
+            ev.record(cur)
 
     def pop_episode_stats(self):
         """(episodes closed, mean unclipped return, mean length) over all groups.  The statistics

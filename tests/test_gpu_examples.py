@@ -229,3 +229,62 @@ def test_env_and_sampler_checkpoint_resumes_bit_identically(dev, tmp_path):
     other = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=42, horizon=T, seed=12, device=dev)
     with pytest.raises(ValueError):
         other.load_state_dict(env.state_dict())
+
+
+def test_async_pipeline_checkpoint_resumes_bit_identically(dev, tmp_path):
+    """AsyncActorLearner.state_dict / load_state_dict (envs and rings written on the ACTOR stream, launches ahead
+    of the host; the collected-but-unlearned `pending` batch; the actors' weight snapshot): save mid-run, three
+    more steps, restore, the same three steps again — every parameter and the pending batch bit-identical."""
+    import parl_amd as parl
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel42
+    from parl_amd.rollout import AsyncActorLearner
+    torch.manual_seed(0)
+    E, T = 16, 8
+    env = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=42, horizon=T, seed=21, device=dev)
+    model = AtariModel42(env.act_dim).to(dev)
+    with torch.no_grad():
+        model.policy_fc.weight.mul_(0.05)
+        model.value_fc.weight.mul_(0.05)
+    alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
+                                 clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+
+    class A(parl.Agent):
+        pass
+
+    agent = A(alg)
+    pipe = AsyncActorLearner(alg, [env], T, seed=7)
+    agent.attach(pipeline=pipe)
+    for _ in range(3):
+        pipe.step(1e-3, -0.01)
+    path = str(tmp_path / 'async.ckpt')
+    agent.save(path)  # no synchronize() by the caller: state_dict drains the streams itself
+    opt_state = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in
+                 {'state': [{n: t.clone() for n, t in st.items()} for st in alg.optimizer.state_dict()['state'].values()]}.items()}
+    full_opt = alg.optimizer.state_dict()
+    full_opt = {'state': {k: {n: (t.clone() if isinstance(t, torch.Tensor) else t) for n, t in st.items()}
+                          for k, st in full_opt['state'].items()}, 'param_groups': full_opt['param_groups']}
+    del opt_state
+
+    def run():
+        for _ in range(3):
+            pipe.step(1e-3, -0.01)
+        pipe.synchronize()
+        return ([p.detach().clone() for p in model.parameters()],
+                {k: v.clone() for k, v in pipe.pending[0][0].items()})
+
+    p1, b1 = run()
+    p_drift, _ = run()
+    assert any(not torch.equal(a, b) for a, b in zip(p1, p_drift))
+    agent.restore(path)
+    alg.optimizer.load_state_dict(full_opt)
+    p2, b2 = run()
+    for a, b in zip(p1, p2):
+        assert torch.equal(a, b)
+    for k in b1:
+        assert torch.equal(b1[k], b2[k]), k
+    env.check_faults()
+    # a model-only checkpoint cannot silently restart attached envs
+    os.remove(path + '.env')
+    with pytest.raises(FileNotFoundError):
+        agent.restore(path)
