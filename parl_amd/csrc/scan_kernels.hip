@@ -1159,14 +1159,94 @@ __device__ __forceinline__ float lane_bcast(float x, int src_lane) {  // src_lan
 
 constexpr int kHeadsHidden = 256;
 
+// gfx950 lane swaps (the clang builtins of this toolchain return the same value twice — checked on the
+// device — hence the instruction itself; a VALU write needs two wait states before the swap reads it)
+__device__ __forceinline__ void lane_swap32(float& a, float& c) {  // a[32..63] <-> c[0..31]
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(c));
+}
+__device__ __forceinline__ void lane_swap16(float& a, float& c) {  // odd 16-lane rows of a <-> even rows of c
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(c));
+}
+typedef float f2v __attribute__((ext_vector_type(2)));
+// two independent scalar chains (two outputs of the heads at once): the tree below is a chain of dependent
+// swap / add / DPP operations, a second output in flight fills its bubbles.  (Packing the two into v_pk_* ops
+// was tried: the compiler materialises every row as a splat pair — 200 more registers, scratch spills.)
+struct F2 { float a, b; };
+__device__ __forceinline__ F2 operator+(F2 x, F2 y) { return F2{x.a + y.a, x.b + y.b}; }
+__device__ __forceinline__ void lane_swap32(F2& x, F2& y) { lane_swap32(x.a, y.a); lane_swap32(x.b, y.b); }
+__device__ __forceinline__ void lane_swap16(F2& x, F2& y) { lane_swap16(x.a, y.a); lane_swap16(x.b, y.b); }
+__device__ __forceinline__ float dot2(float2 h, float wx, float wy) { return __builtin_fmaf(h.y, wy, h.x * wx); }
+__device__ __forceinline__ F2 dot2(float2 h, F2 wx, F2 wy) { return F2{dot2(h, wx.a, wy.a), dot2(h, wx.b, wy.b)}; }
+
+template <int DPP_CTRL>
+__device__ __forceinline__ float dpp_partner_add(float keep, float send) {
+  return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), DPP_CTRL, 0xf,
+                                                                      0xf, true));
+}
+template <int DPP_CTRL>
+__device__ __forceinline__ float stage_combine(float x, float y, bool hi) {
+  return dpp_partner_add<DPP_CTRL>(hi ? y : x, hi ? x : y);
+}
+template <int DPP_CTRL>
+__device__ __forceinline__ F2 stage_combine(F2 x, F2 y, bool hi) {
+  return F2{stage_combine<DPP_CTRL>(x.a, y.a, hi), stage_combine<DPP_CTRL>(x.b, y.b, hi)};
+}
+
+// Row sums of (h row) . (w of one output, or of two outputs at once: F2) for the <= 64 rows a wave
+// holds: lane t ends up with row t's sum.  Butterfly: at the stage of lane bit `off` the lanes with that bit clear
+// keep the lower half of the rows they still hold, the others the upper half, each adding what its partner
+// holds of the half it keeps.  Stages 32 and 16 are ONE v_permlane32_swap / v_permlane16_swap + one add per pair
+// of values (gfx950: the swap exchanges the upper half / the odd rows of 16 lanes of one register with the lower
+// half / the even rows of a second one — exactly "keep mine, get the partner's"), stages 8..1 are DPP adds
+// (row_mirror, row_half_mirror, quad_perm: the partner differs in the stage's bit, which is all the tree needs).
+// No LDS-crossbar shuffles (the first version used 63 ds_bpermute per output), and the tree is evaluated DEPTH
+// FIRST (four rows down to one value, then one pending value per stage): a handful of live partials instead of 64.
+template <int TMAX, typename V>
+__device__ __forceinline__ V rows4(const float2 (&hr)[TMAX], V wx, V wy, int i) {  // rows i, i+16, i+32, i+48
+  V p0 = dot2(hr[i < TMAX ? i : 0], wx, wy);
+  V p1 = i + 16 < TMAX ? dot2(hr[i + 16 < TMAX ? i + 16 : 0], wx, wy) : V{};
+  V p2 = i + 32 < TMAX ? dot2(hr[i + 32 < TMAX ? i + 32 : 0], wx, wy) : V{};
+  V p3 = i + 48 < TMAX ? dot2(hr[i + 48 < TMAX ? i + 48 : 0], wx, wy) : V{};
+  lane_swap32(p0, p2);   // lanes < 32: rows i (+ the partner's), lanes >= 32: rows i + 32
+  V u0 = p0 + p2;
+  lane_swap32(p1, p3);   // rows i + 16 | i + 48
+  V u1 = p1 + p3;
+  lane_swap16(u0, u1);   // lane bit 4 clear: rows i | i + 32, set: rows i + 16 | i + 48
+  return u0 + u1;
+}
+template <int TMAX, int OFF, typename V>
+__device__ __forceinline__ V rows_tree(const float2 (&hr)[TMAX], V wx, V wy, int lane, int i) {
+  if constexpr (OFF == 16) {
+    return rows4<TMAX, V>(hr, wx, wy, i);
+  } else {
+    const V x = rows_tree<TMAX, OFF * 2, V>(hr, wx, wy, lane, i);
+    const V y = rows_tree<TMAX, OFF * 2, V>(hr, wx, wy, lane, i + OFF);
+    constexpr int ctrl = OFF == 8 ? 0x140 : (OFF == 4 ? 0x141 : (OFF == 2 ? 0x4e : 0xb1));  // row_mirror, row_half_mirror, quad_perm [2,3,0,1], [1,0,3,2]
+    return stage_combine<ctrl>(x, y, (lane & OFF) != 0);
+  }
+}
+template <int TMAX, typename V>
+__device__ __forceinline__ V heads_row_sums(const float2 (&hr)[TMAX], V wx, V wy, int lane) {
+  return rows_tree<TMAX, 1, V>(hr, wx, wy, lane, 0);
+}
+
 // TWO wavefronts per sequence, 128 columns each (lane l: columns half * 128 + 2l, +1): with one wave
 // holding whole rows the kernel needed all 512 VGPRs of a SIMD, could not share it with a resident
 // emulator wave (171 VGPRs) and waited for the env kernel to drain (332 us in the bench against 39 us
-// alone).  At <= 256 VGPRs it slots in next to the actors.  The two halves exchange their partial head
-// outputs through LDS and run the (cheap) loss math redundantly; each produces its half of the columns
-// of d total / d h and of the weight gradients.
+// alone).  Registers decide how many of these waves fit NEXT TO an emulator wave (one per SIMD, always
+// there in the bench): at 255 VGPRs one (the 512 workgroups then run in two rounds: 67 us beside the env
+// kernel against 46 us alone, tools/heads_beside_env.py); at <= 168 two — __launch_bounds__(256, 3) —
+// which the depth-first butterfly below (a handful of live partials instead of 64) reaches without
+// scratch for T <= 50: 47 us beside the env kernel, 43 alone (kernel itself 32.5 us).  The two halves
+// exchange their partial head outputs through LDS and run the (cheap) loss math redundantly; each produces
+// its half of the columns of d total / d h and of the weight gradients.
+// Where the 32.5 us go (variants timed with rocprofv3): loading the 52 MB of h and storing 52 MB straight
+// back takes 18.5 us (5.7 TB/s: the access pattern is fine); + the head outputs 22.0; loss + backward
+// without the forward 25.5.  The phases of a wave do not overlap and neither staggering half of the
+// workgroups nor more ILP (two outputs in flight, packed backward) moves the total: what is left is per-wave
+// latency, two waves per SIMD.
 template <int A_CT, int TMAX>  // TMAX >= T: rows held in registers (2 VGPRs each)
-__global__ __launch_bounds__(256, 2) void impala_heads_loss_kernel(
+__global__ __launch_bounds__(256, 3) void impala_heads_loss_kernel(
     const float* __restrict__ h, const float* __restrict__ wpi, const float* __restrict__ bpi,
     const float* __restrict__ wv, const float* __restrict__ bv, const float* __restrict__ blog,
     const int64_t* __restrict__ actions, const float* __restrict__ rew, const uint8_t* __restrict__ dones,
@@ -1200,38 +1280,16 @@ __global__ __launch_bounds__(256, 2) void impala_heads_loss_kernel(
   __shared__ float xch[2][2][NO][64];  // [sequence of the workgroup][half][output][lane = row]
   float outv[NO];
 #pragma unroll
-  for (int j = 0; j < NO; ++j) {
-    // butterfly: at offset `off` the lanes with that bit clear keep the lower half of the rows, the
-    // others the upper half, each adding what its partner holds of the half it keeps.  The first
-    // stage forms the dot products as it consumes them (rows i and i + 32), 4 exchanges in flight at a
-    // time: with all 64 partials formed up front the kernel spilled rows of h (15 MB of scratch traffic)
-    float part[32];
-    {
-      const bool hi = (lane & 32) != 0;
-#pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const float a = __builtin_fmaf(hr[i < TMAX ? i : 0].y, wj[j].y, hr[i < TMAX ? i : 0].x * wj[j].x);
-        const float c = i + 32 < TMAX ? __builtin_fmaf(hr[i + 32 < TMAX ? i + 32 : 0].y, wj[j].y,
-                                                       hr[i + 32 < TMAX ? i + 32 : 0].x * wj[j].x) : 0.f;
-        const float send = hi ? a : c, keep = hi ? c : a;
-        part[i] = keep + __shfl_xor(send, 32, 64);
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#pragma unroll
-    for (int off = 16, n = 32; off >= 1; off >>= 1, n >>= 1) {
-      const bool hi = (lane & off) != 0;
-#pragma unroll
-      for (int i = 0; i < n / 2; ++i) {
-        const float a = part[i], c = part[i + n / 2];
-        const float send = hi ? a : c, keep = hi ? c : a;
-        part[i] = keep + __shfl_xor(send, off, 64);
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    outv[j] = part[0];
-    xch[sq][half][j][lane] = part[0];
-    __builtin_amdgcn_sched_barrier(0);  // one output at a time: 64 partials live, not 64 * (A + 1)
+  for (int j = 0; j + 1 < NO; j += 2) {  // two outputs at a time
+    const F2 r = heads_row_sums<TMAX, F2>(hr, F2{wj[j].x, wj[j + 1].x}, F2{wj[j].y, wj[j + 1].y}, lane);
+    outv[j] = r.a; outv[j + 1] = r.b;
+    xch[sq][half][j][lane] = r.a; xch[sq][half][j + 1][lane] = r.b;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (NO & 1) {
+    const float r = heads_row_sums<TMAX, float>(hr, wj[NO - 1].x, wj[NO - 1].y, lane);
+    outv[NO - 1] = r;
+    xch[sq][half][NO - 1][lane] = r;
   }
   __syncthreads();
 #pragma unroll
@@ -1298,20 +1356,22 @@ __global__ __launch_bounds__(256, 2) void impala_heads_loss_kernel(
     }
   }
   // ---- 4. backward of the heads: dh rows out, weight gradients from the rows still in registers
-  float2 accw[NO];
+  f2v accw[NO];  // two columns per lane: v_pk_fma_f32 with the row's output gradient as the (scalar) multiplier
 #pragma unroll
-  for (int j = 0; j < NO; ++j) accw[j] = make_float2(0.f, 0.f);
+  for (int j = 0; j < NO; ++j) accw[j] = f2v{0.f, 0.f};
 #pragma unroll
   for (int tt = 0; tt < TMAX; ++tt) {
     if (tt < T) {
-      float2 d = make_float2(0.f, 0.f);
+      f2v d = {0.f, 0.f};
+      const f2v hrow = {hr[tt].x, hr[tt].y};
 #pragma unroll
       for (int j = 0; j < NO; ++j) {
         const float gj = lane_bcast(g[j], tt);
-        d.x = __builtin_fmaf(gj, wj[j].x, d.x); d.y = __builtin_fmaf(gj, wj[j].y, d.y);
-        accw[j].x = __builtin_fmaf(gj, hr[tt].x, accw[j].x); accw[j].y = __builtin_fmaf(gj, hr[tt].y, accw[j].y);
+        const f2v gg = {gj, gj};
+        d = __builtin_elementwise_fma(gg, f2v{wj[j].x, wj[j].y}, d);
+        accw[j] = __builtin_elementwise_fma(gg, hrow, accw[j]);
       }
-      if (live) *(float2*)(dh + ((int64_t)tt * B + b) * H + col) = d;
+      if (live) *(float2*)(dh + ((int64_t)tt * B + b) * H + col) = make_float2(d.x, d.y);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -1320,7 +1380,7 @@ __global__ __launch_bounds__(256, 2) void impala_heads_loss_kernel(
   __shared__ float redb[2][NO + 4];
 #pragma unroll
   for (int j = 0; j < NO; ++j) {
-    redw[sq][j][half * 64 + lane] = accw[j];
+    redw[sq][j][half * 64 + lane] = make_float2(accw[j].x, accw[j].y);
     const float s = wave_sum(g[j]);
     if (lane == 0 && half == 0) redb[sq][j] = s;
   }

@@ -408,6 +408,26 @@ def _mfma_b_layout(wflat):
     return wflat.reshape(n // 16, 16, k // 4, 4).permute(2, 0, 3, 1).contiguous()
 
 
+_layout_cache = {}
+
+
+def _cached_layout(w, kind, fn):
+    """MFMA operand-order copy of a weight tensor, rebuilt only when the tensor was written since (its autograd
+    version counter moves on every in-place write: optimizer steps, the actors' snapshot copy).  The actors
+    call the forward kernels once per env step with weights that change once per rollout: without the cache
+    every step re-laid out both matrices (three small copy kernels and their host time)."""
+    key = (id(w), kind)
+    hit = _layout_cache.get(key)
+    ver = w._version
+    if hit is not None and hit[0] is w and hit[1] == ver and hit[2] == w.data_ptr():
+        return hit[3]
+    out = fn(w)
+    if len(_layout_cache) > 64:
+        _layout_cache.clear()
+    _layout_cache[key] = (w, ver, w.data_ptr(), out)
+    return out
+
+
 def atari84_conv23(a1, conv2_weight, conv2_bias, conv3_weight, conv3_bias, save_a2=False):
     """conv2 + ReLU + conv3 + ReLU of the A2C Atari network (examples/A2C/atari_model.py:21-104) fused
     in one MFMA kernel: a1 f32 [n,32,20,20] (atari84_conv1's output) -> a3 f32 [n,5184]; with
@@ -419,8 +439,13 @@ def atari84_conv23(a1, conv2_weight, conv2_bias, conv3_weight, conv3_bias, save_
     n = a1.shape[0]
     w2 = _f32(conv2_weight.detach(), 'conv2_weight')
     w3 = _f32(conv3_weight.detach(), 'conv3_weight')
-    wt2 = _mfma_b_layout(w2.reshape(64, 512))
-    wt3 = _mfma_b_layout(w3.permute(0, 2, 3, 1).reshape(64, 576))   # k' = (kh*3 + kw)*64 + c
+    if torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+        wt2 = _mfma_b_layout(w2.reshape(64, 512))
+        wt3 = _mfma_b_layout(w3.permute(0, 2, 3, 1).reshape(64, 576))   # k' = (kh*3 + kw)*64 + c
+    else:  # the actors: same weights for a whole rollout
+        wt2 = _cached_layout(conv2_weight, 'wt2', lambda w: _mfma_b_layout(w.detach().reshape(64, 512)))
+        wt3 = _cached_layout(conv3_weight, 'wt3',
+                             lambda w: _mfma_b_layout(w.detach().permute(0, 2, 3, 1).reshape(64, 576)))
     b2, b3 = _f32(conv2_bias.detach(), 'conv2_bias'), _f32(conv3_bias.detach(), 'conv3_bias')
     a3 = torch.empty((n, 64 * 81), dtype=torch.float32, device=a1.device)
     a2 = torch.empty((n, 64, 11, 11), dtype=torch.float32, device=a1.device) if save_a2 else None
