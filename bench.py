@@ -317,6 +317,9 @@ def self_launch(args):
     if torch.cuda.device_count() < args.gpus:
         env['PARL_AMD_SHARE_GPU'] = '1'
         env['PARL_AMD_DIST_BACKEND'] = 'gloo'
+        # N processes on one device: every stream priority level of every process wants its own hardware queue;
+        # let the runtime multiplex streams onto two queues per process instead of exhausting the device's
+        env.setdefault('GPU_MAX_HW_QUEUES', '2')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.exit(subprocess.call(cmd, env=env))
@@ -472,6 +475,8 @@ def main():
             'frame_skip': 4, 'parallelism': 'dp%d (envs sharded by rank, grad all-reduce)' % world,
             'actor_learner_overlap': not args.no_overlap, 'actor_groups': G, 'elastic_launches': elastic,
             'learner_rows_per_pass': args.learn_rows or T * E,
+            'learner_updates_per_step': len(pipe.sub_batches) if (pipe is not None and pipe.sub_batches) else 1,
+            'env_ids_per_rank': [[r * E, r * E + E - 1] for r in range(world)],
             'collectives': (('none (single process)' if not pdist.active() else 'RCCL, one-rank group (PARL_AMD_FORCE_DIST)')
                             if world == 1 else
                             ('gloo, ranks SHARE GPUs (fewer devices than ranks: functional run, not a scaling number)'

@@ -174,6 +174,43 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert out['config']['train_batch'] == 2 * 64 * 10
 
 
+def test_bench_eight_ranks_dry_run_on_one_gpu():
+    """The real rank count of BASELINE configs[3] (8 ranks), self-launched by `python bench.py --gpus 8` exactly as
+    the driver launches it (torch.distributed.run, one process per rank), on the ONE GPU of the test box over
+    gloo: env-id ranges per rank, rendezvous / port handling, weight broadcast, the order of collectives (flat-
+    gradient all-reduce, small-tensor all-gather, max-over-ranks timing, barriers) with 8 participants.  Not a
+    scaling number (the JSON line says so)."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    cmd = [sys.executable, 'bench.py', '--gpus', '8', '--envs', '32', '--quick', '--steps', '2', '--warmup', '1',
+           '--sample-batch-steps', '10', '--no-cpu-baseline']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, text=True)
+    assert p.returncode == 0, '\n'.join(ln for ln in p.stdout.splitlines() if 'amdgpu.ids' not in ln and 'hostname' not in ln)[-12000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(line) == 1, p.stdout[-2000:]
+    out = json.loads(line[0])
+    assert out['n_gpus'] == 8 and out['value'] > 0 and out['config']['train_batch'] == 8 * 32 * 10
+    assert 'SHARE' in out['config']['collectives']
+    assert out['config']['env_ids_per_rank'] == [[r * 32, r * 32 + 31] for r in range(8)]
+
+
+def test_bench_two_ranks_reference_train_batch(tmp_path):
+    """the data-parallel form of the hipGraph updates (train_batch_size mode): forward + backward graph | gradient
+    all-reduce | clip + Adam graph, two ranks sharing the GPU over gloo"""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--envs', '16', '--quick', '--steps', '2', '--warmup', '1',
+           '--sample-batch-steps', '10', '--train-batch', '40', '--no-cpu-baseline']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    out = json.loads(line[0])
+    assert out['n_gpus'] == 2 and out['config']['learner_updates_per_step'] == 4  # 16 sequences / (40 // 10)
+    assert out['learner_updates_per_sec'] > 0
+
+
 def test_ppo_example_atari_runs():
     out = _run(['examples/PPO/train.py', '--env_num', '8', '--step_nums', '32', '--train_total_steps', '512'])
     assert "'value_loss': " in out and "'update': 2" in out
