@@ -131,7 +131,7 @@ def _event_time(fn, iters=20, warmup=3):
     return ts[len(ts) // 2] * 1e-3
 
 
-def extra_legs(dev):
+def extra_legs(dev, only=None):
     """Short runs of the other BASELINE.json configs on ONE GPU (each leg: its own envs / model,
     1 warm-up + a few timed iterations, wall-clock with synchronize on both sides; frames = emulated
     2600 frames of agent steps).  They ride on the headline's JSON line under their own keys and
@@ -140,6 +140,8 @@ def extra_legs(dev):
     out = {}
 
     def guarded(name, fn):
+        if only and name not in only:
+            return
         try:
             out[name] = fn()
         except Exception as e:  # a leg must never take the headline down
@@ -293,11 +295,94 @@ def extra_legs(dev):
                                'traffic_key': 'profiles/r01e_scan_hbm_traffic.json:gae_T2048_B4096_f32'},
                 'adv_normalize_kernel': {'us': a * 1e6, 'bytes': aby, 'GBps': aby / a / 1e9}}
 
+    # ---- configs[4] END TO END: the examples/PPO/train.py loop at HalfCheetah shapes ----
+    def ppo_c5():
+        ex = os.path.join(ROOT, 'examples', 'PPO')
+        sys.path.insert(0, ex)
+        try:
+            from agent import PPOAgent
+            from env_utils import ParallelEnv
+            from mujoco_config import mujoco_config
+            from mujoco_model import MujocoModel
+            from storage import RolloutStorage
+        finally:
+            sys.path.remove(ex)
+        from parl_amd.algorithms import PPO
+        cfg = dict(mujoco_config, env_num=4096, seed=0)
+        cfg['batch_size'] = cfg['env_num'] * cfg['step_nums']
+        cfg['num_updates'] = 100
+        envs = ParallelEnv(cfg, device=dev)
+        model = MujocoModel(envs.obs_space, envs.act_space)
+        ppo = PPO(model, clip_param=cfg['clip_param'], entropy_coef=cfg['entropy_coef'], initial_lr=cfg['initial_lr'],
+                  continuous_action=True)
+        agent = PPOAgent(ppo, cfg)
+        rollout = RolloutStorage(cfg['step_nums'], cfg['env_num'], envs.obs_space, envs.act_space, device=dev)
+        obs = envs.reset()
+        done = torch.zeros(cfg['env_num'], device=dev)
+        phases = {}
+
+        def iteration():
+            nonlocal obs, done
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for step in range(cfg['step_nums']):  # examples/PPO/train.py:90-103
+                value, action, logprob, _ = agent.sample(obs)
+                next_obs, reward, next_done = envs.step(action)
+                rollout.append(obs, action, logprob, reward, done, value.flatten())
+                obs, done = next_obs, next_done
+            torch.cuda.synchronize()
+            t1 = time.time()
+            rollout.compute_returns(agent.value(obs).flatten(), done)  # :105-107
+            torch.cuda.synchronize()
+            t2 = time.time()
+            out = agent.learn(rollout)  # :108: update_epochs x num_minibatches PPO.learn calls
+            torch.cuda.synchronize()
+            t3 = time.time()
+            phases.update(rollout_s=t1 - t0, compute_returns_s=t2 - t1, learn_s=t3 - t2)
+            return out, t3 - t0
+
+        # warm-up: a short rollout's worth of steps and one minibatch pass would leave the storage half filled;
+        # one full untimed iteration instead
+        iteration()
+        (vl, al, el, lr), dt = iteration()
+        assert np.isfinite(vl) and np.isfinite(al)
+        n = cfg['batch_size']
+        # CPU baseline of the wrapper + returns part on a bounded sample: the C oracle's VecNormalize (one
+        # RunningMeanStd per env, mujoco_wrappers.py:73-206) for 64 steps of 4096 envs, the numpy port of
+        # RolloutStorage.compute_returns (storage.py:45-64) at full size
+        from oracle import c_oracle, py_baselines
+        vn = c_oracle.VecNormalize(4096, 17)
+        rng = np.random.default_rng(0)
+        raw, rw, dn = rng.standard_normal((4096, 17)), rng.standard_normal(4096), np.zeros(4096, np.uint8)
+        t0 = time.time()
+        for _ in range(64):
+            vn.filter_obs(raw)
+            vn.filter_reward(rw, dn)
+        vn_s = (time.time() - t0) / 64
+        T_, E_ = cfg['step_nums'], cfg['env_num']
+        r_, v_ = rng.standard_normal((T_, E_)).astype(np.float32), rng.standard_normal((T_, E_)).astype(np.float32)
+        d_ = (rng.random((T_, E_)) < 1e-3).astype(np.float32)
+        t0 = time.time()
+        py_baselines.compute_returns(r_, v_, d_, v_[0], d_[0])
+        cr_s = time.time() - t0
+        return {'workload': 'BASELINE configs[4] end to end: the examples/PPO/train.py loop (train.py:90-112) with 4096 '
+                            'host-stepped simulators (a synthetic stand-in with HalfCheetah shapes: MuJoCo is not in the '
+                            'image), per step: policy sample on the device, actions D2H, host step, one H2D of raw f64 '
+                            'obs / rewards / dones, VecNormalize + RolloutStorage.append kernels; then compute_returns '
+                            '(T=2048 x E=4096) and update_epochs=10 x num_minibatches=32 PPO.learn calls on 262,144-row '
+                            'minibatches gathered on the device',
+                'agent_steps_per_s': n / dt, 'seconds_per_iteration': dt, 'phases': phases,
+                'updates_per_s': cfg['update_epochs'] * cfg['num_minibatches'] / dt,
+                'cpu_port_baseline': {'vecnormalize_step_ms_4096_envs (C oracle, 1 core)': vn_s * 1e3,
+                                      'compute_returns_s_T2048_E4096 (numpy port, 1 core)': cr_s,
+                                      'kind': 'port', 'cores': 1}}
+
     guarded('impala_ref_batch', impala_ref_batch)
     guarded('a2c_c2', a2c_c2)
     guarded('impala_84', impala_84)
     guarded('breakout_c4_per_gpu', breakout_c4)
     guarded('ppo_c5_scans', ppo_c5_scans)
+    guarded('ppo_c5', ppo_c5)
     return out
 
 
@@ -352,8 +437,15 @@ def main():
                     help='headline workload only: skip the saturating-shape roofline and the extra config legs')
     ap.add_argument('--no-overlap', action='store_true',
                     help='run rollout and learner update back to back on one stream instead of overlapped')
+    ap.add_argument('--only-legs', default='',
+                    help='dev: run only these extra legs (comma separated) and print their JSON, no headline run')
     args = ap.parse_args()
 
+    if args.only_legs:
+        dev = torch.device('cuda', 0)
+        torch.cuda.set_device(dev)
+        print(json.dumps(extra_legs(dev, only=set(args.only_legs.split(',')))))
+        return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         return self_launch(args)
     rank, local, world = pdist.init()
