@@ -208,6 +208,13 @@ int parlhip_policy_sample_f32(const float* logits_or_probs, int is_logits,
                               double* uniforms_out, int B, int A, uint64_t seed,
                               uint64_t offset, uint64_t row0, parlhip_stream_t stream);
 
+/* The actors' policy head and the draw in ONE launch: logits = hidden [B,256] @ w_policy^T [A,256] + b_policy
+ * (examples/IMPALA/atari_model.py:44-57,73-79) written to logits_out [B,A] (a rollout slab), then the action
+ * exactly as parlhip_policy_sample_f32(is_logits = 1) draws it.  hidden_units must be 256, A <= 18.       */
+int parlhip_policy_head_sample_f32(const float* hidden, const float* w_policy, const float* b_policy,
+                                   float* logits_out, int64_t* actions, int B, int hidden_units, int A,
+                                   uint64_t seed, uint64_t offset, uint64_t row0, parlhip_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Frame pipeline: MaxAndSkipEnv max + WarpFrame
  * parl/env/atari_wrappers.py:239 (obs_buffer.max(axis=0)), :263-267 (cv2 RGB2GRAY +
@@ -231,6 +238,13 @@ int parlhip_frame_post_since_u8(const uint8_t* frames0, const uint8_t* frames1, 
                                 const uint8_t* flags, uint8_t* out, int64_t out_stride, int E, int dim,
                                 const void* tables_dev, const uint8_t* since_prev, uint8_t* since_next,
                                 parlhip_stream_t stream);
+/* The same plus the MonitorEnv statistics of parlhip_episode_stats_accum_f64 (atari_wrappers.py:88-95) in the
+ * same launch: the whole post-emulator part of VectorEnv.step for E envs is ONE kernel.              */
+int parlhip_frame_post_step_u8(const uint8_t* frames0, const uint8_t* frames1, int64_t in_stride, int fmt,
+                               const uint8_t* flags, uint8_t* out, int64_t out_stride, int E, int dim,
+                               const void* tables_dev, const uint8_t* since_prev, uint8_t* since_next,
+                               const float* ep_returns, const int32_t* ep_lengths, double* ep_acc3,
+                               parlhip_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------

@@ -48,12 +48,14 @@ SIGNATURES = {
     'parlhip_adv_normalize_workspace_bytes': (_sz, [_i64]),
     'parlhip_adv_normalize_f32': (_i, [_p, _p, _p, _i64, _f, _p, _sz, _p, _p]),
     'parlhip_categorical_sample_f32': (_i, [_p, _p, _p, _i, _i, _p]),
+    'parlhip_policy_head_sample_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _u64, _u64, _u64, _p]),
     'parlhip_policy_sample_f32':
     (_i, [_p, _i, _p, _p, _p, _i, _i, _u64, _u64, _u64, _p]),
     'parlhip_frame_post_tables_bytes': (_sz, [_i]),
     'parlhip_frame_post_tables_init': (_i, [_p, _i]),
     'parlhip_frame_post_u8': (_i, [_p, _p, _i64, _i, _p, _p, _i64, _i, _i, _p, _p]),
     'parlhip_frame_post_since_u8': (_i, [_p, _p, _i64, _i, _p, _p, _i64, _i, _i, _p, _p, _p, _p]),
+    'parlhip_frame_post_step_u8': (_i, [_p, _p, _i64, _i, _p, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     'parlhip_atari_state_bytes': (_sz, []),
     'parlhip_atari_frame_bytes': (_sz, []),
     'parlhip_atari_rom_table_bytes': (_sz, [ctypes.c_uint32]),

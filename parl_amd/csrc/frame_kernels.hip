@@ -37,7 +37,8 @@ __global__ __launch_bounds__(512) void frame_post_kernel(
     const uint8_t* __restrict__ frames0, const uint8_t* __restrict__ frames1, int64_t in_stride,
     int fmt, const uint8_t* __restrict__ flags, uint8_t* __restrict__ out, int64_t out_stride,
     int dim, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ since_prev,
-    uint8_t* __restrict__ since_next) {
+    uint8_t* __restrict__ since_next, const float* __restrict__ ep_returns, const int* __restrict__ ep_lengths,
+    double* __restrict__ ep_acc) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fp_lds[];
   uint8_t* gray = fp_lds;                                   // [kFrameBytes] (33,600: 16-byte multiple)
   uint32_t* pal = (uint32_t*)(fp_lds + kFrameBytes);        // [128]
@@ -46,6 +47,14 @@ __global__ __launch_bounds__(512) void frame_post_kernel(
   int* s_xstart = (int*)(s_yt + (kH + 2 * dim));            // [dim + 1]
   int* s_ystart = s_xstart + (dim + 1);                     // [dim + 1]
   const int e = blockIdx.x;
+  if (ep_acc && threadIdx.x == 32) {  // MonitorEnv statistics of this env's step (episode_stats_kernel), same launch
+    const int len = ep_lengths[e];
+    if (len > 0) {
+      atomicAdd(ep_acc + 0, 1.0);
+      atomicAdd(ep_acc + 1, (double)ep_returns[e]);
+      atomicAdd(ep_acc + 2, (double)len);
+    }
+  }
   if (flags && (flags[e] & 4)) {  // elastic stepping: this env delivered no observation in this launch
     if (since_next && threadIdx.x == 0) since_next[e] = 0;
     return;
@@ -343,7 +352,8 @@ PARLHIP_EXPORT int parlhip_frame_post_u8(const uint8_t* frames0, const uint8_t* 
     }
   }
   frame_post_kernel<<<E, 512, lds, (hipStream_t)stream>>>(frames0, frames1, in_stride, fmt, flags, out,
-                                                          out_stride, dim, (const uint8_t*)tables_dev, nullptr, nullptr);
+                                                          out_stride, dim, (const uint8_t*)tables_dev, nullptr, nullptr,
+                                                          nullptr, nullptr, nullptr);
   return check_launch();
 }
 
@@ -358,7 +368,26 @@ PARLHIP_EXPORT int parlhip_frame_post_since_u8(const uint8_t* frames0, const uin
                     (frames1 ? reinterpret_cast<uintptr_t>(frames1) : 0)) & 15))
     return PARLHIP_EINVAL;
   frame_post_kernel<<<E, 512, frame_post_lds_bytes(dim), (hipStream_t)stream>>>(
-      frames0, frames1, in_stride, fmt, flags, out, out_stride, dim, (const uint8_t*)tables_dev, since_prev, since_next);
+      frames0, frames1, in_stride, fmt, flags, out, out_stride, dim, (const uint8_t*)tables_dev, since_prev, since_next,
+      nullptr, nullptr, nullptr);
+  return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_frame_post_step_u8(const uint8_t* frames0, const uint8_t* frames1, int64_t in_stride,
+                                              int fmt, const uint8_t* flags, uint8_t* out, int64_t out_stride, int E,
+                                              int dim, const void* tables_dev, const uint8_t* since_prev,
+                                              uint8_t* since_next, const float* ep_returns, const int32_t* ep_lengths,
+                                              double* ep_acc3, parlhip_stream_t stream) {
+  if (E < 0 || dim < 1 || dim > 84 || (fmt != 0 && fmt != 1)) return PARLHIP_EINVAL;
+  if (E == 0) return PARLHIP_OK;
+  if (!frames0 || !out || !tables_dev || !flags || !since_next || !ep_returns || !ep_lengths || !ep_acc3)
+    return PARLHIP_EINVAL;
+  if (fmt == 1 && ((reinterpret_cast<uintptr_t>(frames0) | (uintptr_t)in_stride |
+                    (frames1 ? reinterpret_cast<uintptr_t>(frames1) : 0)) & 15))
+    return PARLHIP_EINVAL;
+  frame_post_kernel<<<E, 512, frame_post_lds_bytes(dim), (hipStream_t)stream>>>(
+      frames0, frames1, in_stride, fmt, flags, out, out_stride, dim, (const uint8_t*)tables_dev, since_prev, since_next,
+      ep_returns, ep_lengths, ep_acc3);
   return check_launch();
 }
 

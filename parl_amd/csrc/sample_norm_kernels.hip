@@ -65,6 +65,63 @@ __global__ __launch_bounds__(256) void policy_sample_kernel(
   actions[b] = a;
 }
 
+// The actors' policy head + sampling in ONE launch (examples/IMPALA/atari_model.py:44-57 policy_fc, then
+// IMPALA.sample + AtariAgent.sample, atari_agent.py:35-42): one wavefront per env row — lane l holds
+// h[row][4l..4l+3], a logit is four FMAs per lane and a wave reduction, lane 0 adds the bias, writes the
+// [A] logits row into the rollout slab and draws the action exactly as policy_sample_kernel does
+// (float32 softmax, float64 inverse CDF, Philox uniform of (offset, row0 + row)).  256 hidden units.
+__device__ __forceinline__ float wave_sum_f32(float x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+  return x;
+}
+
+template <int A_MAX>
+__global__ __launch_bounds__(256) void policy_head_sample_kernel(
+    const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ logits_out, int64_t* __restrict__ actions, int B, int A, uint64_t seed, uint64_t offset,
+    uint64_t row0) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;  // whole wave
+  const float4 hv = ((const float4*)(h + b * 256))[lane];
+  float row[A_MAX];
+#pragma unroll
+  for (int k = 0; k < A_MAX; ++k) {
+    row[k] = 0.f;
+    if (k < A) {
+      const float4 wv = ((const float4*)(w + (size_t)k * 256))[lane];
+      float p = hv.x * wv.x;
+      p = __builtin_fmaf(hv.y, wv.y, p);
+      p = __builtin_fmaf(hv.z, wv.z, p);
+      p = __builtin_fmaf(hv.w, wv.w, p);
+      row[k] = wave_sum_f32(p) + bias[k];
+    }
+  }
+  if (lane != 0) return;
+  const double u = philox_uniform53(seed, offset, row0 + (uint64_t)b);
+  float m = row[0];
+#pragma unroll
+  for (int k = 1; k < A_MAX; ++k) if (k < A) m = fmaxf(m, row[k]);
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < A_MAX; ++k) if (k < A) s += expf(row[k] - m);
+  double last = 0.0;
+#pragma unroll
+  for (int k = 0; k < A_MAX; ++k) if (k < A) last += (double)(expf(row[k] - m) / s);
+  double c = 0.0;
+  int64_t a = A;
+#pragma unroll
+  for (int k = 0; k < A_MAX; ++k) {
+    if (k < A) {
+      logits_out[b * A + k] = row[k];
+      c += (double)(expf(row[k] - m) / s);
+      if (a == A && c / last > u) a = k;
+    }
+  }
+  actions[b] = a;
+}
+
 // ----------------------------------------------------------------------------------------
 // Advantage normalisation: two kernels, deterministic (no atomics).
 //   pass 1: per-block partial (sum, sum of squares about a pivot) in float64 -> workspace
@@ -152,6 +209,25 @@ PARLHIP_EXPORT int parlhip_categorical_sample_f32(const float* probs, const doub
   const int block = B >= 256 * 64 ? 256 : 64;
   categorical_sample_kernel<<<ceil_div(B, block), block, 0, (hipStream_t)stream>>>(
       probs, uniforms, actions, B, A);
+  return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_policy_head_sample_f32(const float* hidden, const float* w_policy, const float* b_policy,
+                                                  float* logits_out, int64_t* actions, int B, int hidden_units, int A,
+                                                  uint64_t seed, uint64_t offset, uint64_t row0,
+                                                  parlhip_stream_t stream) {
+  if (B < 0 || A < 1) return PARLHIP_EINVAL;
+  if (hidden_units != 256 || A > 18) return PARLHIP_ENOSUP;
+  if (B == 0) return PARLHIP_OK;
+  if (!hidden || !w_policy || !b_policy || !logits_out || !actions) return PARLHIP_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(hidden) | reinterpret_cast<uintptr_t>(w_policy)) & 15) return PARLHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (A <= 6)
+    policy_head_sample_kernel<6><<<ceil_div(B, 4), 256, 0, s>>>(hidden, w_policy, b_policy, logits_out, actions, B, A,
+                                                                 seed, offset, row0);
+  else
+    policy_head_sample_kernel<18><<<ceil_div(B, 4), 256, 0, s>>>(hidden, w_policy, b_policy, logits_out, actions, B, A,
+                                                                  seed, offset, row0);
   return check_launch();
 }
 

@@ -105,10 +105,22 @@ class DeviceVectorEnv(object):
                     N.ptr(self.reset_cache), N.ptr(self.jam), N.stream_ptr()), 'reset_cache_build')
 
     # ---------------------------------------------------------------- internals
-    def _frame_post(self, slot):
-        # max-2 + gray + INTER_AREA into ring[slot] and the FrameStack `since` counters, one launch
+    def _frame_post(self, slot, ep_acc=None):
+        # max-2 + gray + INTER_AREA into ring[slot] and the FrameStack `since` counters, one launch; with
+        # ep_acc (f64 [3] on the device) also the MonitorEnv statistics of accumulate_episode_stats
         L = N.lib()
         prev = self.since[slot - 1] if slot > 0 else None
+        if ep_acc is not None:
+            if ep_acc.dtype != torch.float64 or ep_acc.numel() != 3 or ep_acc.device.type != self.device.type:
+                raise N.ParlHipError('ep_acc must be float64 [3] on the env device')
+            N.check(
+                L.parlhip_frame_post_step_u8(
+                    N.ptr(self.raw_frames), self.raw_frames.data_ptr() + 210 * 160, 2 * 210 * 160, 1,
+                    N.ptr(self.obs_flags), N.ptr(self.ring[slot]), self.fsz, self.envs_num, self.dim,
+                    N.ptr(self.fp_tables), N.ptr(prev) if prev is not None else None, N.ptr(self.since[slot]),
+                    N.ptr(self.ep_returns), N.ptr(self.ep_lengths), N.ptr(ep_acc), N.stream_ptr()),
+                'parlhip_frame_post_step_u8')
+            return
         N.check(
             L.parlhip_frame_post_since_u8(
                 N.ptr(self.raw_frames), self.raw_frames.data_ptr() + 210 * 160, 2 * 210 * 160, 1,
@@ -156,9 +168,10 @@ class DeviceVectorEnv(object):
         self._frame_post(3)
         return self.current_obs()
 
-    def step_async(self, actions, rewards_out=None, dones_out=None):
+    def step_async(self, actions, rewards_out=None, dones_out=None, ep_acc=None):
         """Enqueue one VectorEnv.step; results land in self.rewards/dones (or the given [E] slabs
-        of a rollout buffer) and the new frame in ring slot t+4."""
+        of a rollout buffer) and the new frame in ring slot t+4.  ep_acc: accumulate_episode_stats(ep_acc)
+        folded into the same launches."""
         if actions.dtype != torch.int64:
             raise N.ParlHipError('actions must be int64')
         if self.t >= self.horizon:
@@ -173,7 +186,7 @@ class DeviceVectorEnv(object):
                 self.max_episode_steps, N.ptr(self.reset_cache), N.ptr(self.jam), N.stream_ptr()),
             'parlhip_atari_vec_step')
         self.t += 1
-        self._frame_post(self.t + 3)
+        self._frame_post(self.t + 3, ep_acc)
 
     # ---------------------------------------------------------------- elastic launches (circular ring)
     def elastic_begin(self):

@@ -96,7 +96,8 @@ class AtariModel42(Model):
             # the actors' path (no autograd): conv1+conv2 as one fused MFMA kernel on the uint8
             # observations (ops.atari42_conv12), conv3 is a 3872 -> 256 linear layer
             h = ops.atari42_conv12(obs, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
-            return F.relu(F.linear(h, self.conv3.weight.flatten(1), self.conv3.bias))
+            # conv3 + ReLU as ONE GEMM with a ReLU epilogue (hipBLASLt) instead of addmm + clamp
+            return torch._addmm_activation(self.conv3.bias, h, self.conv3.weight.flatten(1).t(), use_gelu=False)
         if obs.dtype == torch.uint8 and obs.is_cuda and obs.shape[0] > 0:
             # the learner's path: the same fused forward kernel under autograd, its backward is ONE
             # kernel that recomputes conv1 and produces the four parameter gradients (no im2col, no
@@ -116,6 +117,16 @@ class AtariModel42(Model):
     def policy_into(self, obs, out):
         """policy(obs) written straight into `out` (a [E, A] slab of a rollout buffer)"""
         return torch.addmm(self.policy_fc.bias, self._trunk(obs), self.policy_fc.weight.t(), out=out)
+
+    @torch.no_grad()
+    def policy_sample_into(self, obs, logits_out, actions_out, seed, offset, row0=0):
+        """the actors' step: policy(obs) into `logits_out` AND the sampled actions into `actions_out` (slabs of
+        a rollout buffer), head + draw in one launch (ops.policy_head_sample_into)"""
+        h = self._trunk(obs)
+        if not ops.policy_head_sample_into(h, self.policy_fc.weight, self.policy_fc.bias, logits_out, actions_out,
+                                           seed, offset, row0):
+            torch.addmm(self.policy_fc.bias, h, self.policy_fc.weight.t(), out=logits_out)
+            ops.policy_sample_into(logits_out, actions_out, seed, offset, row0)
 
     def value(self, obs):
         return self.value_fc(self._trunk(obs)).squeeze(1)

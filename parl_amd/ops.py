@@ -318,6 +318,25 @@ def policy_sample_into(logits, actions_out, seed, offset, row0=0):
     return actions_out
 
 
+def policy_head_sample_into(hidden, w_policy, b_policy, logits_out, actions_out, seed, offset, row0=0):
+    """policy_fc + policy_sample in one launch for the actors: logits_out [B,A] f32 and actions_out [B] int64 are
+    slabs of a rollout buffer; hidden f32 [B,256].  Returns False when the library has no instantiation (the
+    caller then runs the framework's head + policy_sample_into)."""
+    hd = _f32(hidden, 'hidden')
+    B, H = hd.shape
+    A = w_policy.shape[0]
+    if H != 256 or A > 18 or logits_out.dtype != torch.float32 or not logits_out.is_contiguous():
+        return False
+    wp, bp = _f32(w_policy.detach(), 'w_policy'), _f32(b_policy.detach(), 'b_policy')
+    code = N.lib().parlhip_policy_head_sample_f32(N.ptr(hd), N.ptr(wp), N.ptr(bp), N.ptr(logits_out), N.ptr(actions_out),
+                                                  B, H, A, int(seed) & (2**64 - 1), int(offset) & (2**64 - 1),
+                                                  int(row0) & (2**64 - 1), N.stream_ptr())
+    if code == ENOSUP:
+        return False
+    N.check(code, 'parlhip_policy_head_sample_f32')
+    return True
+
+
 def atari42_conv12(obs, conv1_weight, conv1_bias, conv2_weight, conv2_bias, out=None):
     """conv1 + ReLU + conv2 + ReLU of the IMPALA Atari network (examples/IMPALA/atari_model.py:59-71)
     for uint8 observations [n,4,42,42], as ONE fused MFMA kernel (inference only).  Returns f32

@@ -14,6 +14,18 @@ import torch
 from . import ops
 
 
+def _policy_and_draw(model, obs, logits_out, actions_out, seed, offset, row0):
+    """behaviour logits of `obs` into the [E, A] slab and the sampled actions into the [E] slab"""
+    if hasattr(model, 'policy_sample_into'):  # head + draw in one launch
+        model.policy_sample_into(obs, logits_out, actions_out, seed, offset, row0)
+        return
+    if hasattr(model, 'policy_into'):
+        model.policy_into(obs, logits_out)  # the head's GEMM writes the slab directly
+    else:
+        logits_out.copy_(model.policy(obs))
+    ops.policy_sample_into(logits_out, actions_out, seed, offset, row0)
+
+
 class DeviceRollout(object):
     def __init__(self, env, sample_batch_steps, seed=0, n_buffers=1):
         """n_buffers > 1: successive collect() calls fill the trajectory slabs round-robin, so a
@@ -64,13 +76,8 @@ class DeviceRollout(object):
         env = self.env
         obs = env.current_obs(self._obs_step)
         logits = self.behaviour_logits[t]
-        if hasattr(model, 'policy_into'):
-            model.policy_into(obs, logits)  # the head's GEMM writes the [E, A] slab directly
-        else:
-            logits.copy_(model.policy(obs))
-        ops.policy_sample_into(logits, self.actions[t], self.seed, self.step_count, env.env_id0)
-        env.step_async(self.actions[t], self.rewards[t], self.dones[t])
-        env.accumulate_episode_stats(self.ep_stats)
+        _policy_and_draw(model, obs, logits, self.actions[t], self.seed, self.step_count, env.env_id0)
+        env.step_async(self.actions[t], self.rewards[t], self.dones[t], ep_acc=self.ep_stats)
         self.step_count += 1
 
     def _batch_view(self):
@@ -187,11 +194,7 @@ class ElasticDeviceRollout(DeviceRollout):
         k = l % self.S
         obs = env.elastic_obs(self._obs_step)
         logits = self.logits_lm[k]
-        if hasattr(model, 'policy_into'):
-            model.policy_into(obs, logits)
-        else:
-            logits.copy_(model.policy(obs))
-        ops.policy_sample_into(logits, self.actions_lm[k], self.seed, self.step_count, env.env_id0)
+        _policy_and_draw(model, obs, logits, self.actions_lm[k], self.seed, self.step_count, env.env_id0)
         # envs may start rows of batch `batch + 1` while batch `batch` is still open, not more
         env.step_elastic_async(self.actions_lm[k], l, (self.batch + 2) * self.T, 2 * self.T, self.T, self.rows_done,
                                self.row_launch, self.row_slot, self.finished, self.rewards_rows, self.dones_rows)
@@ -318,8 +321,7 @@ class DeviceA2CRollout(object):
             logits, values = model.policy_and_value(obs)
             self.values[t].copy_(values)
             ops.policy_sample_into(logits, self.actions[t], self.seed, self.step_count, env.env_id0)
-            env.step_async(self.actions[t], self.rewards[t], self.dones[t])
-            env.accumulate_episode_stats(self.ep_stats)
+            env.step_async(self.actions[t], self.rewards[t], self.dones[t], ep_acc=self.ep_stats)
             self.step_count += 1
         next_value = model.value(env.current_obs(self._obs_step))  # ignored where the last step was terminal
         adv, target = ops.gae(self.rewards, self.values, self.dones, next_value, self.gamma, self.lam)

@@ -226,3 +226,26 @@ def test_full_size_vector_matches_oracle_on_a_subset_of_envs(dev, oracle, game, 
     env.check_faults()
     if game == 'breakout':
         assert ndone >= 3  # life losses inside the window
+
+
+def test_step_with_folded_episode_stats_equals_separate_accumulation(dev):
+    """step_async(ep_acc=...) (MonitorEnv statistics inside the frame_post launch) == step_async() followed by
+    accumulate_episode_stats(): same frames, same statistics, on Breakout (episodes end inside the window)."""
+    from parl_amd.env import DeviceVectorEnv
+    E, T = 32, 400
+    envs = [DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=42, horizon=T, seed=3, device=dev) for _ in range(2)]
+    accs = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in range(2)]
+    g = torch.Generator(device=dev).manual_seed(1)
+    for e in envs:
+        e.reset()
+    for t in range(T):
+        a = torch.randint(0, envs[0].act_dim, (E, ), device=dev, generator=g)
+        envs[0].step_async(a, ep_acc=accs[0])
+        envs[1].step_async(a)
+        envs[1].accumulate_episode_stats(accs[1])
+    assert torch.equal(envs[0].ring, envs[1].ring) and torch.equal(envs[0].since, envs[1].since)
+    a0, a1 = accs[0].cpu().numpy(), accs[1].cpu().numpy()
+    assert a0[0] == a1[0] and a0[0] > 0 and a0[2] == a1[2]
+    np.testing.assert_allclose(a0[1], a1[1], rtol=1e-12)
+    for e in envs:
+        e.check_faults()

@@ -519,3 +519,27 @@ def test_impala_learn_fused_heads_equals_framework_heads(dev):
         assert abs(outs[0][1] - other[1]) <= 1e-4 * abs(outs[0][1]) + 1e-7
         for a, b in zip(outs[0][2], other[2]):
             assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize('B,A', [(1024, 6), (37, 4), (5, 18)])
+def test_policy_head_sample_equals_head_then_policy_sample(dev, B, A):
+    """parlhip_policy_head_sample_f32 (the actors' policy_fc + draw in one launch): logits against a float64 head
+    (1e-5 of scale), and the actions bit-exact against parlhip_policy_sample_f32 on the logits it wrote (same
+    Philox stream, same softmax / inverse-CDF arithmetic) — and through it against numpy's choice."""
+    from parl_amd import ops
+    torch.manual_seed(B + A)
+    h = torch.relu(torch.randn(B, 256, device=dev))
+    w, b = torch.randn(A, 256, device=dev) * 0.1, torch.randn(A, device=dev)
+    logits = torch.zeros(B, A, device=dev)
+    act = torch.zeros(B, dtype=torch.int64, device=dev)
+    assert ops.policy_head_sample_into(h, w, b, logits, act, seed=7, offset=3, row0=11)
+    ref = (h.double() @ w.double().t() + b.double()).cpu().numpy()
+    got = logits.cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    act2 = ops.policy_sample(logits, 7, 3, row0=11)
+    assert torch.equal(act, act2)
+    assert int(act.min()) >= 0 and int(act.max()) < A
+    # 512 hidden units: no instantiation, the caller falls back
+    assert not ops.policy_head_sample_into(torch.zeros(4, 512, device=dev), torch.zeros(A, 512, device=dev), b,
+                                           torch.zeros(4, A, device=dev), torch.zeros(4, dtype=torch.int64, device=dev),
+                                           1, 2)
