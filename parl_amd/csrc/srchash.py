@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 def source_files():
     fs = [f for f in glob.glob(os.path.join(HERE, '*.hip')) + glob.glob(os.path.join(HERE, '*.hpp'))
           if not f.endswith('.gen.hpp')]
-    fs += [os.path.join(HERE, 'gen_cart_native.py'), os.path.join(HERE, 'Makefile'),
+    fs += [os.path.join(HERE, 'gen_cart_native.py'), os.path.join(HERE, 'cart_branch_profile.json'),
+           os.path.join(HERE, 'Makefile'),
            os.path.join(ROOT, 'include', 'parl_hip.h')]
     fs += [f for f in (os.path.join(ROOT, 'roms', 'pong.bin'), os.path.join(ROOT, 'roms', 'breakout.bin'))
            if os.path.exists(f)]

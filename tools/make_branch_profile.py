@@ -1,0 +1,34 @@
+"""Dev tool (CPU only): taken / not-taken counts of every conditional branch of the cartridges from the oracle's
+instruction trace (tests/tools/oracle_profile.py [outdir=/tmp/prof] first) -> parl_amd/csrc/cart_branch_profile.json,
+which gen_cart_native.py turns into branch-probability hints.  Tuning data derived from a run of the user-supplied
+cartridges (like a compiler's PGO profile), keyed by the cartridge's CRC-32."""
+import collections
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+if __name__ == '__main__':
+    prof = sys.argv[1] if len(sys.argv) > 1 else '/tmp/prof'
+    out = {}
+    for name in ('pong', 'breakout'):
+        rom = open(os.path.join(ROOT, 'roms', name + '.bin'), 'rb').read()
+        tr = np.fromfile(os.path.join(prof, name + '.trace'), dtype=np.uint16).reshape(-1, 2)
+        pcs = tr[:, 0].astype(int)
+        nxt = np.roll(pcs, -1)
+        isbr = np.array([(rom[p & (len(rom) - 1)] & 0x1f) == 0x10 for p in range(65536)])
+        m = isbr[pcs]
+        m[-1] = False
+        bp, bn = pcs[m], nxt[m]
+        taken = bn != ((bp + 2) & 0xffff)
+        c = collections.defaultdict(lambda: [0, 0])
+        for p, t in zip(bp, taken):
+            c[int(p)][int(t)] += 1
+        out['%08x' % (zlib.crc32(rom) & 0xffffffff)] = {
+            'game': name, 'branches': {'%04x' % p: [v[0], v[1]] for p, v in sorted(c.items())}}
+    json.dump(out, open(os.path.join(ROOT, 'parl_amd', 'csrc', 'cart_branch_profile.json'), 'w'), indent=0)
+    print({k: len(v['branches']) for k, v in out.items()})
