@@ -10,6 +10,11 @@
  * routines are restated from OpenCV's published algorithm (imgproc/color_rgb.cpp RGB2Gray<uchar>
  * and imgproc/resize.cpp computeResizeAreaTab / ResizeArea_Invoker, 8UC1, non-integer scale):
  *   gray = (R*4899 + G*9617 + B*1868 + (1<<13)) >> 14
+ *     — the 14-bit coefficients of OpenCV <= 4.3 (yuv_shift = 14: R2Y = 4899, G2Y = 9617, B2Y = 1868), the
+ *     version the reference's CI pins (.teamcity/requirements.txt:3: opencv-python<=4.3.0.34).  OpenCV >= 4.4
+ *     uses 15 bits (9798 / 19235 / 3735, >> 15).  The two agree on every one of the 128 NTSC palette colours,
+ *     i.e. on every single frame; they differ by 1 on 12 of the 16,384 per-channel maxima of two palette
+ *     colours that MaxAndSkipEnv can produce (tests/test_frame_oracle_pin.py enumerates them).
  *   area resize: per-axis (src index, alpha) tap tables built in double and stored as float;
  *   for each source row: buf[dx] = sum_k S[sx_k]*alpha_k (float, in tap order);
  *   sum[dx] = beta_0*buf_0 (assignment) then += beta_j*buf_j; dst = saturate(cvRound(sum)).

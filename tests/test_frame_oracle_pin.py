@@ -116,3 +116,33 @@ def test_integer_factor_rows_agree_with_pil_box():
         pil = np.asarray(Image.fromarray(gray).resize((42, 42), Image.BOX)).astype(np.int64)
         assert np.abs(out.astype(np.int64) - pil).max() <= 1
         assert (out == out[:, :1]).all()
+
+
+def test_opencv_gray_variants_enumerated():
+    """frame_oracle.c restates the RGB2GRAY fixed point of OpenCV <= 4.3 (14-bit: 4899 / 9617 / 1868), the version the
+    reference's CI pins (.teamcity/requirements.txt:3); OpenCV >= 4.4 uses 15 bits (9798 / 19235 / 3735).  On what
+    this path can feed it — an NTSC palette colour, or the per-channel maximum of two of them (MaxAndSkipEnv,
+    atari_wrappers.py:239) — the variants agree on all 128 colours and differ (by exactly 1) on 12 of the 16,384
+    ordered pairs; the list is pinned here so that a change of either side shows up."""
+    import ctypes
+    pal = (ctypes.c_uint32 * 128)()
+    c_oracle.lib().oracle_palette(pal)
+    p = np.array(pal, dtype=np.uint32)
+    rgb = np.stack([(p >> 16) & 255, (p >> 8) & 255, p & 255], 1).astype(np.int64)
+
+    def g14(c):
+        return (c[..., 0] * 4899 + c[..., 1] * 9617 + c[..., 2] * 1868 + (1 << 13)) >> 14
+
+    def g15(c):
+        return (c[..., 0] * 9798 + c[..., 1] * 19235 + c[..., 2] * 3735 + (1 << 14)) >> 15
+
+    assert np.array_equal(g14(rgb), g15(rgb)), 'the variants agree on every palette colour'
+    mx = np.maximum(rgb[:, None, :], rgb[None, :, :])  # [128, 128, 3]
+    a, b = g14(mx), g15(mx)
+    diff = np.argwhere(a != b)
+    assert len(diff) == 12 and np.abs(a - b).max() == 1
+    pairs = sorted({tuple(sorted((int(i), int(j)))) for i, j in diff})
+    # unordered pairs of palette indices (colour byte = 2 * index)
+    assert pairs == [(5, 95), (23, 110), (52, 118), (59, 83), (66, 74), (69, 119)]
+    # the oracle itself is the 14-bit variant
+    assert np.array_equal(gray_ref(mx.astype(np.uint8)), a.astype(np.uint8))

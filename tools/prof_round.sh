@@ -1,0 +1,19 @@
+#!/bin/bash
+# GPU box: the round's whole evidence set into gpurun_out/<tag>/ (copy what is judged into profiles/).
+# Usage: tools/prof_round.sh <tag>
+TAG=${1:-rXX}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -1 $O/pytest_gpu.log
+bash tools/prof_bench.sh ${TAG}_bench > /dev/null 2>&1
+bash tools/prof_bench.sh ${TAG}_bench_quick --quick > /dev/null 2>&1
+bash tools/prof_traffic.sh > $O/traffic.log 2>&1
+bash tools/pmc_env.sh $O/env_pmc.log > /dev/null 2>&1
+(python tools/emu_bench.py PongNoFrameskip-v4 1024,4096; python tools/emu_bench.py BreakoutNoFrameskip-v4 1024,4096) 2>&1 | grep "E=" > $O/emu_bench.log
+python tools/microbench.py > $O/microbench_scans.json 2> $O/microbench.err
+python tools/learner_bench.py --json $O/learner_bench.json > $O/learner_bench.log 2>&1
+(bash tools/prof_heads_alone.sh tree; python tools/heads_beside_env.py; bash tools/pmc_heads.sh $O/heads_pmc_raw.log) > $O/heads_loss.log 2>&1
+(python tools/ref_batch_probe.py; python tools/actor_chain_probe.py 1024 42; python tools/actor_chain_probe.py 1024 84) 2>&1 | grep -v amdgpu > $O/learner_actor_probes.log
+ls $O
