@@ -4,8 +4,9 @@
     (benchmark/fluid/DQN_variant/rom_files/).  They are user-supplied DATA for the
     emulator (like ALE's ROM import), git-ignored, and travel to the GPU box with the snapshot.
   * oracle/_ref/a2c/{train,actor,atari_agent,atari_model,a2c_config}.py — the reference's own torch
-    A2C example scripts (benchmark/torch/a2c/), staged byte for byte so that the GPU box — which has
-    no /root/reference — can run them UNMODIFIED through compat/{parl,gym}
+    A2C example scripts (benchmark/torch/a2c/), and oracle/_ref/{impala,a2c_paddle}/ — its headline
+    examples (examples/IMPALA, examples/A2C: Paddle-flavoured), staged byte for byte so that the GPU box —
+    which has no /root/reference — can run them UNMODIFIED through compat/{paddle,parl,gym}
     (tests/test_reference_scripts.py).  oracle/_ref/ is git-ignored (never in history) but not
     gpurun-ignored, like the built .so files.
 
@@ -20,6 +21,9 @@ REF = '/root/reference'
 ROM_DIR = os.path.join(REF, 'benchmark/fluid/DQN_variant/rom_files')
 A2C_DIR = os.path.join(REF, 'benchmark/torch/a2c')
 A2C_SCRIPTS = ['train.py', 'actor.py', 'atari_agent.py', 'atari_model.py', 'a2c_config.py']
+# the reference's OWN (Paddle-flavoured) headline examples, run unmodified through compat/{paddle,parl,gym}
+EXAMPLES = {'impala': ('examples/IMPALA', ['train.py', 'actor.py', 'atari_agent.py', 'atari_model.py', 'impala_config.py']),
+            'a2c_paddle': ('examples/A2C', ['train.py', 'actor.py', 'atari_agent.py', 'atari_model.py', 'a2c_config.py'])}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MD5 = {'pong': '60e0ea3cbe0913d39803477945e9e5ec', 'breakout': 'f34f08e5eb96e500e851a80be3277a56'}
 
@@ -52,6 +56,14 @@ def main():
         for s in A2C_SCRIPTS:
             if copy_if_different(os.path.join(A2C_DIR, s), os.path.join(out, s)):
                 changed.append('oracle/_ref/a2c/' + s)
+    for name, (sub, files) in EXAMPLES.items():
+        src_dir = os.path.join(REF, sub)
+        if os.path.isdir(src_dir):
+            out = os.path.join(ROOT, 'oracle', '_ref', name)
+            os.makedirs(out, exist_ok=True)
+            for f in files:
+                if copy_if_different(os.path.join(src_dir, f), os.path.join(out, f)):
+                    changed.append('oracle/_ref/%s/%s' % (name, f))
     print('make_ref: ' + ('staged ' + ', '.join(changed) if changed else 'everything up to date'))
 
 

@@ -46,7 +46,8 @@ class A2C(Algorithm):
             self.grad_hook(self.model)
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=40.0)
         self.optimizer.step()
-        return total_loss, pi_loss, vf_loss, entropy
+        # values, not graph nodes: the reference's agents call `.cpu().numpy()` on them (examples/A2C/atari_agent.py:108)
+        return total_loss.detach(), pi_loss.detach(), vf_loss.detach(), entropy.detach()
 
     @torch.no_grad()
     def sample(self, obs):

@@ -301,7 +301,11 @@ class IMPALA(Algorithm):
         self._zero_grad()
         vtrace_loss.total_loss.backward()
         self._apply_gradients(learning_rate)
-        return vtrace_loss, kl
+        # what the caller gets are VALUES (the reference's agent does `.cpu().numpy()` on them,
+        # examples/IMPALA/atari_agent.py:69-73): nothing may still hang on the autograd graph
+        for k in ('total_loss', 'pi_loss', 'vf_loss', 'entropy'):
+            setattr(vtrace_loss, k, getattr(vtrace_loss, k).detach())
+        return vtrace_loss, kl.detach()
 
     def learn_batches(self, batches, learning_rate, entropy_coeff, time_major=False):
         """ONE parameter update on the union of several flat batches (dicts with the arguments of

@@ -1,4 +1,12 @@
-"""The reference's OWN torch A2C example — benchmark/torch/a2c/{train.py, actor.py, atari_agent.py,
+"""(1) The reference's OWN headline examples — examples/IMPALA/{train, actor, atari_model, atari_agent, impala_config}.py
+and examples/A2C/{...}.py, Paddle-flavoured — executed UNMODIFIED through compat/{paddle,parl,gym} in a subprocess
+(tests/tools/run_reference_example.py: their actor / learner threads never stop): `import paddle` resolves to the
+torch-backed alias of exactly the Paddle surface those files touch, `parl` / `gym` to parl_amd / the device env.
+Learner with its learn thread and DataLoader.from_generator reader, @parl.remote_class Actors stepping
+VectorEnv([wrap_deepmind(gym.make(...))]), np.random.choice sampling, parl.algorithms.IMPALA / A2C learn,
+get_weights / set_weights parameter sync, schedulers, MonitorEnv metrics: all the example's own code.
+
+(2) The reference's OWN torch A2C example — benchmark/torch/a2c/{train.py, actor.py, atari_agent.py,
 atari_model.py, a2c_config.py} — executed UNMODIFIED through the drop-in boundary:
 `import gym` / `import parl` resolve to compat/gym and compat/parl (aliases of parl_amd), and
     gym.make -> wrap_deepmind(dim, obs_format='NCHW') -> VectorEnv(envs).reset()/step()
@@ -144,3 +152,58 @@ def test_reference_torch_a2c_scripts_run_unmodified_on_the_device(dev, tmp_path,
     monkeypatch.setattr(torch.backends.cudnn, 'enabled', False)
     learner = _run_reference_a2c(d, monkeypatch, steps=3, env_num=4, actor_num=2, T=20)
     assert str(learner.device) == 'cuda'
+
+
+# ---- the reference's own (Paddle-flavoured) headline examples, unmodified, in a subprocess ----
+EXAMPLES = {'impala': ('/root/reference/examples/IMPALA', os.path.join(ROOT, 'oracle', '_ref', 'impala'),
+                       ['train.py', 'actor.py', 'atari_agent.py', 'atari_model.py', 'impala_config.py']),
+            'a2c_paddle': ('/root/reference/examples/A2C', os.path.join(ROOT, 'oracle', '_ref', 'a2c_paddle'),
+                           ['train.py', 'actor.py', 'atari_agent.py', 'atari_model.py', 'a2c_config.py'])}
+
+
+def _example_dir(kind, prefer_reference=True):
+    ref, staged, files = EXAMPLES[kind]
+    for d in ((ref, staged) if prefer_reference else (staged, ref)):
+        if all(os.path.exists(os.path.join(d, f)) for f in files):
+            return d
+    pytest.skip('needs the reference %s example (/root/reference or oracle/_ref staged by build())' % kind)
+
+
+def _run_example(kind, script_dir, extra, timeout):
+    import json
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'tools', 'run_reference_example.py'), kind,
+                        script_dir] + extra, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=timeout, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('RESULT ')]
+    assert p.returncode == 0 and len(lines) == 1, p.stdout[-4000:]
+    return json.loads(lines[0][7:])
+
+
+@pytest.mark.parametrize('kind', ['impala', 'a2c_paddle'])
+def test_staged_examples_are_the_reference_files_byte_for_byte(kind):
+    ref, staged, files = EXAMPLES[kind]
+    if not os.path.isdir(ref) or not os.path.isdir(staged):
+        pytest.skip('needs /root/reference and the staged copy (python __graft_entry__.py)')
+    for f in files:
+        assert open(os.path.join(staged, f), 'rb').read() == open(os.path.join(ref, f), 'rb').read(), f
+
+
+@pytest.mark.parametrize('kind', ['impala', 'a2c_paddle'])
+def test_reference_paddle_examples_run_unmodified_on_cpu_doubles(kind):
+    if not os.path.exists(os.path.join(ROOT, 'roms', 'pong.bin')):
+        pytest.skip('cartridge not provisioned')
+    out = _run_example(kind, _example_dir(kind), ['--cpu-doubles', '--steps', '2'], 600)
+    assert out['learn_steps'] >= 2 and out['weights_changed'] and np.isfinite(out['total_loss'])
+    assert out['lr'] > 0 and out['entropy_coeff'] == -0.01 and out['device'] == 'cpu'
+    if kind == 'impala':  # 2 actors x 2 envs x 10 steps per actor batch = the train batch of 40 rows
+        assert out['sample_total_steps'] >= 2 * 40 and out['total_params_sync'] >= 2 and np.isfinite(out['kl'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['impala', 'a2c_paddle'])
+def test_reference_paddle_examples_run_unmodified_on_the_device(kind):
+    out = _run_example(kind, _example_dir(kind, prefer_reference=False), ['--steps', '4'], 900)
+    assert out['learn_steps'] >= 4 and out['weights_changed'] and np.isfinite(out['total_loss'])
+    assert out['device'].startswith('cuda')
