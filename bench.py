@@ -304,7 +304,7 @@ def extra_legs(dev, only=None):
             from env_utils import ParallelEnv
             from mujoco_config import mujoco_config
             from mujoco_model import MujocoModel
-            from storage import RolloutStorage
+            from parl_amd.storage import RolloutStorage
         finally:
             sys.path.remove(ex)
         from parl_amd.algorithms import PPO

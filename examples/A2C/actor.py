@@ -5,7 +5,7 @@ import torch
 
 import parl_amd as parl
 from atari_agent import AtariAgent
-from atari_model import AtariModel
+from parl_amd.models import AtariModel84 as AtariModel  # torch twin of examples/A2C/atari_model.py:21-104
 from parl_amd.algorithms import A2C
 from parl_amd.env import DeviceVectorEnv
 from parl_amd.rollout import DeviceA2CRollout

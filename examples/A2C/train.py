@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import parl_amd as parl  # noqa: E402
 from actor import Actor  # noqa: E402
 from atari_agent import AtariAgent  # noqa: E402
-from atari_model import AtariModel  # noqa: E402
+from parl_amd.models import AtariModel84 as AtariModel  # noqa: E402  (torch twin of examples/A2C/atari_model.py:21-104)
 from parl_amd.algorithms import A2C  # noqa: E402
 from parl_amd.env import GAMES  # noqa: E402
 from parl_amd.utils import logger, summary  # noqa: E402

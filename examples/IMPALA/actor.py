@@ -8,7 +8,7 @@ import torch
 
 import parl_amd as parl
 from atari_agent import AtariAgent
-from atari_model import AtariModel
+from parl_amd.models import AtariModel42 as AtariModel  # torch twin of examples/IMPALA/atari_model.py:21-90
 from parl_amd.env import DeviceVectorEnv
 from parl_amd.rollout import DeviceRollout, ElasticDeviceRollout
 

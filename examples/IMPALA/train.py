@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import parl_amd as parl  # noqa: E402
 from actor import Actor  # noqa: E402
 from atari_agent import AtariAgent  # noqa: E402
-from atari_model import AtariModel  # noqa: E402
+from parl_amd.models import AtariModel42 as AtariModel  # noqa: E402  (torch twin of examples/IMPALA/atari_model.py:21-90)
 from parl_amd.env import GAMES  # noqa: E402
 from parl_amd.utils import logger, summary  # noqa: E402
 from parl_amd.utils.scheduler import PiecewiseScheduler  # noqa: E402

@@ -22,7 +22,7 @@ from atari_model import AtariModel  # noqa: E402
 from env_utils import ParallelEnv  # noqa: E402
 from mujoco_config import mujoco_config  # noqa: E402
 from mujoco_model import MujocoModel  # noqa: E402
-from storage import RolloutStorage  # noqa: E402
+from parl_amd.storage import RolloutStorage  # noqa: E402  (device twin of examples/PPO/storage.py)
 
 
 def main(args):

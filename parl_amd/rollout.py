@@ -9,6 +9,8 @@ Philox uniforms) -> DeviceVectorEnv.step_async (emulator + frame_post kernels) w
 dones straight into the [T,E] slabs of this buffer.  The batch handed to the learner is
 TIME-major ([t0 all envs, t1 all envs, ...]); IMPALA.learn(time_major=True) consumes it without
 a transpose (sum-reduced losses are order independent, impala.py:67-79)."""
+import os
+
 import torch
 
 from . import ops
@@ -417,6 +419,17 @@ class AsyncActorLearner(object):
             seqs = max(1, int(train_batch_size) // self.T)
             n = max(1, E // seqs)
             self.sub_batches = [(i * seqs, seqs if i < n - 1 else E - i * seqs) for i in range(n)]
+        # Mid-rollout weight refresh (train_batch_size mode, synchronous launches).  With n updates per rollout
+        # the actors' snapshot is n .. 2n updates old by the time its rows are learned from (1024 envs: 51 ..
+        # 102; the reference's 32 staggered actors fetch the current weights before every 50-step sample,
+        # train.py:176-191: a handful).  The learner is much faster than the rollout (51 updates in the time of
+        # ~20 env steps), so at step T/5 the actors pick up the weights after 2n/5 of this pass's updates and
+        # at step 2T/5 the weights after all n: 60 % of the rollout's rows then act with weights that are only
+        # as old as their own consumption delay.  [(env step, updates of the concurrent learner pass done)]
+        self.refresh_points = []
+        if self.sub_batches and not elastic and self.T >= 10 and int(os.environ.get('PARL_AMD_REFRESH', '1')):
+            n = len(self.sub_batches)
+            self.refresh_points = [(self.T // 5, max(1, (2 * n) // 5)), ((2 * self.T) // 5, n)]
         self._src = [p for p in alg.model.parameters()] + [b for b in alg.model.buffers()]
         self._dst = [p for p in self.actor_model.parameters()] + [b for b in self.actor_model.buffers()]
         cur = torch.cuda.current_stream(dev)
@@ -426,6 +439,9 @@ class AsyncActorLearner(object):
         self.weights_ready.record(cur)
         for e in self.batch_free:
             e.record(cur)
+        self._pub = [[t.detach().clone() for t in self._src] for _ in self.refresh_points]
+        self._pub_ready = [torch.cuda.Event() for _ in self.refresh_points]
+        self._pass_enqueued = False  # a learner pass (with its publications) was enqueued before this rollout
         self.graphed = {}
         if self.sub_batches:
             from .algorithms.impala.graphed import GraphedLearn
@@ -444,13 +460,20 @@ class AsyncActorLearner(object):
         reference's learner does (train.py:111-112)"""
         E = self.env.envs_num
         gl = None
-        for b0, nb in self.sub_batches:
+        ls = torch.cuda.current_stream(self.env.device)
+        for u, (b0, nb) in enumerate(self.sub_batches):
             gl = self.graphed[nb]
             gl.load(batch, b0, E)
             lr = learning_rate.step() if hasattr(learning_rate, 'step') else learning_rate
             ec = entropy_coeff.step() if hasattr(entropy_coeff, 'step') else entropy_coeff
             gl.replay(lr, ec)
             self.updates += 1
+            for i, (_, after) in enumerate(self.refresh_points):
+                if after == u + 1:  # publish the weights for the actors' mid-rollout refresh
+                    with torch.no_grad():
+                        torch._foreach_copy_(self._pub[i], self._src)
+                    self._pub_ready[i].record(ls)
+        self._pass_enqueued = True
         return _GraphedLoss(gl.out), gl.out[4]
 
     def pop_learn_stats(self):
@@ -486,7 +509,18 @@ class AsyncActorLearner(object):
                 st.wait_event(self.snapshot_done)
                 st.wait_event(self.batch_free[k])
                 ro.collect_begin()
-        if len(self.rollouts) == 1:
+        if len(self.rollouts) == 1 and self.refresh_points and self._pass_enqueued:
+            st, ro = self.actor_streams[0], self.rollouts[0]
+            at = {step: i for i, (step, _) in enumerate(self.refresh_points)}
+            with torch.cuda.stream(st):
+                for t in range(self.T):
+                    if t in at:  # the learner pass enqueued before this rollout published these weights
+                        st.wait_event(self._pub_ready[at[t]])
+                        with torch.no_grad():
+                            torch._foreach_copy_(self._dst, self._pub[at[t]])
+                    ro.collect_step(self.actor_model, t)
+            self._pass_enqueued = False
+        elif len(self.rollouts) == 1:
             with torch.cuda.stream(self.actor_streams[0]):
                 self.rollouts[0].collect_steps(self.actor_model)
         else:
