@@ -684,6 +684,10 @@ def main():
             del pipe, rollout, envs, env, model, alg  # free the headline's buffers before the extra legs
             torch.cuda.empty_cache()
             out.update(extra_legs(dev))
+            rb = out.get('impala_ref_batch', {})
+            if 'updates_per_s' in rb:  # the same workload with the reference's 1000-row learner updates (see the leg)
+                out['learner_updates_per_sec_at_reference_train_batch'] = rb['updates_per_s']
+                out['env_frames_per_sec_at_reference_train_batch'] = rb['env_frames_per_s']
         print(json.dumps(out))
 
 
