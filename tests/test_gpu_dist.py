@@ -61,3 +61,21 @@ def test_bench_data_parallel_path_over_rccl_with_one_rank():
     assert p.returncode == 0, p.stdout[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][0])
     assert out['n_gpus'] == 1 and out['value'] > 0 and 'RCCL' in out['config']['collectives']
+
+
+def test_bench_reference_train_batch_over_rccl_with_one_rank():
+    """the hipGraph updates in their data-parallel form (forward + backward graph | RCCL all-reduce | clip + Adam
+    graph) on the REAL backend: PARL_AMD_FORCE_DIST=1 creates a one-rank RCCL group, --train-batch makes every
+    rollout several graph-replayed updates with the all-reduce between the two graphs on the learner stream."""
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', PARL_AMD_FORCE_DIST='1',
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'PARL_AMD_SHARE_GPU', 'PARL_AMD_DIST_BACKEND'):
+        env.pop(k, None)
+    cmd = [sys.executable, 'bench.py', '--gpus', '1', '--steps', '3', '--warmup', '1', '--envs', '32',
+           '--sample-batch-steps', '10', '--train-batch', '80', '--no-cpu-baseline', '--quick']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    out = json.loads(line[0])
+    assert 'RCCL' in out['config']['collectives'] and out['config']['learner_updates_per_step'] == 4
+    assert out['learner_updates_per_sec'] > 0 and out['value'] > 0
