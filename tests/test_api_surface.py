@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 import parl_amd as parl
+from conftest import ROOT
 from parl_amd.remote import FutureGetRepeatedlyError, RemoteError
 
 
@@ -332,3 +333,42 @@ def test_ppo_learn_host_logic_matches_reference_fixture(case, monkeypatch):
     prefix = case + '/final/'
     for k, v in alg.model.state_dict().items():
         np.testing.assert_allclose(v.numpy(), z[prefix + k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def test_compat_paddle_surface_used_by_the_reference_examples():
+    """compat/paddle: exactly what examples/IMPALA/*.py and examples/A2C/*.py import from Paddle, on torch"""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'compat'))
+    try:
+        for m in [k for k in sys.modules if k == 'paddle' or k.startswith('paddle.')]:
+            del sys.modules[m]
+        paddle = importlib.import_module('paddle')
+        nn = importlib.import_module('paddle.nn')
+        F = importlib.import_module('paddle.nn.functional')
+    finally:
+        sys.path.remove(os.path.join(ROOT, 'compat'))
+    assert paddle.__file__.startswith(os.path.join(ROOT, 'compat'))
+    x = paddle.to_tensor(np.arange(12, dtype=np.float64).reshape(3, 4), dtype='float32')
+    assert isinstance(x, torch.Tensor) and x.dtype == torch.float32 and tuple(x.shape) == (3, 4)
+    assert paddle.to_tensor(np.array([1, 0], dtype=np.int32), dtype='int64').dtype == torch.int64
+    assert paddle.to_tensor(np.array([True, False]), dtype='bool').dtype == torch.bool
+    assert tuple(paddle.squeeze(torch.zeros(5, 1), axis=1).shape) == (5, )
+    conv = nn.Conv2D(in_channels=4, out_channels=16, kernel_size=4, stride=2, padding=1)
+    fc = nn.Linear(in_features=256, out_features=6,
+                   weight_attr=paddle.ParamAttr(initializer=paddle.nn.initializer.Normal()),
+                   bias_attr=paddle.ParamAttr(initializer=paddle.nn.initializer.Normal()))
+    assert tuple(conv.weight.shape) == (16, 4, 4, 4) and tuple(fc.weight.shape) == (6, 256)
+    assert 0.8 < float(fc.weight.std()) < 1.2  # Normal() = N(0, 1), atari_model.py:44-57
+    y = F.relu(conv(torch.zeros(2, 4, 42, 42, device=conv.weight.device)))
+    assert tuple(y.shape) == (2, 16, 21, 21) and tuple(nn.Flatten()(y).shape) == (2, 16 * 21 * 21)
+    loader = paddle.io.DataLoader.from_generator(capacity=5)
+    loader.set_batch_generator(lambda: iter([[np.zeros(2)], [np.ones(2)]]))
+    assert [float(b[0].sum()) for b in loader()] == [0.0, 2.0]
+
+
+def test_machine_info():
+    from parl_amd.utils import machine_info
+    assert machine_info.get_gpu_count() == (torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    assert machine_info.is_gpu_available() == (machine_info.get_gpu_count() > 0)
+    assert machine_info.is_port_available(int(machine_info.get_free_tcp_port()))
