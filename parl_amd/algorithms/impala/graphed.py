@@ -134,6 +134,29 @@ class GraphedLearn(object):
         for g in opt.param_groups:
             g['lr'].zero_()
         acc0 = self.acc.clone()
+        try:
+            self._warm_up_and_capture(dev)
+        finally:  # also when the capture fails: never leave the optimizer with lr = 0 and warm-up state
+            torch.cuda.synchronize(dev)
+            with torch.no_grad():
+                for p, s in zip(params, saved_p):
+                    p.copy_(s)
+                for p in params:
+                    st = opt.state.get(p, {})
+                    for k, v in st.items():
+                        if isinstance(v, torch.Tensor):
+                            if p in had_state and k in had_state[p]:
+                                v.copy_(had_state[p][k])
+                            else:
+                                v.zero_()
+                for g, lr in zip(opt.param_groups, lrs):
+                    g['lr'].copy_(lr)
+                    g.pop('_lr_value', None)
+                self.acc.copy_(acc0)
+            torch.cuda.synchronize(dev)
+
+    def _warm_up_and_capture(self, dev):
+        alg = self.alg
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(cur)
@@ -163,22 +186,6 @@ class GraphedLearn(object):
             self.graphs = [g1]
         if self.pool is None:
             self.pool = g1.pool()
-        with torch.no_grad():
-            for p, s in zip(params, saved_p):
-                p.copy_(s)
-            for p in params:
-                st = opt.state.get(p, {})
-                for k, v in st.items():
-                    if isinstance(v, torch.Tensor):
-                        if p in had_state and k in had_state[p]:
-                            v.copy_(had_state[p][k])
-                        else:
-                            v.zero_()
-            for g, lr in zip(opt.param_groups, lrs):
-                g['lr'].copy_(lr)
-                g.pop('_lr_value', None)
-            self.acc.copy_(acc0)
-        torch.cuda.synchronize(dev)
 
     # ---- per update --------------------------------------------------------------------------
     def load(self, batch, b0, E):
