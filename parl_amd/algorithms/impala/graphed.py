@@ -23,7 +23,7 @@ issues (tests/test_gpu_graphed.py compares parameters and losses of both over se
 """
 import torch
 
-__all__ = ['GraphedLearn', 'make_capturable']
+__all__ = ['GraphedLearn', 'make_capturable', 'load_optimizer_state_inplace']
 
 
 def make_capturable(optimizer, device):
@@ -48,6 +48,35 @@ def set_lr(optimizer, lr):
                 g['_lr_value'] = lr
         else:
             g['lr'] = lr
+
+
+def load_optimizer_state_inplace(optimizer, state_dict):
+    """optimizer.load_state_dict for an optimizer whose state a captured graph refers to BY ADDRESS: the
+    checkpoint's tensors are copied into the existing state tensors (torch's load_state_dict replaces them,
+    after which a replay would keep updating the old ones).  The learning rate is restored into the device
+    scalar.  State that does not exist yet (no step taken) is created by a normal load."""
+    if not optimizer.state:
+        optimizer.load_state_dict(state_dict)
+        dev = next(p for g in optimizer.param_groups for p in g['params']).device
+        make_capturable(optimizer, dev)
+        return
+    params = [p for g in optimizer.param_groups for p in g['params']]
+    ids = [i for g in state_dict['param_groups'] for i in g['params']]
+    assert len(ids) == len(params), 'optimizer / checkpoint parameter counts differ'
+    with torch.no_grad():
+        for p, i in zip(params, ids):
+            src, dst = state_dict['state'].get(i, {}), optimizer.state[p]
+            for k, v in dst.items():
+                if isinstance(v, torch.Tensor):
+                    v.copy_(torch.as_tensor(src[k]).to(device=v.device, dtype=v.dtype))
+        for g, sg in zip(optimizer.param_groups, state_dict['param_groups']):
+            lr = sg['lr']
+            set_lr(optimizer if len(optimizer.param_groups) == 1 else _one_group(g), float(lr))
+
+
+class _one_group(object):
+    def __init__(self, g):
+        self.param_groups = [g]
 
 
 class GraphedLearn(object):

@@ -103,3 +103,55 @@ def test_async_pipeline_with_reference_train_batch(dev):
     means, n = pipe.pop_learn_stats()
     assert n == 5 and np.isfinite(means).all()
     env.check_faults()
+
+
+def test_graphed_pipeline_checkpoint_resumes_bit_identically(dev):
+    """train_batch_size mode: the optimizer state lives at addresses the captured graphs hold, so a resume copies
+    the checkpoint INTO it (graphed.load_optimizer_state_inplace) — save after two steps, two more steps, restore,
+    the same two steps again: every parameter bit-identical (envs, samplers, pending batch, actor snapshot from
+    AsyncActorLearner.state_dict; mid-rollout weight refresh active)."""
+    import parl_amd as parl
+    from parl_amd.algorithms.impala.graphed import load_optimizer_state_inplace
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel42
+    from parl_amd.rollout import AsyncActorLearner
+    from parl_amd.utils import PiecewiseScheduler
+    torch.manual_seed(2)
+    T, E = 10, 12
+    env = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=42, horizon=T, seed=13, device=dev)
+    model = AtariModel42(env.act_dim).to(dev)
+    with torch.no_grad():
+        model.policy_fc.weight.mul_(0.05)
+        model.value_fc.weight.mul_(0.05)
+    alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
+                                 clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+    pipe = AsyncActorLearner(alg, [env], T, seed=3, train_batch_size=4 * T)
+    assert pipe.refresh_points == [(2, 1), (4, 3)] and len(pipe.sub_batches) == 3
+    lr_s = PiecewiseScheduler([(0, 1e-3), (7, 5e-4)])
+    for _ in range(2):
+        pipe.step(lr_s, -0.01)
+    sd_pipe = pipe.state_dict()
+    sd_model = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    osd = alg.optimizer.state_dict()
+    sd_opt = {'state': {i: {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in st.items()}
+                        for i, st in osd['state'].items()},
+              'param_groups': [{k: (float(v) if isinstance(v, torch.Tensor) else v) for k, v in g.items()}
+                               for g in osd['param_groups']]}
+    lr_state = (lr_s.cur_index, lr_s.cur_step, lr_s.cur_value)
+
+    def run():
+        for _ in range(2):
+            pipe.step(lr_s, -0.01)
+        pipe.synchronize()
+        return [p.detach().clone() for p in model.parameters()]
+
+    p1 = run()
+    assert any(not torch.equal(a, b) for a, b in zip(p1, sd_model.values()))
+    model.load_state_dict(sd_model)
+    load_optimizer_state_inplace(alg.optimizer, sd_opt)
+    pipe.load_state_dict(sd_pipe)
+    lr_s.cur_index, lr_s.cur_step, lr_s.cur_value = lr_state
+    p2 = run()
+    for a, b in zip(p1, p2):
+        assert torch.equal(a, b)
+    env.check_faults()
