@@ -244,7 +244,8 @@ def extra_legs(dev, only=None):
                             (len(pipe.sub_batches), pipe.sub_batches[-1][1]),
                 'env_frames_per_s': K * T * E * 4 / dt, 'updates_per_s': (pipe.updates - u0) / dt,
                 'updates_per_rollout': len(pipe.sub_batches), 'rows_per_update': 1000, 'ms_per_step': dt / K * 1e3,
-                'steps': K, 'update_alone_ms': rep * 1e3, 'mean_losses_total_pi_vf_entropy_kl': stats}
+                'steps': K, 'update_alone_ms': rep * 1e3, 'mean_losses_total_pi_vf_entropy_kl': stats,
+                'actor_weight_refresh_points (env step, updates of the concurrent pass done)': [list(x) for x in pipe.refresh_points]}
 
     # ---- configs[3] per GPU: Breakout IMPALA, 1024 of the 8192 actors, A=4 ----
     def breakout_c4():
@@ -568,6 +569,7 @@ def main():
             'actor_learner_overlap': not args.no_overlap, 'actor_groups': G, 'elastic_launches': elastic,
             'learner_rows_per_pass': args.learn_rows or T * E,
             'learner_updates_per_step': len(pipe.sub_batches) if (pipe is not None and pipe.sub_batches) else 1,
+            'actor_weight_refresh_points': [list(x) for x in pipe.refresh_points] if pipe is not None else [],
             'env_ids_per_rank': [[r * E, r * E + E - 1] for r in range(world)],
             'collectives': (('none (single process)' if not pdist.active() else 'RCCL, one-rank group (PARL_AMD_FORCE_DIST)')
                             if world == 1 else

@@ -372,13 +372,17 @@ class AsyncActorLearner(object):
     the role of the reference actor's `set_weights` (actor.py:103-104): it is refreshed from the
     learner before every rollout, so the behaviour policy lags the learner by exactly one update."""
 
-    def __init__(self, alg, envs, sample_batch_steps, seed=0, elastic=False, train_batch_size=None):
+    def __init__(self, alg, envs, sample_batch_steps, seed=0, elastic=False, train_batch_size=None,
+                 refresh_points='auto'):
         """elastic: ElasticDeviceRollout (one env group; the env's horizon is the launch bound of a batch).
         train_batch_size: the reference's learner batch in ROWS (impala_config.py:31: 1000 = 20 sequences of
         T = 50; the learner concatenates actor batches until it holds at least that many, train.py:98).  None:
         one update per step() on the whole T*E rollout.  Otherwise step() runs E // (train_batch_size // T)
         updates, each on the next `train_batch_size // T` sequences of the rollout (the last one takes the
-        remainder as well), every update one hipGraph replay (algorithms.impala.graphed.GraphedLearn)."""
+        remainder as well), every update one hipGraph replay (algorithms.impala.graphed.GraphedLearn).
+        refresh_points (train_batch_size mode): the actors' mid-rollout weight refresh, see below — 'auto'
+        (calibrated from the measured speed of learner pass and rollout), an explicit list of (env step,
+        updates of the concurrent pass done) pairs (deterministic: checkpoints, tests), or None / [] (off)."""
         import copy
         self.alg = alg
         self.envs = list(envs) if isinstance(envs, (list, tuple)) else [envs]
@@ -422,14 +426,23 @@ class AsyncActorLearner(object):
         # Mid-rollout weight refresh (train_batch_size mode, synchronous launches).  With n updates per rollout
         # the actors' snapshot is n .. 2n updates old by the time its rows are learned from (1024 envs: 51 ..
         # 102; the reference's 32 staggered actors fetch the current weights before every 50-step sample,
-        # train.py:176-191: a handful).  The learner is much faster than the rollout (51 updates in the time of
-        # ~20 env steps), so at step T/5 the actors pick up the weights after 2n/5 of this pass's updates and
-        # at step 2T/5 the weights after all n: 60 % of the rollout's rows then act with weights that are only
-        # as old as their own consumption delay.  [(env step, updates of the concurrent learner pass done)]
+        # train.py:176-191: a handful).  At 42x42 the learner is much faster than the rollout (its 51 updates take
+        # the time of ~20 env steps), so the actors pick newer weights up INSIDE the rollout: at env step s they
+        # wait for (an event after) update u(s) of the concurrent pass and copy what the learner published
+        # there.  u(s) must be something the learner has long passed when the actors reach step s — at 84x84
+        # learner and rollout take equally long, waiting for "40 % of the updates at 20 % of the rollout"
+        # stalled the actors (1.67 -> 1.36 M frames/s) — so 'auto' measures both once (the second step's learner
+        # pass and rollout, HIP events) and asks at steps T/5, 2T/5, 3T/5 for 60 % of the updates the learner is
+        # then expected to have done.  [(env step, updates of the concurrent learner pass done)]
         self.refresh_points = []
-        if self.sub_batches and not elastic and self.T >= 10 and int(os.environ.get('PARL_AMD_REFRESH', '1')):
-            n = len(self.sub_batches)
-            self.refresh_points = [(self.T // 5, max(1, (2 * n) // 5)), ((2 * self.T) // 5, n)]
+        self._refresh_auto = False
+        self._calib = None
+        can = bool(self.sub_batches and not elastic and self.T >= 10 and int(os.environ.get('PARL_AMD_REFRESH', '1')))
+        if can and refresh_points == 'auto':
+            self._refresh_auto = True
+        elif can and refresh_points:
+            self.refresh_points = sorted((int(a), int(b)) for a, b in refresh_points)
+            assert all(0 < a < self.T and 0 < b <= len(self.sub_batches) for a, b in self.refresh_points)
         self._src = [p for p in alg.model.parameters()] + [b for b in alg.model.buffers()]
         self._dst = [p for p in self.actor_model.parameters()] + [b for b in self.actor_model.buffers()]
         cur = torch.cuda.current_stream(dev)
@@ -439,8 +452,9 @@ class AsyncActorLearner(object):
         self.weights_ready.record(cur)
         for e in self.batch_free:
             e.record(cur)
-        self._pub = [[t.detach().clone() for t in self._src] for _ in self.refresh_points]
-        self._pub_ready = [torch.cuda.Event() for _ in self.refresh_points]
+        n_pub = 3 if self._refresh_auto else len(self.refresh_points)
+        self._pub = [[t.detach().clone() for t in self._src] for _ in range(n_pub)]
+        self._pub_ready = [torch.cuda.Event() for _ in range(n_pub)]
         self._pass_enqueued = False  # a learner pass (with its publications) was enqueued before this rollout
         self.graphed = {}
         if self.sub_batches:
@@ -454,6 +468,31 @@ class AsyncActorLearner(object):
                         pool = self.graphed[nb].pool
             self.learn_stream.synchronize()
 
+    def _calibrate_refresh(self):
+        """'auto' refresh points: step 1 runs plain (graphs and caches warm up), step 2 is timed (learner pass and
+        rollout, overlapped as always), step 3 reads the two durations (one host wait, once) and fixes the points"""
+        self._steps_seen = getattr(self, '_steps_seen', 0) + 1
+        if self._steps_seen == 2:
+            self._calib = {}
+        elif self._steps_seen == 3 and self._calib and 'r1' in self._calib and 'l1' in self._calib:
+            self._calib['r1'].synchronize()
+            self._calib['l1'].synchronize()
+            L = self._calib['l0'].elapsed_time(self._calib['l1'])
+            R = self._calib['r0'].elapsed_time(self._calib['r1'])
+            n, T = len(self.sub_batches), self.T
+            pts, last = [], 0
+            for s_ in (T // 5, (2 * T) // 5, (3 * T) // 5):
+                u = min(n, int(0.6 * n * (s_ * R / T) / max(L, 1e-6)))
+                if u >= max(2, n // 10) and u > last:
+                    pts.append((s_, u))
+                    last = u
+                if last >= n:
+                    break
+            self.refresh_points = pts
+            self.refresh_calibration = {'learner_pass_ms': L, 'rollout_ms': R}
+            self._calib = None
+            self._refresh_auto = False
+
     def _learn_sub_batches(self, batch, learning_rate, entropy_coeff):
         """the rollout as E // seqs updates of the reference's train_batch_size (on the learner stream);
         learning_rate / entropy_coeff: floats, or schedulers whose step() is called once per update as the
@@ -461,6 +500,9 @@ class AsyncActorLearner(object):
         E = self.env.envs_num
         gl = None
         ls = torch.cuda.current_stream(self.env.device)
+        if self._refresh_auto and self._calib is not None and 'l0' not in self._calib:
+            self._calib['l0'] = torch.cuda.Event(enable_timing=True)
+            self._calib['l0'].record(ls)
         for u, (b0, nb) in enumerate(self.sub_batches):
             gl = self.graphed[nb]
             gl.load(batch, b0, E)
@@ -473,6 +515,9 @@ class AsyncActorLearner(object):
                     with torch.no_grad():
                         torch._foreach_copy_(self._pub[i], self._src)
                     self._pub_ready[i].record(ls)
+        if self._refresh_auto and self._calib is not None and 'l1' not in self._calib:
+            self._calib['l1'] = torch.cuda.Event(enable_timing=True)
+            self._calib['l1'].record(ls)
         self._pass_enqueued = True
         return _GraphedLoss(gl.out), gl.out[4]
 
@@ -509,7 +554,17 @@ class AsyncActorLearner(object):
                 st.wait_event(self.snapshot_done)
                 st.wait_event(self.batch_free[k])
                 ro.collect_begin()
-        if len(self.rollouts) == 1 and self.refresh_points and self._pass_enqueued:
+        if self._refresh_auto and self._calib is not None and 'r0' not in self._calib and self._pass_enqueued:
+            # calibration rollout: timed, not refreshed
+            st = self.actor_streams[0]
+            with torch.cuda.stream(st):
+                self._calib['r0'] = torch.cuda.Event(enable_timing=True)
+                self._calib['r0'].record(st)
+                self.rollouts[0].collect_steps(self.actor_model)
+                self._calib['r1'] = torch.cuda.Event(enable_timing=True)
+                self._calib['r1'].record(st)
+            self._pass_enqueued = False
+        elif len(self.rollouts) == 1 and self.refresh_points and self._pass_enqueued:
             st, ro = self.actor_streams[0], self.rollouts[0]
             at = {step: i for i, (step, _) in enumerate(self.refresh_points)}
             with torch.cuda.stream(st):
@@ -549,6 +604,8 @@ class AsyncActorLearner(object):
         `wait_outputs()` (or `synchronize()`)."""
         self.prime()
         batches, k = self.pending
+        if self._refresh_auto:
+            self._calibrate_refresh()
         # the snapshot for the next rollout is taken first; the learner may not touch the
         # parameters before it is done
         self._snapshot()
@@ -589,7 +646,8 @@ class AsyncActorLearner(object):
         torch.cuda.synchronize(self.env.device)
         d = {'envs': [e.state_dict() for e in self.envs], 'rollouts': [r.state_dict() for r in self.rollouts],
              'actor_model': {k: v.detach().cpu().clone() for k, v in self.actor_model.state_dict().items()},
-             'updates': self.updates, 'pending': None}
+             'updates': self.updates, 'pending': None,
+             'refresh_points': [list(x) for x in self.refresh_points], 'refresh_auto': bool(self._refresh_auto)}
         if self.pending is not None:
             k = self.pending[1]
             d['pending'] = {'k': k, 'buffers': [r.buffer_state(k) for r in self.rollouts]}
@@ -604,6 +662,10 @@ class AsyncActorLearner(object):
             r.load_state_dict(s)
         self.actor_model.load_state_dict(d['actor_model'])
         self.updates = int(d['updates'])
+        if 'refresh_points' in d and not d.get('refresh_auto', False) and len(d['refresh_points']) <= len(self._pub):
+            self.refresh_points = [tuple(x) for x in d['refresh_points']]  # a calibrated run resumes with its points
+            self._refresh_auto, self._calib = False, None
+        self._pass_enqueued = False
         self.pending = None
         if d['pending'] is not None:
             k = int(d['pending']['k'])

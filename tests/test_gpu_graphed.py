@@ -125,7 +125,8 @@ def test_graphed_pipeline_checkpoint_resumes_bit_identically(dev):
         model.value_fc.weight.mul_(0.05)
     alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
                                  clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
-    pipe = AsyncActorLearner(alg, [env], T, seed=3, train_batch_size=4 * T)
+    # explicit refresh points: deterministic (the default 'auto' calibrates them from measured timings)
+    pipe = AsyncActorLearner(alg, [env], T, seed=3, train_batch_size=4 * T, refresh_points=[(2, 1), (4, 3)])
     assert pipe.refresh_points == [(2, 1), (4, 3)] and len(pipe.sub_batches) == 3
     lr_s = PiecewiseScheduler([(0, 1e-3), (7, 5e-4)])
     for _ in range(2):
