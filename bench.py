@@ -206,10 +206,34 @@ def extra_legs(dev, only=None):
         dt = time.time() - t0
         assert np.isfinite(float(loss.total_loss))
         env.check_faults()
-        return {'workload': 'PongNoFrameskip-v4 IMPALA V-trace at 84x84 (the north-star frame size), 1024 actors, T=50, '
-                            'actor/learner overlapped; ONE update per step on the 51,200-row batch (8 chunks accumulated); convolutions of actors '
-                            'and learner on the MFMA kernels (conv1_84 / conv23_84 forward, three backward kernels)',
-                'env_frames_per_s': K * T * E * 4 / dt, 'updates_per_s': K / dt, 'ms_per_step': dt / K * 1e3, 'steps': K}
+        res = {'workload': 'PongNoFrameskip-v4 IMPALA V-trace at 84x84 (the north-star frame size), 1024 actors, T=50, '
+                           'actor/learner overlapped; ONE update per step on the 51,200-row batch (8 chunks accumulated); convolutions of actors '
+                           'and learner on the MFMA kernels (conv1_84 / conv23_84 forward, three backward kernels)',
+               'env_frames_per_s': K * T * E * 4 / dt, 'updates_per_s': K / dt, 'ms_per_step': dt / K * 1e3, 'steps': K}
+        # the same with the reference's 1000-row learner updates (hipGraph replays, mid-rollout weight refresh)
+        del pipe, alg, model, env
+        torch.cuda.empty_cache()
+        env = DeviceVectorEnv('PongNoFrameskip-v4', E, dim=84, horizon=T, seed=8, device=dev)
+        model = AtariModel84(env.act_dim).to(dev)
+        alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
+                                     clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+        pipe = AsyncActorLearner(alg, [env], T, seed=4, train_batch_size=1000)
+        pipe.prime()
+        for _ in range(3):  # warm-up + the refresh calibration
+            pipe.step(0.001, -0.01)
+        pipe.synchronize()
+        u0, t0 = pipe.updates, time.time()
+        for _ in range(K + 1):
+            loss, kl = pipe.step(0.001, -0.01)
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        assert np.isfinite(float(loss.total_loss))
+        env.check_faults()
+        res['train_batch_1000'] = {'env_frames_per_s': (K + 1) * T * E * 4 / dt, 'updates_per_s': (pipe.updates - u0) / dt,
+                                   'ms_per_step': dt / (K + 1) * 1e3,
+                                   'actor_weight_refresh_points': [list(x) for x in pipe.refresh_points]}
+        return res
 
     # ---- configs[2] at the REFERENCE's learner batch: train_batch_size = 1000 rows per update ----
     def impala_ref_batch():
@@ -222,7 +246,8 @@ def extra_legs(dev, only=None):
         lr_s = parl.utils.PiecewiseScheduler([(0, 0.001), (20000, 0.0005), (40000, 0.0001)])
         ent_s = parl.utils.PiecewiseScheduler([(0, -0.01)])
         pipe.prime()
-        pipe.step(lr_s, ent_s)
+        for _ in range(3):  # warm-up + the calibration of the actors' refresh points
+            pipe.step(lr_s, ent_s)
         pipe.synchronize()
         u0, t0 = pipe.updates, time.time()
         for _ in range(K):
