@@ -10,7 +10,6 @@ list-of-numpy view the reference's actor.py expects.
 
 All compute goes through the C ABI (include/parl_hip.h); there is no CPU fallback.
 """
-import ctypes
 import hashlib
 import os
 

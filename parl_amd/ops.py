@@ -4,7 +4,6 @@ Every function takes HIP-resident torch tensors, enqueues the hand-written gfx95
 torch's current stream and returns torch tensors.  Nothing here computes on the host and
 nothing falls back: a CPU tensor or a missing library raises ``ParlHipError``/``ImportError``.
 """
-import math
 
 import torch
 
