@@ -13,11 +13,17 @@ Semantics kept: `to_tensor(x, dtype=...)` returns a tensor on the default device
 GPU when there is one); layers create their parameters there too; `Normal()` is N(0, 1)
 (paddle.nn.initializer.Normal defaults); `Conv2D` is this repository's GEMM-lowered convolution (the image ships
 no MIOpen kernel database for gfx950).  Parameter LAYOUT differs from Paddle's for `Linear` (torch keeps
-[out, in]) — invisible to the examples, which exchange weights only between their own models."""
+[out, in]) — invisible to the examples, which exchange weights only between their own models.
+
+`paddle.nn`, `paddle.nn.functional`, `paddle.nn.initializer` and `paddle.io` are module objects built here
+(registered in sys.modules so that `import paddle.nn.functional as F` works)."""
+import sys
+import types
+
 import numpy as np
 import torch
 
-from . import io, nn  # noqa: F401
+from parl_amd.models.atari_model import GemmConv2d
 
 __version__ = '2.3.1'  # the reference CI's Paddle (.teamcity/build.sh:208)
 
@@ -36,10 +42,7 @@ def _dtype(dtype):
 
 
 def to_tensor(data, dtype=None, place=None, stop_gradient=True):
-    if isinstance(data, torch.Tensor):
-        t = data
-    else:
-        t = torch.from_numpy(np.ascontiguousarray(data))
+    t = data if isinstance(data, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(data))
     return t.to(device=_device(), dtype=_dtype(dtype))
 
 
@@ -54,3 +57,83 @@ class ParamAttr(object):
 
 no_grad = torch.no_grad
 Tensor = torch.Tensor
+
+
+# ---- paddle.nn.initializer ----
+class Normal(object):
+    """paddle.nn.initializer.Normal(mean=0.0, std=1.0)"""
+
+    def __init__(self, mean=0.0, std=1.0):
+        self.mean, self.std = mean, std
+
+    def __call__(self, tensor):
+        torch.nn.init.normal_(tensor, self.mean, self.std)
+
+
+def _apply(attr, tensor):
+    init = getattr(attr, 'initializer', None) if attr is not None else None
+    if init is not None:
+        with torch.no_grad():
+            init(tensor)
+
+
+# ---- paddle.nn ----
+class Conv2D(GemmConv2d):
+    """paddle.nn.Conv2D(in_channels, out_channels, kernel_size, stride=1, padding=0, ...)"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, weight_attr=None, bias_attr=None):
+        super(Conv2D, self).__init__(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                                     device=_device())
+        _apply(weight_attr, self.weight)
+        _apply(bias_attr, self.bias)
+
+
+class Linear(torch.nn.Linear):
+    """paddle.nn.Linear(in_features, out_features, weight_attr=None, bias_attr=None)"""
+
+    def __init__(self, in_features, out_features, weight_attr=None, bias_attr=None, name=None):
+        super(Linear, self).__init__(in_features, out_features, device=_device())
+        _apply(weight_attr, self.weight)
+        _apply(bias_attr, self.bias)
+
+
+# ---- paddle.io ----
+class _GeneratorLoader(object):
+    """paddle.io.DataLoader.from_generator as examples/IMPALA/train.py:129-133 uses it: a bounded prefetch queue in
+    front of a batch generator.  Here the generator is simply iterated (its batches are numpy arrays that
+    agent.learn uploads itself, atari_agent.py:58-63); the learner thread blocks in the generator's own queue."""
+
+    def __init__(self, capacity):
+        self.capacity = capacity
+        self._reader = None
+
+    def set_batch_generator(self, reader, places=None):
+        self._reader = reader
+        return self
+
+    def __call__(self):
+        return iter(self._reader())
+
+    __iter__ = __call__
+
+
+class DataLoader(object):
+    @staticmethod
+    def from_generator(feed_list=None, capacity=None, use_double_buffer=True, iterable=True, return_list=False,
+                       use_multiprocess=False, drop_last=True):
+        return _GeneratorLoader(capacity)
+
+
+def _module(name, **members):
+    m = types.ModuleType(name)
+    m.__dict__.update(members)
+    sys.modules[name] = m
+    return m
+
+
+_functional = _module('paddle.nn.functional', relu=torch.nn.functional.relu, softmax=torch.nn.functional.softmax,
+                      log_softmax=torch.nn.functional.log_softmax)
+_initializer = _module('paddle.nn.initializer', Normal=Normal)
+nn = _module('paddle.nn', Layer=torch.nn.Module, Flatten=torch.nn.Flatten, Conv2D=Conv2D, Linear=Linear,
+             functional=_functional, initializer=_initializer)
+io = _module('paddle.io', DataLoader=DataLoader)

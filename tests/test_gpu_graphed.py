@@ -156,3 +156,37 @@ def test_graphed_pipeline_checkpoint_resumes_bit_identically(dev):
     for a, b in zip(p1, p2):
         assert torch.equal(a, b)
     env.check_faults()
+
+
+def test_refresh_points_are_calibrated_after_the_second_step(dev):
+    """refresh_points='auto' (the default): step 2 is timed, step 3 fixes the points — at most three, at env steps
+    T/5, 2T/5, 3T/5, each asking for no more updates than a pass has, increasing; the pipeline keeps running and
+    the calibrated points travel in its state_dict"""
+    import parl_amd as parl
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel42
+    from parl_amd.rollout import AsyncActorLearner
+    torch.manual_seed(4)
+    T, E = 20, 24
+    env = DeviceVectorEnv('PongNoFrameskip-v4', E, dim=42, horizon=T, seed=2, device=dev)
+    model = AtariModel42(env.act_dim).to(dev)
+    with torch.no_grad():
+        model.policy_fc.weight.mul_(0.05)
+        model.value_fc.weight.mul_(0.05)
+    alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
+                                 clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+    pipe = AsyncActorLearner(alg, [env], T, seed=1, train_batch_size=2 * T)
+    n = len(pipe.sub_batches)
+    assert n == 12 and pipe.refresh_points == []
+    for i in range(5):
+        loss, kl = pipe.step(1e-3, -0.01)
+        if i < 2:
+            assert pipe.refresh_points == []  # not before the timed step has been read
+    pipe.synchronize()
+    pts = pipe.refresh_points
+    assert len(pts) <= 3 and all(s in (T // 5, 2 * T // 5, 3 * T // 5) and 2 <= u <= n for s, u in pts)
+    assert [u for _, u in pts] == sorted({u for _, u in pts})
+    assert pipe.refresh_calibration['rollout_ms'] > 0 and pipe.refresh_calibration['learner_pass_ms'] > 0
+    assert np.isfinite(float(loss.total_loss)) and pipe.updates == 5 * n
+    assert [tuple(x) for x in pipe.state_dict()['refresh_points']] == pts
+    env.check_faults()
