@@ -595,6 +595,7 @@ def main():
             'learner_rows_per_pass': args.learn_rows or T * E,
             'learner_updates_per_step': len(pipe.sub_batches) if (pipe is not None and pipe.sub_batches) else 1,
             'actor_weight_refresh_points': [list(x) for x in pipe.refresh_points] if pipe is not None else [],
+            'loss_kernel_aligned_to_env_step': (pipe.align_step if (pipe is not None and pipe._align) else None),
             'env_ids_per_rank': [[r * E, r * E + E - 1] for r in range(world)],
             'collectives': (('none (single process)' if not pdist.active() else 'RCCL, one-rank group (PARL_AMD_FORCE_DIST)')
                             if world == 1 else

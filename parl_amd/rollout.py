@@ -56,6 +56,7 @@ class DeviceRollout(object):
         # (episodes closed, sum of unclipped returns, sum of lengths)
         self.ep_stats = torch.zeros(3, dtype=torch.float64, device=dev)
         self.started = False
+        self.chain_events = None  # optional: one event per step, see collect_step
 
     def _select(self, k):
         b = self._bufs[k]
@@ -79,6 +80,8 @@ class DeviceRollout(object):
         obs = env.current_obs(self._obs_step)
         logits = self.behaviour_logits[t]
         _policy_and_draw(model, obs, logits, self.actions[t], self.seed, self.step_count, env.env_id0)
+        if self.chain_events is not None:  # "the policy chain of step t is done, its emulator launch comes next"
+            self.chain_events[t].record()
         env.step_async(self.actions[t], self.rewards[t], self.dones[t], ep_acc=self.ep_stats)
         self.step_count += 1
 
@@ -456,6 +459,20 @@ class AsyncActorLearner(object):
         self._pub = [[t.detach().clone() for t in self._src] for _ in range(n_pub)]
         self._pub_ready = [torch.cuda.Event() for _ in range(n_pub)]
         self._pass_enqueued = False  # a learner pass (with its publications) was enqueued before this rollout
+        # One update per rollout (no train_batch_size), synchronous launches: the learner's V-trace loss kernel —
+        # 107 MB through HBM in ~35 us, two workgroups per CU next to an emulator wave — is started when the
+        # policy chain of an env step has just finished, i.e. at the beginning of that step's emulator launch
+        # (1.3 ms of one wave per SIMD, everything else idle).  Landing in the actors' MFMA chain instead costs it
+        # 2x (45 vs 100 us, whichever the phase of the two streams happened to be) and the chain its CUs.  The
+        # rollout is enqueued BEFORE the learner pass so that the events exist; align_step = the first env step
+        # whose chain ends after the learner's forward passes (2 at 42x42).
+        self._align = bool(not elastic and len(self.envs) == 1 and not self.sub_batches
+                           and int(os.environ.get('PARL_AMD_ALIGN_LOSS', '1')))
+        self.align_step = min(2, self.T - 1)
+        self._align_ev = None
+        self._align_flag = {}
+        if self._align:
+            self.rollout.chain_events = [torch.cuda.Event() for _ in range(self.T)]
         self.graphed = {}
         if self.sub_batches:
             from .algorithms.impala.graphed import GraphedLearn
@@ -610,8 +627,48 @@ class AsyncActorLearner(object):
         # parameters before it is done
         self._snapshot()
         ls = self.learn_stream
+        new_pending = None
+        if self._align:
+            for b in batches:
+                for v in b.values():
+                    v.record_stream(ls)
+            self._align_steps = getattr(self, '_align_steps', 0) + 1
+            timed = self._align_steps == 2  # the second step is timed once, the third reads it (one host wait)
+            if self._align_steps == 3 and self._align_ev is not None:
+                a0, a1, r0, r1 = self._align_ev
+                if self._align_flag.get('a1'):
+                    r1.synchronize()
+                    a1.synchronize()
+                    fwd_ms, step_ms = a0.elapsed_time(a1), r0.elapsed_time(r1) / self.T
+                    self.align_step = int(min(self.T - 1, max(1, -(-fwd_ms // max(step_ms, 1e-6)))))
+                    self.align_calibration = {'learner_forward_ms': fwd_ms, 'env_step_ms': step_ms}
+                self._align_ev = None
+            st = self.actor_streams[0]
+            if timed:
+                r0 = torch.cuda.Event(enable_timing=True)
+                with torch.cuda.stream(st):
+                    st.wait_event(self.snapshot_done)
+                    r0.record(st)
+            new_pending = self._collect()  # the rollout first: its per-step events exist when the learner waits on one
+            if timed:
+                r1 = torch.cuda.Event(enable_timing=True)
+                r1.record(st)
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self._align_ev = (a0, a1, r0, r1)
+            ev = self.rollout.chain_events[self.align_step]
+
+            def hook():
+                cur = torch.cuda.current_stream(self.env.device)
+                if timed and self._align_ev is not None and not self._align_flag.get('a1'):
+                    a1.record(cur)
+                    self._align_flag['a1'] = True
+                cur.wait_event(ev)
+
+            self.alg.pre_loss_hook = hook
         with torch.cuda.stream(ls):
             ls.wait_event(self.snapshot_done)
+            if new_pending is not None and self._align_ev is not None and self._align_steps == 2:
+                self._align_ev[0].record(ls)
             for g in range(len(batches)):
                 ls.wait_event(self.batch_ready[g][k])
             if self.sub_batches:
@@ -631,6 +688,10 @@ class AsyncActorLearner(object):
             self.weights_ready.record(ls)
             self.batch_free[k].record(ls)
             self.step_done.record(ls)
+        self.alg.pre_loss_hook = None
+        if new_pending is not None:
+            self.pending = new_pending
+            return out
         for b in batches:
             for v in b.values():  # tensors made on an actor stream (e.g. dones.bool()), read on the learner's
                 v.record_stream(ls)
