@@ -17,9 +17,9 @@ config = {
     'sample_batch_steps': 50,
 
     # ==========  learner config ==========
-    # rows per learner update; must be a multiple of sample_batch_steps.  The reference uses 1000
-    # (= 20 sequences); the rollout of env_num sequences is consumed in chunks of this size.
-    'train_batch_size': 6400,
+    # rows per learner update (whole sequences of sample_batch_steps): the reference's value; the rollout of
+    # env_num sequences is consumed as env_num // 20 updates
+    'train_batch_size': 1000,
     'sample_queue_max_size': 8,
     'gamma': 0.99,
 

@@ -27,8 +27,16 @@ def test_a2c_example_runs():
 
 
 def test_impala_example_runs():
+    """default mode: AsyncActorLearner with hipGraph updates of train_batch_size rows"""
     out = _run(['examples/IMPALA/train.py', '--minutes', '0.2', '--env-num', '16', '--train-batch-size', '400',
                 '--log-interval', '3'])
+    assert "'learn_steps': " in out and "'kl': " in out and "'learner_updates_per_s': " in out
+
+
+def test_impala_example_runs_with_the_reference_thread_structure():
+    """--threads: class Learner (learn thread + queue + one sampling thread per @parl.remote_class Actor)"""
+    out = _run(['examples/IMPALA/train.py', '--threads', '--minutes', '0.2', '--env-num', '16',
+                '--train-batch-size', '400', '--log-interval', '3'])
     assert "'learn_steps': " in out and "'kl': " in out
 
 
