@@ -1,29 +1,29 @@
-"""A2C on the device env — keys and hyper-parameters of examples/A2C/a2c_config.py:15-44; the 5 x 5
-CPU envs of the reference become `actor_num` in-process actors x `env_num` GPU-resident envs
-(BASELINE configs[1]: 256 vectorised envs on one MI355X)."""
-config = {
-    # ==========  remote config ==========
-    'master_address': 'localhost:8110',
-    # ==========  env config ==========
-    'env_name': 'PongNoFrameskip-v4',
-    'env_dim': 84,
+"""A2C on the device env.  The dictionary has the keys the reference's example reads
+(examples/A2C/a2c_config.py:15-44) with its learner hyper-parameters; what differs is where the actors live:
+`actor_num` in-process actors, each with `env_num` GPU-resident envs (BASELINE configs[1]: 256 vectorised
+envs on one MI355X) instead of 5 CPU processes x 5 envs."""
 
-    # ==========  actor config ==========
-    'actor_num': 1,
-    'env_num': 256,
-    'sample_batch_steps': 20,
+_where = dict(
+    master_address='localhost:8110',     # only handed to parl.connect(); nothing listens
+    env_name='PongNoFrameskip-v4',
+    env_dim=84,                          # the A2C model's input (AtariModel84)
+)
 
-    # ==========  learner config ==========
-    'max_sample_steps': int(1e7),
-    'gamma': 0.99,
-    'lambda': 1.0,  # GAE
+_actors = dict(
+    actor_num=1,
+    env_num=256,
+    sample_batch_steps=20,               # n of the n-step return
+)
 
-    # start learning rate
-    'start_lr': 0.001,
+_learner = dict(
+    max_sample_steps=int(1e7),           # end of the linear learning-rate decay and of training
+    start_lr=0.001,
+    gamma=0.99,
+    vf_loss_coeff=0.5,
+    entropy_coeff_scheduler=[(0, -0.01)],    # (train_step, coefficient) pairs, piecewise constant
+    get_remote_metrics_interval=10,
+    log_metrics_interval_s=10,
+)
+_learner['lambda'] = 1.0                 # GAE lambda; 1.0 = plain n-step returns
 
-    # coefficient of policy entropy adjustment schedule: (train_step, coefficient)
-    'entropy_coeff_scheduler': [(0, -0.01)],
-    'vf_loss_coeff': 0.5,
-    'get_remote_metrics_interval': 10,
-    'log_metrics_interval_s': 10,
-}
+config = {**_where, **_actors, **_learner}

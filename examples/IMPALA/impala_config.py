@@ -1,37 +1,34 @@
-"""IMPALA on the device env — same keys and learner hyper-parameters as the reference's
-examples/IMPALA/impala_config.py:15-46.  Differences: `actor_num` actors live in THIS process, each
-owning `env_num` GPU-resident envs (the reference: 32 CPU actor processes x 5 envs)."""
-config = {
-    'experiment_name': 'Pong',
+"""IMPALA on the device env.  Keys and learner hyper-parameters are those the reference's example reads
+(examples/IMPALA/impala_config.py:15-46).  `actor_num` actors live in THIS process and each owns `env_num`
+GPU-resident envs (the reference: 32 CPU actor processes x 5 envs)."""
 
-    # ==========  remote config ==========
-    'master_address': 'localhost:8010',  # kept for parl.connect(); actors are in-process
+_where = dict(
+    experiment_name='Pong',
+    master_address='localhost:8010',     # only handed to parl.connect(); the actors are in-process
+    env_name='PongNoFrameskip-v4',
+    env_dim=42,                          # AtariModel42
+)
 
-    # ==========  env config ==========
-    'env_name': 'PongNoFrameskip-v4',
-    'env_dim': 42,
+_actors = dict(
+    actor_num=1,
+    env_num=1024,                        # BASELINE configs[2]: 1024 actors on one MI355X
+    sample_batch_steps=50,
+    params_broadcast_interval=1,
+)
 
-    # ==========  actor config ==========
-    'actor_num': 1,
-    'env_num': 1024,
-    'sample_batch_steps': 50,
+_learner = dict(
+    # rows per learner update, whole sequences of sample_batch_steps: the reference's 1000.  A rollout of
+    # env_num sequences is consumed as env_num // 20 updates.
+    train_batch_size=1000,
+    sample_queue_max_size=8,
+    gamma=0.99,
+    vf_loss_coeff=0.5,
+    clip_rho_threshold=1.0,
+    clip_pg_rho_threshold=1.0,
+    lr_scheduler=[(0, 0.001), (20000, 0.0005), (40000, 0.0001)],     # (train_step, learning rate)
+    entropy_coeff_scheduler=[(0, -0.01)],                            # (train_step, coefficient)
+    get_remote_metrics_interval=1,
+    log_metrics_interval_s=10,
+)
 
-    # ==========  learner config ==========
-    # rows per learner update (whole sequences of sample_batch_steps): the reference's value; the rollout of
-    # env_num sequences is consumed as env_num // 20 updates
-    'train_batch_size': 1000,
-    'sample_queue_max_size': 8,
-    'gamma': 0.99,
-
-    # learning rate adjustment schedule: (train_step, learning_rate)
-    'lr_scheduler': [(0, 0.001), (20000, 0.0005), (40000, 0.0001)],
-
-    # coefficient of policy entropy adjustment schedule: (train_step, coefficient)
-    'entropy_coeff_scheduler': [(0, -0.01)],
-    'vf_loss_coeff': 0.5,
-    'clip_rho_threshold': 1.0,
-    'clip_pg_rho_threshold': 1.0,
-    'get_remote_metrics_interval': 1,
-    'log_metrics_interval_s': 10,
-    'params_broadcast_interval': 1,
-}
+config = {**_where, **_actors, **_learner}

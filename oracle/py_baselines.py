@@ -15,6 +15,7 @@ loaded by path instead (kind "reference").
 """
 import importlib.util
 import os
+import sys
 import time
 
 import numpy as np
@@ -33,7 +34,11 @@ def load_calc_gae():
     if os.path.exists(p):
         spec = importlib.util.spec_from_file_location('ref_rl_utils', p)
         m = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(m)
+        keep, sys.dont_write_bytecode = sys.dont_write_bytecode, True  # no __pycache__ in the reference tree
+        try:
+            spec.loader.exec_module(m)
+        finally:
+            sys.dont_write_bytecode = keep
         return m.calc_gae, 'reference'
     return _calc_gae_port, 'port'
 

@@ -1,30 +1,38 @@
-"""TimeStat — context-manager timer with a windowed mean (parl/utils/time_stat.py:22-52)."""
-import time
+"""TimeStat: `with stat: ...` measures the block; mean / min / max over the last `window_size` blocks.
 
-from .window_stat import WindowStat
+Mirrors the interface of parl/utils/time_stat.py:22-52 (the examples' learners print `sample_time.mean` etc.).
+The clock is time.perf_counter (monotonic: a wall-clock step during a run cannot produce a negative sample);
+nested use of one instance is supported (a stack of start times) — the reference overwrites its single start
+time and reports the inner block twice."""
+import time
+from collections import deque
 
 __all__ = ['TimeStat']
 
 
+def _stat(reduce):
+    def get(self):
+        return reduce(self._samples) if self._samples else None
+    return property(get)
+
+
 class TimeStat(object):
     def __init__(self, window_size=1):
-        self.time_samples = WindowStat(window_size)
-        self._start_time = None
+        self._samples = deque(maxlen=int(window_size))
+        self._starts = []
 
     def __enter__(self):
-        self._start_time = time.time()
+        self._starts.append(time.perf_counter())
+        return self
 
-    def __exit__(self, exc_type, exc_value, tb):
-        self.time_samples.add(time.time() - self._start_time)
+    def __exit__(self, *exc):
+        self._samples.append(time.perf_counter() - self._starts.pop())
+        return False
 
-    @property
-    def mean(self):
-        return self.time_samples.mean
-
-    @property
-    def min(self):
-        return self.time_samples.min
+    mean = _stat(lambda s: sum(s) / len(s))
+    min = _stat(min)
+    max = _stat(max)
 
     @property
-    def max(self):
-        return self.time_samples.max
+    def count(self):
+        return len(self._samples)

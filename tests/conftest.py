@@ -1,6 +1,11 @@
 import os
 import sys
 
+# tests execute reference modules from /root/reference by path (and spawn subprocesses that do): never leave a
+# __pycache__ in that tree, it is read-only for this project
+sys.dont_write_bytecode = True
+os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+
 import numpy as np
 import pytest
 

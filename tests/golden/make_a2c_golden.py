@@ -17,6 +17,8 @@ import importlib.util
 import os
 import sys
 
+sys.dont_write_bytecode = True  # modules are imported from /root/reference by path: never leave a __pycache__ there
+
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))

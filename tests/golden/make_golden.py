@@ -21,6 +21,8 @@ import importlib.util
 import os
 import sys
 
+sys.dont_write_bytecode = True  # modules are imported from /root/reference by path: never leave a __pycache__ there
+
 import numpy as np
 
 REF = '/root/reference'

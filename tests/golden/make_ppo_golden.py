@@ -26,6 +26,8 @@ import types
 
 import numpy as np
 
+sys.dont_write_bytecode = True  # modules are imported from /root/reference by path: never leave a __pycache__ there
+
 REF = '/root/reference'
 OUT = os.path.dirname(os.path.abspath(__file__))
 

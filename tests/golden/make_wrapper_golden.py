@@ -35,6 +35,8 @@ import zlib
 
 import numpy as np
 
+sys.dont_write_bytecode = True  # modules are imported from /root/reference by path: never leave a __pycache__ there
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)

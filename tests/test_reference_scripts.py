@@ -207,3 +207,16 @@ def test_reference_paddle_examples_run_unmodified_on_the_device(kind):
     out = _run_example(kind, _example_dir(kind, prefer_reference=False), ['--steps', '4'], 900)
     assert out['learn_steps'] >= 4 and out['weights_changed'] and np.isfinite(out['total_loss'])
     assert out['device'].startswith('cuda')
+
+
+def test_running_the_reference_leaves_no_bytecode_in_its_tree():
+    """The reference tree is read-only for this project.  Everything here that executes reference modules by path
+    (this file, tests/tools/run_reference_example.py, tests/golden/make_*.py, oracle/py_baselines.py) switches
+    bytecode writing off, in this process and — through PYTHONDONTWRITEBYTECODE — in the subprocesses it
+    spawns; pytest runs this module's tests in file order, so the imports above have happened by now."""
+    if not os.path.isdir('/root/reference'):
+        pytest.skip('needs /root/reference (build container)')
+    assert sys.dont_write_bytecode and os.environ.get('PYTHONDONTWRITEBYTECODE') == '1'
+    left = [os.path.join(d, n) for d, sub, files in os.walk('/root/reference')
+            for n in sub + files if n == '__pycache__' or n.endswith('.pyc')]
+    assert not left, left

@@ -14,6 +14,8 @@ import os
 import sys
 import time
 
+sys.dont_write_bytecode = True  # modules are imported from /root/reference by path: never leave a __pycache__ there
+
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
