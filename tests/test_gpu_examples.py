@@ -83,6 +83,53 @@ def test_a2c_rollout_matches_per_segment_calc_gae(dev, oracle):
     assert np.isfinite(float(total))
 
 
+def test_a2c_rollout_rows_are_aligned(dev):
+    """Row (t, e) of the batch DeviceA2CRollout hands to A2C.learn carries the stacked observation the policy
+    saw at step t for env e, the action drawn from THAT forward pass and the value it produced (the sums of
+    a2c.py:67-79 do not care about the order of the rows, but they do care that a row's obs, action, advantage
+    and target belong together).  The observations are recorded at the model call, the batch is compared
+    with the recording after the rollout; several rollouts so that the ring has been rolled and the
+    picture moves."""
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel84
+    from parl_amd.rollout import DeviceA2CRollout
+    torch.manual_seed(1)
+    E, T = 6, 12
+    env = DeviceVectorEnv('PongNoFrameskip-v4', E, dim=84, horizon=T, seed=7, device=dev)
+    model = AtariModel84(env.act_dim).to(dev)
+    ro = DeviceA2CRollout(env, T, gamma=0.99, lam=1.0, seed=5)
+    seen, outs = [], []
+    inner = model.policy_and_value
+
+    def recording(obs):
+        logits, values = inner(obs)
+        seen.append(obs.clone())
+        outs.append((logits.clone(), values.clone()))
+        return logits, values
+
+    model.policy_and_value = recording
+    moved = False
+    for it in range(4):
+        del seen[:], outs[:]
+        b = ro.collect(model)
+        torch.cuda.synchronize()
+        assert len(seen) == T
+        obs = b['obs'].reshape(T, E, 4, 84, 84)
+        act = b['actions'].reshape(T, E)
+        val = (b['target_values'] - b['advantages']).reshape(T, E)
+        for t in range(T):
+            assert torch.equal(obs[t], seen[t]), (it, t)
+            torch.testing.assert_close(val[t], outs[t][1], rtol=0, atol=1e-5)
+            assert torch.equal(act[t], ro.actions[t])
+            assert int(act[t].min()) >= 0 and int(act[t].max()) < env.act_dim
+        # the newest frame of step t is the second newest of step t + 1 (FrameStack), inside one episode
+        for t in range(T - 1):
+            keep = ro.dones[t] == 0
+            assert torch.equal(obs[t + 1][keep][:, 2], obs[t][keep][:, 3])
+        moved = moved or not torch.equal(obs[0], obs[T - 1])
+    assert moved, 'the picture never changed: the comparison above proved nothing'
+
+
 def test_async_actor_learner_pipeline(dev):
     """AsyncActorLearner (learner update on batch i-1 overlapped with the collection of batch i on
     a second stream): the first batch is bit-identical to a plain DeviceRollout's, the behaviour
