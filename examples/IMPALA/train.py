@@ -188,7 +188,11 @@ class PipelineLearner(object):
         elastic = config.get('elastic_launches', 'Breakout' in config['env_name'])
         self.env = DeviceVectorEnv(config['env_name'], E, dim=config['env_dim'], horizon=4 * T + 32 if elastic else T,
                                    seed=config.get('seed', 0), device=dev)
-        model = AtariModel(self.env.act_dim).to(dev)
+        if config['env_dim'] == 84:  # the north-star frame size: the A2C example's network (examples/A2C/atari_model.py)
+            from parl_amd.models import AtariModel84
+            model = AtariModel84(self.env.act_dim).to(dev)
+        else:
+            model = AtariModel(self.env.act_dim).to(dev)
         self.alg = parl.algorithms.IMPALA(
             model, sample_batch_steps=T, gamma=config['gamma'], vf_loss_coeff=config['vf_loss_coeff'],
             clip_rho_threshold=config['clip_rho_threshold'], clip_pg_rho_threshold=config['clip_pg_rho_threshold'])
@@ -235,6 +239,8 @@ if __name__ == '__main__':
     ap.add_argument('--env-num', type=int, default=None)
     ap.add_argument('--env-name', default=None, help='PongNoFrameskip-v4 (config default) or BreakoutNoFrameskip-v4')
     ap.add_argument('--train-batch-size', type=int, default=None)
+    ap.add_argument('--env-dim', type=int, default=None, choices=(42, 84),
+                    help='observation size: 42 (config default, AtariModel42) or 84 (AtariModel84; pipeline mode)')
     ap.add_argument('--log-interval', type=float, default=None)
     ap.add_argument('--threads', action='store_true',
                     help='the reference\'s thread-per-actor structure (class Learner) instead of the stream pipeline')
@@ -249,6 +255,9 @@ if __name__ == '__main__':
         config['train_batch_size'] = args.train_batch_size
     if args.log_interval:
         config['log_metrics_interval_s'] = args.log_interval
+    if args.env_dim:
+        assert args.env_dim == 42 or not args.threads, '--env-dim 84 runs in the pipeline mode'
+        config['env_dim'] = args.env_dim
     if not args.threads:
         learner = PipelineLearner(config)
         t0 = t_log = time.time()

@@ -33,6 +33,14 @@ def test_impala_example_runs():
     assert "'learn_steps': " in out and "'kl': " in out and "'learner_updates_per_s': " in out
 
 
+def test_impala_example_runs_at_the_north_star_frame_size():
+    """--env-dim 84: AtariModel84 (the 84x84 MFMA trunk kernels, heads by rocBLAS + the one-kernel V-trace loss)
+    under the same pipeline; 3 minutes of it on 1024 envs: profiles/r03_impala_pong_84_3min.log"""
+    out = _run(['examples/IMPALA/train.py', '--env-dim', '84', '--minutes', '0.2', '--env-num', '16',
+                '--train-batch-size', '400', '--log-interval', '3'])
+    assert "'learn_steps': " in out and "'kl': " in out and "'learner_updates_per_s': " in out
+
+
 def test_impala_example_runs_with_the_reference_thread_structure():
     """--threads: class Learner (learn thread + queue + one sampling thread per @parl.remote_class Actor)"""
     out = _run(['examples/IMPALA/train.py', '--threads', '--minutes', '0.2', '--env-num', '16',
