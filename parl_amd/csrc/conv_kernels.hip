@@ -371,30 +371,46 @@ __global__ __launch_bounds__(256) void conv12_bwd_reduce_kernel(const float* __r
 // + ReLU (84x84 -> 20x20).  Per observation an implicit GEMM [400 positions x 256] x [256 x 32]
 // (6.55 MFLOP), k = c*64 + kh*8 + kw (the order of weight.flatten(1)).
 //
-// One workgroup (4 wavefronts, one per SIMD) per observation, grid-stride over observations:
-//   * the u8 stack is read once with 4-byte loads (28,224 B), divided by 255 and laid out in LDS
-//     shifted by the padding: tile[c][py][px] = obs[c][py-1][px-1] / 255, row 0 / column 0 = 0.
-//     (pad 1 with floor((84+2-8)/4)+1 = 20 outputs: padded rows/columns 84 and 85 are never read,
-//     so the tile is 4 x 84 x 84 floats = 112,896 B);
+// One workgroup (4 wavefronts) per observation, grid-stride over observations:
+//   * the observation stays uint8 in LDS, UNSHIFTED (tile[c][y][x] at byte 88 + c*7056 + y*84 + x, copied with
+//     4-byte loads / stores): 28.3 KB instead of the 112.9 KB of a float tile, so that the kernel co-resides
+//     with the learner's kernels (75-113 KB) and with two more workgroups of its own (round 3; the float
+//     tile was exclusive on its CU).  An A element is u / 255 computed in registers as q = u * r,
+//     q += fma(-q, 255, u) * r with r = 1 / 255.0f — bit-identical to the IEEE division for all 256 bytes
+//     (checked exhaustively on the host and by the kernel's tests), four VALU operations in the shadow of the
+//     two MFMAs they feed, and no second dependent LDS read (the table form the backward kernels use).
+//     The padding costs no branch: pad 1 with floor((84+2-8)/4)+1 = 20 outputs reads input rows / columns
+//     -1 .. 82, never 83.  Row 83 and column 83 of every plane are stored as zeros, and in the flat layout
+//     "column -1 of row y" IS column 83 of row y-1, "row -1 of plane c" IS row 83 of plane c-1; plane 0 has
+//     88 zero bytes in front of it for the same purpose.
 //   * the whole B operand (the 32 KB weight matrix) lives in registers: 64 k-steps x 2 N-tiles =
-//     128 VGPRs per lane, loaded once per workgroup (a single wave per SIMD has 512 VGPRs);
+//     128 VGPRs per lane, loaded once per workgroup;
 //   * each wave owns M-tiles (16 output positions) and issues 2 MFMAs per A gather (both N-tiles);
 //   * D (col = channel, rows = 4 consecutive positions) + bias + ReLU goes straight to HBM as one
 //     16-byte store per lane in NCHW order — no staging, no im2col matrix in HBM (the GEMM-lowered
 //     conv writes and re-reads 410 KB of patches per observation).
 // Algorithmic bytes per observation: 28,224 read + 51,200 written.
 // ----------------------------------------------------------------------------------------
-constexpr int kD84 = 84;                 // input size = padded-tile size (see above)
+constexpr int kD84 = 84;                 // input size
 constexpr int kO84 = 20, kC84 = 32;      // conv1 output size / channels
 constexpr int kM84 = kO84 * kO84;        // 400 positions = 25 M-tiles of 16
 constexpr int kK84 = 4 * 8 * 8;          // 256
 constexpr int kPlane84 = kD84 * kD84;    // 7056
-constexpr int kLds84Floats = 4 * kPlane84;
+constexpr int kGuard84 = 88;                                     // zero bytes in front of plane 0 (>= 85, 4-byte multiple)
+constexpr int kLds84u8Bytes = kGuard84 + 4 * kPlane84 + 8;       // 28,320
 
-__global__ __launch_bounds__(256) void conv1_84_u8_mfma_kernel(
+// (float)u / 255.0f without the division: one Newton step makes the product correctly rounded for u = 0 .. 255
+__device__ __forceinline__ float byte_over_255(uint32_t u) {
+  const float x = (float)u, r = 1.0f / 255.0f;
+  const float q = x * r;
+  return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), r, q);
+}
+
+__global__ __launch_bounds__(256, 2) void conv1_84_u8_mfma_kernel(
     const uint8_t* __restrict__ obs, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, int n_obs) {
-  extern __shared__ float lds[];  // [4][84][84], shifted by the padding
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
+  uint8_t* tile = lds8;                                          // [88 guard][4][84][84]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, col = lane & 15;
   // B[k][n] = w[n][k]: lane (q, col) holds k = 4*ks + q, n = 16*nt + col
@@ -405,40 +421,47 @@ __global__ __launch_bounds__(256) void conv1_84_u8_mfma_kernel(
     breg[ks][1] = w[(16 + col) * kK84 + ks * 4 + q];
   }
   const float bias0 = bias[col], bias1 = bias[16 + col];
-  // the padding: row 0 and column 0 of every channel plane (never overwritten below)
-  for (int i = tid; i < 4 * kD84; i += 256) {
-    const int c = i / kD84, p = i - c * kD84;
-    lds[c * kPlane84 + p] = 0.0f;
-    lds[c * kPlane84 + p * kD84] = 0.0f;
-  }
+  if (tid < kGuard84 / 4) reinterpret_cast<uint32_t*>(tile)[tid] = 0u;
   for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
     __syncthreads();  // the previous observation's gathers are done before the tile is rewritten
     const uint32_t* src = reinterpret_cast<const uint32_t*>(obs + (size_t)n * 4 * kPlane84);
-    for (int wi = tid; wi < kPlane84; wi += 256) {  // 4 * 7056 bytes = 7056 words; 84 % 4 == 0
-      const uint32_t v = src[wi];
+    uint32_t* dstw = reinterpret_cast<uint32_t*>(tile + kGuard84);
+    for (int wi = tid; wi < kPlane84; wi += 256) {  // 4 * 7056 bytes = 7056 words; 84 % 4 == 0: a word never spans two rows
+      uint32_t v = src[wi];
       const int i = wi * 4;
-      const int c = i / kPlane84, r = i - c * kPlane84, y = r / kD84, x = r - y * kD84;
-      if (y < kD84 - 1) {  // input row 83 lies outside every window
-        float* d = lds + c * kPlane84 + (y + 1) * kD84 + (x + 1);
-        d[0] = (float)(v & 255u) / 255.0f;
-        d[1] = (float)((v >> 8) & 255u) / 255.0f;
-        d[2] = (float)((v >> 16) & 255u) / 255.0f;
-        if (x + 4 < kD84) d[3] = (float)(v >> 24) / 255.0f;  // input column 83 likewise
-      }
+      const int r = i % kPlane84, y = r / kD84, x = r - y * kD84;
+      v = (x == kD84 - 4) ? (v & 0x00ffffffu) : v;   // column 83 := 0 (it doubles as column -1 of the next row)
+      v = (y == kD84 - 1) ? 0u : v;                  // row 83 := 0 (it doubles as row -1 of the next plane)
+      dstw[wi] = v;
     }
     __syncthreads();
     float* dst = out + (size_t)n * kC84 * kM84;
     for (int mt = wave; mt < kM84 / 16; mt += 4) {
       const int m = mt * 16 + col;
       const int oy = m / kO84, ox = m - oy * kO84;
-      const float* a_base = lds + (4 * oy) * kD84 + 4 * ox + q;
+      // input (4 oy + kh - 1, 4 ox + kw - 1), kw = (ks & 1) * 4 + q
+      const uint8_t* a_base = tile + kGuard84 + (4 * oy - 1) * kD84 + (4 * ox - 1) + q;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      // k = 4*ks + q = c*64 + kh*8 + kw  ->  c = ks>>4, kh = (ks>>1)&7, kw = (ks&1)*4 + q.  The bytes of the NEXT
+      // 16 k-steps (one input plane) are in flight while the MFMAs of this plane run: without the explicit
+      // double buffer the compiler issues every LDS read right in front of its use.
+      uint32_t ub[16];
 #pragma unroll
-      for (int ks = 0; ks < 64; ++ks) {
-        // k = 4*ks + q = c*64 + kh*8 + kw  ->  c = ks>>4, kh = (ks>>1)&7, kw = (ks&1)*4 + q
-        const float a = a_base[(ks >> 4) * kPlane84 + ((ks >> 1) & 7) * kD84 + (ks & 1) * 4];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[ks][0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[ks][1], acc1, 0, 0, 0);
+      for (int j = 0; j < 16; ++j) ub[j] = a_base[((j >> 1) & 7) * kD84 + (j & 1) * 4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float a[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = byte_over_255(ub[j]);
+        if (c < 3) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) ub[j] = a_base[(c + 1) * kPlane84 + ((j >> 1) & 7) * kD84 + (j & 1) * 4];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], breg[c * 16 + j][0], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], breg[c * 16 + j][1], acc1, 0, 0, 0);
+        }
       }
       // D: column = channel (col), rows 4q..4q+3 = 4 consecutive positions -> one 16 B store
       f32x4 o0, o1;
@@ -967,14 +990,14 @@ PARLHIP_EXPORT int parlhip_atari84_conv1_u8_f32(const uint8_t* obs, const float*
   // starting at an observation boundary keeps both: 28,224 and 51,200 are multiples of 16)
   if (((uintptr_t)obs & 3u) || ((uintptr_t)out & 15u)) return PARLHIP_EINVAL;
   static bool attr_set = false;
-  const size_t lds_bytes = kLds84Floats * sizeof(float);
+  const size_t lds_bytes = kLds84u8Bytes;
   if (!attr_set) {
     int rc = check(hipFuncSetAttribute((const void*)conv1_84_u8_mfma_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     if (rc) return rc;
     attr_set = true;
   }
-  const int grid = n_obs < kNumCU ? n_obs : kNumCU;  // 113 KB of LDS: one workgroup per CU
+  const int grid = n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU;  // 28 KB of LDS, <= 256 VGPRs: two workgroups per CU
   conv1_84_u8_mfma_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(obs, w1, b1, out, n_obs);
   return check_launch();
 }
