@@ -16,12 +16,10 @@ _actors = dict(
 )
 
 _learner = dict(
-    # End of the linear learning-rate decay and of training.  The reference's 1e7 sample steps are 20,000 updates
-    # of its 5 x 5 envs x 20 steps = 500 rows; an update here has env_num x 20 = 5,120 rows, so the same number
-    # of updates is 1e8 sample steps.  Measured on one MI355X (profiles/r03_a2c_pong_256envs_*.log): with 1e7 the
-    # 1,953 updates end at -20.2 (the policy never leaves uniform); with 1e8 Pong crosses 0 after 1.85e7 steps
-    # (130 s) and stands at +20.2 after 3.3e7 (230 s, 570 k frames/s).
-    max_sample_steps=int(1e8),
+    # The reference's value (examples/A2C/a2c_config.py:33): end of the linear learning-rate decay and of training,
+    # in sample steps of ITS actor pool (5 actors x 5 envs x 20 steps = 500 rows per update -> 20,000 updates).
+    # train.py keeps the number of UPDATES, not of samples, when the pool is bigger (`--horizon`, see there).
+    max_sample_steps=int(1e7),
     start_lr=0.001,
     gamma=0.99,
     vf_loss_coeff=0.5,

@@ -1,7 +1,15 @@
 """A2C learner — the synchronous step() of examples/A2C/train.py:30-186 (kick off all actors,
 collect, one update) on the device path.
 
-    python examples/A2C/train.py [--max_sample_steps N] [--env-num E]
+    python examples/A2C/train.py [--max_sample_steps N] [--env-num E] [--horizon updates|samples]
+
+The config file carries the reference's `max_sample_steps` = 1e7, which its 5 x 5 CPU envs consume as 20,000
+updates of 500 rows.  An update here has env_num x actor_num x 20 rows (256 envs: 5,120), so the same number of
+sample steps would be 1,953 updates — measured on one MI355X (profiles/r03_a2c_pong_256envs_*.log) that ends
+at -20.2, the policy never leaves uniform, while the reference's number of UPDATES takes Pong across 0 after
+1.85e7 steps (130 s) to +20.2 after 3.3e7 (230 s).  `--horizon updates` (the default) therefore scales the
+config's value by (envs here) / (the reference's 25 envs) and logs it; `--horizon samples` or an explicit
+`--max_sample_steps N` uses the number as it stands.
 """
 import argparse
 import os
@@ -101,11 +109,21 @@ if __name__ == '__main__':
     parser.add_argument('--max_sample_steps', type=int, default=None, help='stop condition: number of sample step')
     parser.add_argument('--env-num', type=int, default=None)
     parser.add_argument('--log-interval', type=float, default=None)
+    parser.add_argument('--horizon', choices=('updates', 'samples'), default='updates',
+                        help='what the config\'s max_sample_steps preserves when the actor pool is bigger than the '
+                        'reference\'s 25 envs: the number of updates (scaled sample steps) or the sample steps')
     args = parser.parse_args()
-    if args.max_sample_steps is not None:
-        config['max_sample_steps'] = args.max_sample_steps
     if args.env_num:
         config['env_num'] = args.env_num
+    if args.max_sample_steps is not None:
+        config['max_sample_steps'] = args.max_sample_steps
+    elif args.horizon == 'updates':
+        REFERENCE_ENVS = 5 * 5  # actor_num x env_num of the reference's a2c_config.py:22-26
+        envs = config['env_num'] * config['actor_num']
+        config['max_sample_steps'] = int(config['max_sample_steps'] * max(1.0, envs / REFERENCE_ENVS))
+        logger.info('max_sample_steps scaled to %d: the reference\'s %d updates at %d rows per update' %
+                    (config['max_sample_steps'], config['max_sample_steps'] // (envs * config['sample_batch_steps']),
+                     envs * config['sample_batch_steps']))
     if args.log_interval:
         config['log_metrics_interval_s'] = args.log_interval
     learner = Learner(config)

@@ -224,6 +224,9 @@ class PipelineLearner(object):
         }
         if stats:
             metric.update(dict(zip(('total_loss', 'pi_loss', 'vf_loss', 'entropy', 'kl'), stats)))
+        for key, value in metric.items():  # the summary scalars the reference's Learner logs (train.py:214-238)
+            if value is not None:
+                summary.add_scalar(key, value, self.sample_total_steps)
         logger.info(metric)
         return metric
 
@@ -266,9 +269,10 @@ if __name__ == '__main__':
             if time.time() - t_log >= config['log_metrics_interval_s']:
                 learner.log_metrics()
                 t_log = time.time()
+        learner.log_metrics()
         learner.shutdown()
         sys.stdout.flush()
-        os._exit(0)
+        sys.exit(0)  # no proxy threads in this mode: a normal interpreter exit (loggers and summary files flushed)
     learner = Learner(config)
     assert config['log_metrics_interval_s'] > 0
     t0 = time.time()

@@ -1,8 +1,13 @@
 """ctypes binding of libparl_hip.so (the C ABI declared in include/parl_hip.h).
 
-The library is the product: if it is missing, or a call fails, this module raises — there is
-no CPU or eager-PyTorch fallback anywhere in parl_amd (oracle/ is test infrastructure and is
-never imported from here).
+The library is the product: if it is missing, or a call fails, this module raises — no entry of
+the C ABI has a CPU twin in parl_amd, and a CPU tensor handed to an op raises (oracle/ is test
+infrastructure and is never imported from here).  What the host framework keeps in PyTorch-ROCm by
+design (north_star: "host code stays Python calling PyTorch-ROCm for the small policy/value
+forward/backward") still runs ON THE DEVICE through the library's kernels: e.g. IMPALA's loss for a
+shape the one-kernel loss has no instantiation for (A not in {2,3,4,6,9,18} or T > 256) is the
+reference's formulas as torch ops around the fused V-trace kernel (algorithms/impala/impala.py,
+`_vtrace_loss`) — a framework-level composition of device kernels, not a fallback off the device.
 
 torch must be imported before the library is loaded so that libparl_hip.so binds to the same
 libamdhip64.so.7 the torch allocator uses (device pointers are shared across the boundary).

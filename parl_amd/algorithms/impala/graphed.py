@@ -35,6 +35,10 @@ def make_capturable(optimizer, device):
         g['foreach'] = False
         if not isinstance(g['lr'], torch.Tensor):
             g['lr'] = torch.tensor(float(g['lr']), dtype=torch.float32, device=device)
+        elif g['lr'].device != torch.device(device) or g['lr'].dtype != torch.float32:
+            # a checkpoint loaded with map_location='cpu' brings its lr tensor along
+            g['lr'] = g['lr'].detach().to(device=device, dtype=torch.float32)
+            g.pop('_lr_value', None)
     for st in optimizer.state.values():
         if 'step' in st and (not st['step'].is_cuda or st['step'].dtype != torch.float32):
             st['step'] = st['step'].to(device=device, dtype=torch.float32)
@@ -56,8 +60,10 @@ def load_optimizer_state_inplace(optimizer, state_dict):
     after which a replay would keep updating the old ones).  The learning rate is restored into the device
     scalar.  State that does not exist yet (no step taken) is created by a normal load."""
     if not optimizer.state:
-        optimizer.load_state_dict(state_dict)
+        _plain_load(optimizer, state_dict)
         dev = next(p for g in optimizer.param_groups for p in g['params']).device
+        for g in optimizer.param_groups:  # the checkpoint's memo of the last filled value says nothing about
+            g.pop('_lr_value', None)      # the tensor just installed
         make_capturable(optimizer, dev)
         return
     params = [p for g in optimizer.param_groups for p in g['params']]
@@ -68,7 +74,10 @@ def load_optimizer_state_inplace(optimizer, state_dict):
             src, dst = state_dict['state'].get(i, {}), optimizer.state[p]
             for k, v in dst.items():
                 if isinstance(v, torch.Tensor):
-                    v.copy_(torch.as_tensor(src[k]).to(device=v.device, dtype=v.dtype))
+                    if k in src:
+                        v.copy_(torch.as_tensor(src[k]).to(device=v.device, dtype=v.dtype))
+                    else:  # saved before this parameter's first step: its state is "no step taken"
+                        v.zero_()
         for g, sg in zip(optimizer.param_groups, state_dict['param_groups']):
             lr = sg['lr']
             set_lr(optimizer if len(optimizer.param_groups) == 1 else _one_group(g), float(lr))
@@ -77,6 +86,26 @@ def load_optimizer_state_inplace(optimizer, state_dict):
 class _one_group(object):
     def __init__(self, g):
         self.param_groups = [g]
+
+
+def _plain_load(optimizer, state_dict):
+    load = getattr(optimizer, '_parl_plain_load_state_dict', None) or optimizer.load_state_dict
+    load(state_dict)
+
+
+def _guard_load_state_dict(optimizer):
+    """After a capture the graph refers to the optimizer's state tensors BY ADDRESS; torch's load_state_dict
+    replaces them and the replays would go on updating the orphans.  It raises from now on and names the
+    in-place loader."""
+    if getattr(optimizer, '_parl_plain_load_state_dict', None) is not None:
+        return
+    optimizer._parl_plain_load_state_dict = optimizer.load_state_dict
+
+    def refuse(state_dict):
+        raise RuntimeError('this optimizer\'s state is referenced by a captured hipGraph (GraphedLearn): use '
+                           'parl_amd.algorithms.impala.graphed.load_optimizer_state_inplace(optimizer, state_dict)')
+
+    optimizer.load_state_dict = refuse
 
 
 class GraphedLearn(object):
@@ -215,6 +244,9 @@ class GraphedLearn(object):
             self.graphs = [g1]
         if self.pool is None:
             self.pool = g1.pool()
+        _guard_load_state_dict(alg.optimizer)
+        for p in list(alg.model.parameters()) + list(alg.model.buffers()):
+            p._parl_graph_written = True  # replays write it without moving its version counter (ops._cached_layout)
 
     # ---- per update --------------------------------------------------------------------------
     def load(self, batch, b0, E):

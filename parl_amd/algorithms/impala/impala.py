@@ -159,9 +159,6 @@ class IMPALA(Algorithm):
         # heads + loss + heads' backward in one kernel when the model exposes its trunk (`_trunk`,
         # `policy_fc`, `value_fc`), the batch is time-major, T <= 64, 256 hidden units, A in {4, 6}
         self.fused_heads = True
-        # called (on the learner's stream) right before the V-trace loss kernel of learn() is launched:
-        # AsyncActorLearner uses it to start that HBM-bound kernel in the shadow of an emulator launch
-        self.pre_loss_hook = None
 
     def _heads(self, obs):
         if hasattr(self.model, 'policy_and_value'):
@@ -223,8 +220,6 @@ class IMPALA(Algorithm):
             hidden = self._heads_in_chunks(obs, True, trunk_only=True)
             if hidden.dtype == torch.float32:
                 A = m.policy_fc.out_features
-                if self.pre_loss_hook is not None:
-                    self.pre_loss_hook()
                 try:
                     total, sums, vs, pg_adv = _FusedHeadsLossFn.apply(
                         hidden.reshape(T, B, 256), m.policy_fc.weight, m.policy_fc.bias, m.value_fc.weight,

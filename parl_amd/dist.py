@@ -98,17 +98,18 @@ class FlatGradAllReduce(object):
 _gather_bufs = {}
 
 
-def all_gather_small(tensors):
+def all_gather_small(tensors, slot=0):
     """All-gather a dict of small per-step tensors along a new leading rank dim.  The [world, ...] receive
-    buffers are allocated once per (key, shape, dtype, device) and reused: one call per learner update.
-    The result of a call is valid until the next call with the same keys."""
+    buffers are allocated once per (slot, key, shape, dtype, device) and reused: one call per learner update
+    and slot.  The result of a call is valid until the next call with the same slot and keys — callers that
+    keep several results alive at once (one per env group) pass a different `slot` for each."""
     w = world_size()
     if not active():
         return {k: v.unsqueeze(0) for k, v in tensors.items()}
     out = {}
     for k, v in tensors.items():
         v = v.contiguous()
-        key = (k, w, tuple(v.shape), v.dtype, v.device)
+        key = (slot, k, w, tuple(v.shape), v.dtype, v.device)
         buf = _gather_bufs.get(key)
         if buf is None:
             buf = _gather_bufs[key] = torch.empty((w, ) + tuple(v.shape), dtype=v.dtype, device=v.device)

@@ -431,18 +431,30 @@ _layout_cache = {}
 
 def _cached_layout(w, kind, fn):
     """MFMA operand-order copy of a weight tensor, rebuilt only when the tensor was written since (its autograd
-    version counter moves on every in-place write: optimizer steps, the actors' snapshot copy).  The actors
+    version counter moves on every eager in-place write: optimizer steps, the actors' snapshot copy).  The actors
     call the forward kernels once per env step with weights that change once per rollout: without the cache
-    every step re-laid out both matrices (three small copy kernels and their host time)."""
+    every step re-laid out both matrices (three small copy kernels and their host time).
+    Two things the version counter cannot see are handled explicitly: (a) a hipGraph replay writes parameters
+    without touching the counter — GraphedLearn flags the parameters it updates (`_parl_graph_written`) and
+    flagged tensors are never cached; (b) the copy is built on ONE stream — an event recorded behind the
+    build is kept with it and a consumer on another stream waits for it (several env groups on their own
+    actor streams share one actor model)."""
+    if getattr(w, '_parl_graph_written', False):
+        return fn(w)
     key = (id(w), kind)
     hit = _layout_cache.get(key)
     ver = w._version
+    cur = torch.cuda.current_stream(w.device)
     if hit is not None and hit[0] is w and hit[1] == ver and hit[2] == w.data_ptr():
+        if hit[5] != cur:
+            cur.wait_event(hit[4])
         return hit[3]
     out = fn(w)
+    ev = torch.cuda.Event()
+    ev.record(cur)
     if len(_layout_cache) > 64:
         _layout_cache.clear()
-    _layout_cache[key] = (w, ver, w.data_ptr(), out)
+    _layout_cache[key] = (w, ver, w.data_ptr(), out, ev, cur)
     return out
 
 

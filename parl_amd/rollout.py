@@ -56,7 +56,6 @@ class DeviceRollout(object):
         # (episodes closed, sum of unclipped returns, sum of lengths)
         self.ep_stats = torch.zeros(3, dtype=torch.float64, device=dev)
         self.started = False
-        self.chain_events = None  # optional: one event per step, see collect_step
 
     def _select(self, k):
         b = self._bufs[k]
@@ -80,8 +79,6 @@ class DeviceRollout(object):
         obs = env.current_obs(self._obs_step)
         logits = self.behaviour_logits[t]
         _policy_and_draw(model, obs, logits, self.actions[t], self.seed, self.step_count, env.env_id0)
-        if self.chain_events is not None:  # "the policy chain of step t is done, its emulator launch comes next"
-            self.chain_events[t].record()
         env.step_async(self.actions[t], self.rewards[t], self.dones[t], ep_acc=self.ep_stats)
         self.step_count += 1
 
@@ -356,6 +353,25 @@ class _GraphedLoss(object):
         self.vtrace_returns = None
 
 
+def fixed_refresh_points(T, updates_per_rollout, obs_dim):
+    """The default mid-rollout weight-refresh points of AsyncActorLearner: at env steps T/5, 2T/5, 3T/5 the
+    actors pick up what the learner published after a fixed share of the concurrent pass's updates.  The share
+    is what the learner has safely passed by then on an MI355X — at 42x42 its 51 updates take the time of ~20
+    env steps (28 % of the updates per fifth of the rollout is ~60 % of what it has done), at 84x84 learner
+    pass and rollout take equally long (9 % per fifth) — and depends on nothing measured at run time, so the
+    same command line is the same training run everywhere.  A slower learner makes the actors wait at a
+    point, never read a half-written publication (events order the two streams)."""
+    n, T = int(updates_per_rollout), int(T)
+    share = 0.28 if obs_dim <= 42 else 0.09
+    pts, last = [], 0
+    for k in (1, 2, 3):
+        s_, u = (k * T) // 5, min(n, int(k * share * n))
+        if 0 < s_ < T and u > last and u >= 2:
+            pts.append((s_, u))
+            last = u
+    return pts
+
+
 class AsyncActorLearner(object):
     """IMPALA's actor / learner decoupling (examples/IMPALA/train.py:155-194: sample threads fill a
     queue while the learn thread drains it; actors act with parameters that lag the learner by up
@@ -376,16 +392,18 @@ class AsyncActorLearner(object):
     learner before every rollout, so the behaviour policy lags the learner by exactly one update."""
 
     def __init__(self, alg, envs, sample_batch_steps, seed=0, elastic=False, train_batch_size=None,
-                 refresh_points='auto'):
+                 refresh_points='fixed'):
         """elastic: ElasticDeviceRollout (one env group; the env's horizon is the launch bound of a batch).
         train_batch_size: the reference's learner batch in ROWS (impala_config.py:31: 1000 = 20 sequences of
         T = 50; the learner concatenates actor batches until it holds at least that many, train.py:98).  None:
         one update per step() on the whole T*E rollout.  Otherwise step() runs E // (train_batch_size // T)
         updates, each on the next `train_batch_size // T` sequences of the rollout (the last one takes the
         remainder as well), every update one hipGraph replay (algorithms.impala.graphed.GraphedLearn).
-        refresh_points (train_batch_size mode): the actors' mid-rollout weight refresh, see below — 'auto'
-        (calibrated from the measured speed of learner pass and rollout), an explicit list of (env step,
-        updates of the concurrent pass done) pairs (deterministic: checkpoints, tests), or None / [] (off)."""
+        refresh_points (train_batch_size mode): the actors' mid-rollout weight refresh, see below — 'fixed'
+        (the default: `fixed_refresh_points`, a function of T, the updates per rollout and the frame size only,
+        so a run is the same run on every box), 'auto' (calibrated once from the measured speed of learner pass
+        and rollout: adapts to the machine, not reproducible across machines), an explicit list of (env step,
+        updates of the concurrent pass done) pairs, or None / [] (off)."""
         import copy
         self.alg = alg
         self.envs = list(envs) if isinstance(envs, (list, tuple)) else [envs]
@@ -443,9 +461,10 @@ class AsyncActorLearner(object):
         can = bool(self.sub_batches and not elastic and self.T >= 10 and int(os.environ.get('PARL_AMD_REFRESH', '1')))
         if can and refresh_points == 'auto':
             self._refresh_auto = True
+        elif can and refresh_points == 'fixed':
+            self.refresh_points = fixed_refresh_points(self.T, len(self.sub_batches), self.env.dim)
         elif can and refresh_points:
-            self.refresh_points = sorted((int(a), int(b)) for a, b in refresh_points)
-            assert all(0 < a < self.T and 0 < b <= len(self.sub_batches) for a, b in self.refresh_points)
+            self.refresh_points = self._checked_refresh_points(refresh_points)
         self._src = [p for p in alg.model.parameters()] + [b for b in alg.model.buffers()]
         self._dst = [p for p in self.actor_model.parameters()] + [b for b in self.actor_model.buffers()]
         cur = torch.cuda.current_stream(dev)
@@ -459,20 +478,6 @@ class AsyncActorLearner(object):
         self._pub = [[t.detach().clone() for t in self._src] for _ in range(n_pub)]
         self._pub_ready = [torch.cuda.Event() for _ in range(n_pub)]
         self._pass_enqueued = False  # a learner pass (with its publications) was enqueued before this rollout
-        # One update per rollout (no train_batch_size), synchronous launches: the learner's V-trace loss kernel —
-        # 107 MB through HBM in ~35 us, two workgroups per CU next to an emulator wave — is started when the
-        # policy chain of an env step has just finished, i.e. at the beginning of that step's emulator launch
-        # (1.3 ms of one wave per SIMD, everything else idle).  Landing in the actors' MFMA chain instead costs it
-        # 2x (45 vs 100 us, whichever the phase of the two streams happened to be) and the chain its CUs.  The
-        # rollout is enqueued BEFORE the learner pass so that the events exist; align_step = the first env step
-        # whose chain ends after the learner's forward passes (2 at 42x42).
-        self._align = bool(not elastic and len(self.envs) == 1 and not self.sub_batches
-                           and int(os.environ.get('PARL_AMD_ALIGN_LOSS', '1')))
-        self.align_step = min(2, self.T - 1)
-        self._align_ev = None
-        self._align_flag = {}
-        if self._align:
-            self.rollout.chain_events = [torch.cuda.Event() for _ in range(self.T)]
         self.graphed = {}
         if self.sub_batches:
             from .algorithms.impala.graphed import GraphedLearn
@@ -484,6 +489,19 @@ class AsyncActorLearner(object):
                                                         pool=pool)
                         pool = self.graphed[nb].pool
             self.learn_stream.synchronize()
+
+    def _checked_refresh_points(self, points):
+        """(env step, updates done) pairs a rollout can honour: 0 < step < T, and an update count some pass
+        reaches — waiting for a publication that is never recorded is a no-op on the device, the actors would
+        copy whatever the publication buffer held"""
+        pts = sorted((int(a), int(b)) for a, b in points)
+        n = len(self.sub_batches or ())
+        for a, b in pts:
+            if not (0 < a < self.T and 0 < b <= n):
+                raise ValueError('refresh point (%d, %d): need 0 < env step < %d and 0 < updates <= %d' % (a, b, self.T, n))
+        if len(set(a for a, _ in pts)) != len(pts):
+            raise ValueError('refresh points: one point per env step')
+        return pts
 
     def _calibrate_refresh(self):
         """'auto' refresh points: step 1 runs plain (graphs and caches warm up), step 2 is timed (learner pass and
@@ -627,48 +645,8 @@ class AsyncActorLearner(object):
         # parameters before it is done
         self._snapshot()
         ls = self.learn_stream
-        new_pending = None
-        if self._align:
-            for b in batches:
-                for v in b.values():
-                    v.record_stream(ls)
-            self._align_steps = getattr(self, '_align_steps', 0) + 1
-            timed = self._align_steps == 2  # the second step is timed once, the third reads it (one host wait)
-            if self._align_steps == 3 and self._align_ev is not None:
-                a0, a1, r0, r1 = self._align_ev
-                if self._align_flag.get('a1'):
-                    r1.synchronize()
-                    a1.synchronize()
-                    fwd_ms, step_ms = a0.elapsed_time(a1), r0.elapsed_time(r1) / self.T
-                    self.align_step = int(min(self.T - 1, max(1, -(-fwd_ms // max(step_ms, 1e-6)))))
-                    self.align_calibration = {'learner_forward_ms': fwd_ms, 'env_step_ms': step_ms}
-                self._align_ev = None
-            st = self.actor_streams[0]
-            if timed:
-                r0 = torch.cuda.Event(enable_timing=True)
-                with torch.cuda.stream(st):
-                    st.wait_event(self.snapshot_done)
-                    r0.record(st)
-            new_pending = self._collect()  # the rollout first: its per-step events exist when the learner waits on one
-            if timed:
-                r1 = torch.cuda.Event(enable_timing=True)
-                r1.record(st)
-                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                self._align_ev = (a0, a1, r0, r1)
-            ev = self.rollout.chain_events[self.align_step]
-
-            def hook():
-                cur = torch.cuda.current_stream(self.env.device)
-                if timed and self._align_ev is not None and not self._align_flag.get('a1'):
-                    a1.record(cur)
-                    self._align_flag['a1'] = True
-                cur.wait_event(ev)
-
-            self.alg.pre_loss_hook = hook
         with torch.cuda.stream(ls):
             ls.wait_event(self.snapshot_done)
-            if new_pending is not None and self._align_ev is not None and self._align_steps == 2:
-                self._align_ev[0].record(ls)
             for g in range(len(batches)):
                 ls.wait_event(self.batch_ready[g][k])
             if self.sub_batches:
@@ -684,14 +662,11 @@ class AsyncActorLearner(object):
             if self.gather_small:  # per-step scalars of the batch just learned, for global statistics
                 from . import dist as pdist
                 self.gathered = [pdist.all_gather_small({'rewards': b['rewards'], 'dones': b['dones'].to(torch.uint8),
-                                                         'actions': b['actions']}) for b in batches]
+                                                         'actions': b['actions']}, slot=g)
+                                 for g, b in enumerate(batches)]
             self.weights_ready.record(ls)
             self.batch_free[k].record(ls)
             self.step_done.record(ls)
-        self.alg.pre_loss_hook = None
-        if new_pending is not None:
-            self.pending = new_pending
-            return out
         for b in batches:
             for v in b.values():  # tensors made on an actor stream (e.g. dones.bool()), read on the learner's
                 v.record_stream(ls)
@@ -715,6 +690,10 @@ class AsyncActorLearner(object):
         return d
 
     def load_state_dict(self, d):
+        pts = None
+        if 'refresh_points' in d and not d.get('refresh_auto', False) and len(d['refresh_points']) <= len(self._pub):
+            # a calibrated run resumes with its points — checked like the constructor's, before anything is touched
+            pts = self._checked_refresh_points(d['refresh_points']) if d['refresh_points'] else []
         self.synchronize()
         torch.cuda.synchronize(self.env.device)
         for e, s in zip(self.envs, d['envs']):
@@ -723,8 +702,8 @@ class AsyncActorLearner(object):
             r.load_state_dict(s)
         self.actor_model.load_state_dict(d['actor_model'])
         self.updates = int(d['updates'])
-        if 'refresh_points' in d and not d.get('refresh_auto', False) and len(d['refresh_points']) <= len(self._pub):
-            self.refresh_points = [tuple(x) for x in d['refresh_points']]  # a calibrated run resumes with its points
+        if pts is not None:
+            self.refresh_points = pts
             self._refresh_auto, self._calib = False, None
         self._pass_enqueued = False
         self.pending = None

@@ -159,7 +159,7 @@ def test_graphed_pipeline_checkpoint_resumes_bit_identically(dev):
 
 
 def test_refresh_points_are_calibrated_after_the_second_step(dev):
-    """refresh_points='auto' (the default): step 2 is timed, step 3 fixes the points — at most three, at env steps
+    """refresh_points='auto': step 2 is timed, step 3 fixes the points — at most three, at env steps
     T/5, 2T/5, 3T/5, each asking for no more updates than a pass has, increasing; the pipeline keeps running and
     the calibrated points travel in its state_dict"""
     import parl_amd as parl
@@ -175,7 +175,7 @@ def test_refresh_points_are_calibrated_after_the_second_step(dev):
         model.value_fc.weight.mul_(0.05)
     alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
                                  clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
-    pipe = AsyncActorLearner(alg, [env], T, seed=1, train_batch_size=2 * T)
+    pipe = AsyncActorLearner(alg, [env], T, seed=1, train_batch_size=2 * T, refresh_points='auto')
     n = len(pipe.sub_batches)
     assert n == 12 and pipe.refresh_points == []
     for i in range(5):
@@ -189,4 +189,37 @@ def test_refresh_points_are_calibrated_after_the_second_step(dev):
     assert pipe.refresh_calibration['rollout_ms'] > 0 and pipe.refresh_calibration['learner_pass_ms'] > 0
     assert np.isfinite(float(loss.total_loss)) and pipe.updates == 5 * n
     assert [tuple(x) for x in pipe.state_dict()['refresh_points']] == pts
+    env.check_faults()
+
+
+def test_default_refresh_points_are_a_function_of_the_shapes_only(dev):
+    """the default ('fixed'): the points depend on T, the updates per rollout and the frame size — not on anything
+    timed — so the same command line is the same run on every box; a checkpoint whose points no pass can honour
+    (an update count beyond the pass, a step outside the rollout) is refused instead of silently never waited for"""
+    import parl_amd as parl
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel42
+    from parl_amd.rollout import AsyncActorLearner, fixed_refresh_points
+    assert fixed_refresh_points(50, 51, 42) == [(10, 14), (20, 28), (30, 42)]
+    assert fixed_refresh_points(50, 51, 84) == [(10, 4), (20, 9), (30, 13)]
+    torch.manual_seed(4)
+    T, E = 20, 24
+    env = DeviceVectorEnv('PongNoFrameskip-v4', E, dim=42, horizon=T, seed=2, device=dev)
+    model = AtariModel42(env.act_dim).to(dev)
+    alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
+                                 clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+    pipe = AsyncActorLearner(alg, [env], T, seed=1, train_batch_size=2 * T)
+    assert pipe.refresh_points == fixed_refresh_points(T, 12, 42) == [(4, 3), (8, 6), (12, 10)]
+    for _ in range(3):
+        loss, kl = pipe.step(1e-3, -0.01)
+    pipe.synchronize()
+    assert np.isfinite(float(loss.total_loss)) and pipe.updates == 36
+    sd = pipe.state_dict()
+    for bad in ([[4, 13]], [[20, 3]], [[0, 3]], [[4, 3], [4, 6]]):
+        with pytest.raises(ValueError):
+            pipe.load_state_dict(dict(sd, refresh_points=bad))
+    pipe.load_state_dict(sd)
+    assert pipe.refresh_points == [(4, 3), (8, 6), (12, 10)]
+    with pytest.raises(RuntimeError, match='load_optimizer_state_inplace'):
+        alg.optimizer.load_state_dict(alg.optimizer.state_dict())  # would detach the graphs from the state
     env.check_faults()

@@ -74,6 +74,12 @@ def main():
                  'c': (torch.rand(7, device=dev) > 0.5).to(torch.uint8)}
             g = pdist.all_gather_small(x)
             assert all(torch.equal(g[k][0], x[k]) and g[k].shape[0] == 1 for k in x)
+            # two env groups gather tensors of identical keys and shapes in one update: each slot owns
+            # its receive buffers, the first result must survive the second call
+            y = {k: v + 1 for k, v in x.items()}
+            g0, g1 = pdist.all_gather_small(x, slot=0), pdist.all_gather_small(y, slot=1)
+            assert all(g0[k].data_ptr() != g1[k].data_ptr() for k in x)
+            assert all(torch.equal(g0[k][0], x[k]) and torch.equal(g1[k][0], y[k]) for k in x)
             pdist.broadcast_model(m)
         st.synchronize()
     pdist.barrier()
