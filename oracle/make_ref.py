@@ -7,7 +7,10 @@
     A2C example scripts (benchmark/torch/a2c/), and oracle/_ref/{impala,a2c_paddle}/ — its headline
     examples (examples/IMPALA, examples/A2C: Paddle-flavoured), staged byte for byte so that the GPU box —
     which has no /root/reference — can run them UNMODIFIED through compat/{paddle,parl,gym}
-    (tests/test_reference_scripts.py).  oracle/_ref/ is git-ignored (never in history) but not
+    (tests/test_reference_scripts.py).
+  * oracle/_ref/torch_alg/{a2c,atari_model}.py — parl/algorithms/torch/a2c.py and the torch ActorCritic of
+    benchmark/torch/a2c/: the reference's learner update, timed on the host cores by bench.py's cpu_baseline
+    leg (oracle/ref_torch_baselines.py).  oracle/_ref/ is git-ignored (never in history) but not
     gpurun-ignored, like the built .so files.
 
 Every file is copied ONLY when its bytes differ from what is already there: an unconditional copy
@@ -24,6 +27,9 @@ A2C_SCRIPTS = ['train.py', 'actor.py', 'atari_agent.py', 'atari_model.py', 'a2c_
 # the reference's OWN (Paddle-flavoured) headline examples, run unmodified through compat/{paddle,parl,gym}
 EXAMPLES = {'impala': ('examples/IMPALA', ['train.py', 'actor.py', 'atari_agent.py', 'atari_model.py', 'impala_config.py']),
             'a2c_paddle': ('examples/A2C', ['train.py', 'actor.py', 'atari_agent.py', 'atari_model.py', 'a2c_config.py'])}
+# the reference's torch A2C algorithm + the torch ActorCritic it trains: the CPU learner baseline of BASELINE.md
+# section 3 (bench.py's cpu_baseline leg loads them by path, oracle/ref_torch_baselines.py)
+TORCH_ALG = {'parl/algorithms/torch/a2c.py': 'a2c.py', 'benchmark/torch/a2c/atari_model.py': 'atari_model.py'}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MD5 = {'pong': '60e0ea3cbe0913d39803477945e9e5ec', 'breakout': 'f34f08e5eb96e500e851a80be3277a56'}
 
@@ -64,6 +70,12 @@ def main():
             for f in files:
                 if copy_if_different(os.path.join(src_dir, f), os.path.join(out, f)):
                     changed.append('oracle/_ref/%s/%s' % (name, f))
+    out = os.path.join(ROOT, 'oracle', '_ref', 'torch_alg')
+    for src, name in TORCH_ALG.items():
+        if os.path.exists(os.path.join(REF, src)):
+            os.makedirs(out, exist_ok=True)
+            if copy_if_different(os.path.join(REF, src), os.path.join(out, name)):
+                changed.append('oracle/_ref/torch_alg/' + name)
     print('make_ref: ' + ('staged ' + ', '.join(changed) if changed else 'everything up to date'))
 
 

@@ -1,10 +1,13 @@
 """Pin the CPU oracle (oracle/scan_oracle.c) against the reference's own golden vectors
 (tests/golden/*.npz, generated from /root/reference by tests/golden/make_golden.py) and against
 numpy's np.random.choice.  CPU-only."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
-from conftest import golden_cases, load_golden
+from conftest import ROOT, golden_cases, load_golden
 
 
 def nan_to_none(x):
@@ -210,3 +213,44 @@ def test_py_baselines_match_reference_fixtures():
                                  float(c['clip_pg_rho_threshold']))
         np.testing.assert_allclose(vs, c['vs'], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(pg, c['pg_advantages'], rtol=1e-5, atol=1e-5)
+
+
+def test_torch_cpu_baselines_match_reference_fixtures():
+    """oracle/ref_torch_baselines.py (bench.py's torch-CPU baselines): the torch port of the
+    reference's per-t V-trace loop reproduces the reference's known-answer vectors; the staged reference torch
+    A2C.learn + ActorCritic (where build() staged them) load by path and reproduce the losses the same reference
+    classes produced for tests/golden/a2c_learn.npz"""
+    import torch
+    from oracle import ref_torch_baselines as rb
+    z = load_golden('vtrace_known_answer.npz')
+    for case in ('ref_B1', 'ref_B4'):
+        c = {k.split('/', 1)[1]: v for k, v in z.items() if k.startswith(case + '/')}
+        t = lambda k: torch.from_numpy(np.ascontiguousarray(c[k]))  # noqa: E731
+        vs, pg = rb.vtrace_torch(t('behaviour_actions_log_probs'), t('target_actions_log_probs'), t('discounts'),
+                                 t('rewards'), t('values'), t('bootstrap_value'), float(c['clip_rho_threshold']),
+                                 float(c['clip_pg_rho_threshold']))
+        np.testing.assert_allclose(vs.numpy(), c['vs'], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(pg.numpy(), c['pg_advantages'], rtol=1e-5, atol=1e-5)
+    if not os.path.exists(os.path.join(rb.STAGED, 'a2c.py')):
+        pytest.skip('oracle/_ref/torch_alg not staged (no /root/reference at build time)')
+    A2C, ActorCritic = rb._load_reference_a2c()
+    assert getattr(sys.modules.get('parl'), 'Model', None) is not torch.nn.Module  # the import stub is gone again
+    g = load_golden('a2c_learn.npz')
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    try:
+        from make_a2c_golden import init_weights
+    finally:
+        sys.path.pop(0)
+    A = int(g['dims'][0])
+    torch.manual_seed(3)
+    n0 = torch.get_num_threads()
+    torch.set_num_threads(4)
+    try:
+        model = ActorCritic(A)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in init_weights(A).items()})
+        alg = A2C(model, {'vf_loss_coeff': 0.5, 'learning_rate': 0.001})
+        out = alg.learn(torch.from_numpy(g['step0/obs']).float(), torch.from_numpy(g['step0/actions']),
+                        torch.from_numpy(g['step0/advantages']), torch.from_numpy(g['step0/target_values']), 1e-3, -0.01)
+    finally:
+        torch.set_num_threads(n0)
+    np.testing.assert_allclose([float(x.detach()) for x in out], g['step0/losses'], rtol=1e-4)
