@@ -26,7 +26,7 @@ from parl_amd.algorithms import A2C  # noqa: E402
 from parl_amd.utils.scheduler import LinearDecayScheduler  # noqa: E402
 
 CONFIG = dict(master_address='localhost:8010', env_name='CartPole-v1', actor_num=4, env_num=4, sample_batch_steps=20,
-              gamma=0.99, vf_loss_coeff=0.5, start_lr=0.005, max_sample_steps=200 * 4 * 4 * 20, entropy_coeff=-0.01)
+              gamma=0.99, vf_loss_coeff=0.5, start_lr=0.01, max_sample_steps=3 * 200 * 4 * 4 * 20, entropy_coeff=-0.01)
 CONFIG['lambda'] = 1.0
 
 
