@@ -708,9 +708,11 @@ def main():
             out['impala_one_update'] = one
         # --- roofline of the V-trace kernel at the workload shape (HBM-bound scan) ---
         Bl = E if G == 1 else Eg
-        if hl_in is not None:
+        if hl_in is not None or (graphed_mode and A in (4, 6) and T <= 64):
             by = heads_loss_bytes(T, Bl, A)
             alone, alone_stats = heads_loss_alone(dev, T, Bl, A)
+            if hl_in is None:  # ranks sharing a GPU / elastic / --no-overlap: no one-update pipeline was run beside it
+                hl_in, hl_in_stats = alone, None
             out['roofline'] = {
                 'kernel': 'impala_heads_loss_kernel (policy_fc + value_fc + log-softmax / entropy / KL + V-trace + loss '
                           'sums + gradient w.r.t. the trunk output and the heads, two waves per sequence, T=%d B=%d A=%d; '
@@ -720,8 +722,10 @@ def main():
                 # `frac` is the IN-PIPELINE figure: the kernel beside the actors' emulator / MFMA kernels, wherever in
                 # their step the two free-running streams happen to put it (no launch-phase tuning)
                 'achieved': by / hl_in / 1e9, 'frac': by / hl_in / 1e9 / HBM_PEAK_GBPS,
-                'frac_in_pipeline': by / hl_in / 1e9 / HBM_PEAK_GBPS, 'in_pipeline_us': hl_in_stats,
-                'in_pipeline_measured_in': 'impala_one_update leg (this process)' if one is not None else 'the timed region',
+                'frac_in_pipeline': (by / hl_in / 1e9 / HBM_PEAK_GBPS) if hl_in_stats else None, 'in_pipeline_us': hl_in_stats,
+                'in_pipeline_measured_in': ('impala_one_update leg (this process)' if one is not None else
+                                            'the timed region' if hl_in_stats else
+                                            'not measured in this configuration: frac is the stand-alone figure'),
                 'frac_alone': by / alone / 1e9 / HBM_PEAK_GBPS, 'achieved_alone': by / alone / 1e9, 'alone_us': alone_stats,
                 'note': 'the V-trace scan at the WORKLOAD shape (T=50 x 1024 sequences), fused with the two heads so that '
                         'the 52 MB trunk output and its gradient cross HBM once each.  In the headline\'s learner mode '

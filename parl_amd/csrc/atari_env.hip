@@ -117,6 +117,9 @@ DEVI void store_env(const Emu& e, const Wrap& v, uint8_t* blob, int lane) {
 #ifdef PARLHIP_ENV_TIMING  // diagnostic build only (tools/env_wave_times.py): per-wave start / end clocks
 __device__ unsigned long long g_env_t0[8192], g_env_t1[8192];
 #endif
+#ifdef PARLHIP_ENV_REGIONS  // diagnostic build only (tools/env_regions.py): where a wave's launch goes
+__device__ unsigned long long g_env_regions[8192][10];
+#endif
 
 // One wavefront per env.  mode STEP: VectorEnv.step; RESET: VectorEnv.reset; SNAPSHOT: wave k
 // builds reset snapshot k (noops = k+1) for the O(1) real-reset path.
@@ -154,6 +157,10 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
 
   Emu emu;
   Wrap v;
+#ifdef PARLHIP_ENV_REGIONS
+  const unsigned long long k0 = __builtin_readcyclecounter();
+  for (int i = 0; i < 4; ++i) { emu.rt[i] = 0; emu.rn[i] = 0; }
+#endif
   emu.romw = rom_lds;
   emu.rom_mask = prm.rom_size - 1;
   emu.lane = lane;
@@ -416,6 +423,12 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
 #ifdef PARLHIP_ENV_TIMING
   if (lane == 0 && e < 8192) g_env_t1[e] = wall_clock64();
 #endif
+#ifdef PARLHIP_ENV_REGIONS
+  if (lane == 0 && e < 8192) {
+    for (int i = 0; i < 4; ++i) { g_env_regions[e][i] = emu.rt[i]; g_env_regions[e][4 + i] = (unsigned long long)emu.rn[i]; }
+    g_env_regions[e][8] = __builtin_readcyclecounter() - k0;
+  }
+#endif
 }
 
 // Row accounting of an elastic launch, before the emulator: who starts a row, who goes on, who waits.
@@ -611,6 +624,14 @@ PARLHIP_EXPORT int parlhip_atari_vec_step_elastic(void* states, const uint32_t* 
                                                        cur_slot, link, since);
   return check_launch();
 }
+
+#ifdef PARLHIP_ENV_REGIONS
+PARLHIP_EXPORT int parlhip_debug_env_regions(unsigned long long* host, int n) {
+  if (n > 8192) return PARLHIP_EINVAL;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(parlhip::atari::g_env_regions), (size_t)n * 80) != hipSuccess) return PARLHIP_EINVAL;
+  return PARLHIP_OK;
+}
+#endif
 
 #ifdef PARLHIP_ENV_TIMING
 PARLHIP_EXPORT int parlhip_debug_env_clocks(unsigned long long* t0_host, unsigned long long* t1_host, int n) {

@@ -56,6 +56,31 @@ QUIET_STORE_GAMES = ('pong', )
 # 783 of the 14,100 ISA branches a Pong frame executes (Breakout: 928 of 19,300): the rest are address-class,
 # no-op-store, flag and renderer conditionals inside the blocks.
 BRANCH_PGO = bool(int(os.environ.get('PARLHIP_BRANCH_PGO', '1')))
+# Hot loops as TRACES (round 4; PARLHIP_TRACE_LOOPS=0 switches it off).  A single-stream innermost 6507 loop
+# (Cart.find_loops) whose back edge the profile says is hot is emitted a second time, specialised, in front
+# of its generic blocks:
+#   * ONE way in (the loop head, after a precondition test), any number of ways out, forward edges only inside:
+#     reducible control flow.  The generic copy of the same instructions loses its back edge (it returns to the
+#     dispatcher, which re-enters the trace), so it is acyclic: LLVM's FixIrreducible / UnifyLoopExits guard-flag
+#     chains (~15 scalar moves + a branch on every block with a hand-over path, a dozen blocks per iteration of
+#     Pong's scanline loop) disappear from both.
+#   * facts that hold for the whole loop are established ONCE at the head instead of per instruction: the stack
+#     pointer (S == its dataflow value: every PHP / PLA inside has a constant address), binary mode (no decimal
+#     arm in ADC / SBC), zero-page bytes the loop only reads (held in scalar registers: a v_readlane round trip
+#     is ~33 clocks against 4.5 for a scalar op, and Pong's loop reads 18 such bytes per iteration), pointers of
+#     (zp),Y loads that stay inside the cartridge (no address-class tree), and scalar shadows of the TIA
+#     registers its stores are compared with (the no-op test of a GRP1 store reads five lanes of the register
+#     file).  A real TIA change still leaves through `pend` exactly like the generic block — after the
+#     interpreter's TIA stages the rest of that iteration runs in the generic blocks, the next one here.
+# An oracle trace of Pong shows 79 % of the 91 iterations per frame complete without any hand-over.
+TRACE_LOOPS = bool(int(os.environ.get('PARLHIP_TRACE_LOOPS', '1')))
+# Measured on MI355X, E=1024, after reset (profiles/r04_trace_loops.log): Pong 1.12 -> 1.02 ms per agent step (PMC per
+# frame: 111.8 k -> 100.5 k instructions, 13.9 k -> 12.7 k branches; the translated code's share of a frame 400 k -> 295 k
+# clocks).  Breakout 1.81 -> 1.98 ms: its loops index RAM with X (`LDA zp,X`, `DEC zp,X`: nothing to hoist), what is left
+# are the stack-pointer / binary-mode facts, and the second copy of two 40-instruction loops with the playfield queue
+# inlined takes the kernel from 669 to 1313 SGPR spills.  Per game, therefore:
+TRACE_GAMES = tuple(x for x in os.environ.get('PARLHIP_TRACE_GAMES', 'pong').split(',') if x)
+TRACE_MIN_TAKEN = 8000   # back-edge "taken" count in cart_branch_profile.json (1600 profiled frames: >= 5 per frame)
 LOOP_REENTRY_GAMES = tuple(x for x in os.environ.get('PARLHIP_LOOP_REENTRY', '').split(',') if x)  # default: none
 
 # ---- mirrors atari_defs.hpp (decode_opcode) ------------------------------------------------------
@@ -119,6 +144,140 @@ def length(mode):
 FLAGS = dict(FN=0x80, FV=0x40, FU=0x20, FB=0x10, FD=0x08, FI=0x04, FZ=0x02, FC=0x01)
 
 
+PLAIN_REGS = {0x01, 0x04, 0x05, 0x06, 0x07, 0x08, 0x09, 0x0a, 0x0b, 0x0c, 0x0d, 0x0e, 0x0f, 0x1d, 0x1e, 0x1f, 0x25,
+              0x26, 0x27}  # Emu::kPlainRegs
+T_DGRP0, T_DGRP1, T_DENABL = 0x35, 0x36, 0x37   # atari_defs.hpp TiaLane (derived lanes of the register file)
+
+
+class Trace(object):
+    """What holds for every iteration of a hot single-stream loop, found by a forward pass over its
+    instruction stream (forward branches only, plus the back edge(s) to the head)."""
+
+    def __init__(self, cart, head, stream):
+        self.head, self.stream, self.sset = head, stream, set(stream)
+        code = cart.code
+        ops = [code[a][2] for a in stream]
+        # ---- stack pointer / X as constants (same transfer function as Cart.stack_hints, now as FACTS under
+        # the precondition S == S_head): state before each instruction, met over fall-through and branch edges
+        UNK = None
+        s_head = cart.s_hint.get(head)
+        st_in = {head: (s_head, UNK)}
+        self.S = {}
+        ok = s_head is not None
+
+        def meet(a, b):
+            return tuple(x if x == y else UNK for x, y in zip(a, b))
+
+        back = []
+        for i, a in enumerate(stream):
+            if a not in st_in:
+                st_in[a] = (UNK, UNK)  # unreachable by fall-through (cannot happen in a linear stream)
+            S, X = st_in[a]
+            self.S[a] = S
+            mode, kind, op, b1, b2 = code[a]
+            if op == 'LDX':
+                X = b1 if mode == M_IMM else UNK
+            elif op == 'TAX':
+                X = UNK
+            elif op == 'TSX':
+                X = S
+            elif op in ('INX', 'DEX'):
+                X = UNK if X is UNK else (X + (1 if op == 'INX' else -1)) & 0xff
+            elif op == 'TXS':
+                S = X
+            elif op in ('PHA', 'PHP'):
+                S = UNK if S is UNK else (S - 1) & 0xff
+            elif op in ('PLA', 'PLP'):
+                S = UNK if S is UNK else (S + 1) & 0xff
+            elif op == 'JSR':
+                S = UNK  # leaves the trace
+            out = (S, X)
+            nxt = (a + length(mode)) & 0xffff
+            if mode == M_REL:
+                t = (a + 2 + (b1 - 256 if b1 & 0x80 else b1)) & 0xffff
+                if t == head:
+                    back.append(out)
+                elif t in self.sset:
+                    st_in[t] = meet(st_in[t], out) if t in st_in else out
+            if i + 1 < len(stream):
+                n2 = stream[i + 1]
+                st_in[n2] = meet(st_in[n2], out) if n2 in st_in else out
+        if not back or any(o[0] != s_head for o in back):
+            ok = False
+        self.use_S = ok
+        if not ok:
+            self.S = {a: None for a in stream}
+        # ---- binary mode
+        self.has_alu = any(o in ('ADC', 'SBC') for o in ops)
+        self.d_clear = self.has_alu and not any(o in ('SED', 'PLP') for o in ops)
+        # ---- RAM bytes the loop only reads at static addresses
+        reads, written, dyn_store = set(), set(), False
+        for a in stream:
+            mode, kind, op, b1, b2 = code[a]
+            if kind == K_READ:
+                if mode == M_ZP and b1 >= 0x80:
+                    reads.add(b1 & 0x7f)
+                elif mode == M_ABS and not ((b1 | (b2 << 8)) & 0x1000) and ((b1 | (b2 << 8)) & 0x280) == 0x80:
+                    reads.add(b1 & 0x7f)
+                elif mode == M_IZY and 0x80 <= b1 < 0xff:
+                    reads |= {b1 & 0x7f, (b1 + 1) & 0x7f}
+            elif kind in (K_WRITE, K_RMW):
+                if mode == M_ZP:
+                    if b1 >= 0x80:
+                        written.add(b1 & 0x7f)
+                elif mode == M_PUSH:
+                    S = self.S[a]
+                    if S is None:
+                        dyn_store = True
+                    elif S & 0x80:
+                        written.add(S & 0x7f)
+                else:
+                    dyn_store = True   # zp,X / zp,Y / absolute / indirect stores: the address is a run-time value
+            if op in ('JSR', 'BRK'):
+                pass  # pushes, then leaves the trace: nothing after it runs here
+        self.hoist = set() if dyn_store else (reads - written)
+        # ---- (zp),Y loads whose pointer bytes are hoisted: one range test at the head instead of a tree per load
+        self.rom_ptrs = sorted({code[a][3] for a in stream if code[a][0] == M_IZY and code[a][1] == K_READ
+                                and 0x80 <= code[a][3] < 0xff and {code[a][3] & 0x7f, (code[a][3] + 1) & 0x7f} <= self.hoist})
+        # ---- scalar shadows of the TIA registers the loop's stores are compared with
+        self.shadows = set()
+        quiet = cart.name in QUIET_STORE_GAMES
+        for a in stream:
+            mode, kind, op, b1, b2 = code[a]
+            if kind != K_WRITE:
+                continue
+            reg = None
+            if mode == M_ZP and b1 < 0x80:
+                reg = b1 & 0x3f
+            elif mode == M_PUSH and self.S[a] is not None and not (self.S[a] & 0x80):
+                reg = self.S[a] & 0x3f
+            if reg is None:
+                continue
+            if reg in PLAIN_REGS and not (0x0d <= reg <= 0x0f):
+                self.shadows.add(reg)
+            elif reg == 0x1b:
+                self.shadows |= {0x1b, 0x1c, T_DGRP1}
+            elif reg == 0x1c:
+                self.shadows |= {0x1b, 0x1c, 0x1f, T_DGRP0, T_DENABL}
+        self.quiet = quiet
+
+    def precondition(self):
+        c = []
+        if self.use_S:
+            c.append('e.S == 0x%02x' % self.S[self.head])
+        if self.d_clear:
+            c.append('!(e.P & FD)')
+        for b1 in self.rom_ptrs:
+            c.append('(hp_%02x & 0x1000) && ((hp_%02x + 0xff) & 0x1000)' % (b1, b1))
+        return ' && '.join('(%s)' % x for x in c) if c else '1'
+
+    def prologue(self):
+        L = ['const int h_%02x = e.ram_rd(0x%02x);' % (x, x) for x in sorted(self.hoist)]
+        L += ['const int hp_%02x = h_%02x | (h_%02x << 8);' % (b1, b1 & 0x7f, (b1 + 1) & 0x7f) for b1 in self.rom_ptrs]
+        L += ['int ts_%02x = e.t(0x%02x);' % (r, r) for r in sorted(self.shadows)]
+        return L
+
+
 class Cart(object):
     def __init__(self, name, rom):
         assert len(rom) in (2048, 4096)
@@ -137,7 +296,24 @@ class Cart(object):
         self.discover()
         self.s_hint = self.stack_hints()
         self.cur = None       # block being emitted (goto() needs the source of an edge)
-        self.loops = self.find_loops() if name in LOOP_REENTRY_GAMES else []
+        self.tc = None        # trace being emitted (None: generic blocks)
+        self.branch_taken = {}
+        if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'cart_branch_profile.json')):
+            import json
+            ent = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'cart_branch_profile.json'))).get(
+                '%08x' % (zlib.crc32(rom) & 0xffffffff))
+            if ent:
+                self.branch_taken = {int(a, 16): tk for a, (nt, tk) in ent['branches'].items()}
+        all_loops = self.find_loops()
+        self.loops = all_loops if name in LOOP_REENTRY_GAMES else []
+        self.traces = {}      # loop head -> Trace
+        self.trace_of = {}    # instruction start inside a traced loop -> its head
+        if TRACE_LOOPS and name in TRACE_GAMES and name not in LOOP_REENTRY_GAMES:
+            for h, stream in all_loops:
+                if max(self.branch_taken.get(x, 0) for x in stream) >= TRACE_MIN_TAKEN:
+                    self.traces[h] = Trace(self, h, stream)
+                    for x in stream:
+                        self.trace_of[x] = h
         self.loop_of = {}     # instruction start inside a re-entry loop -> index of the loop
         for i, (h, stream) in enumerate(self.loops):
             for x in stream:
@@ -305,7 +481,7 @@ class Cart(object):
         merge) — with every address a switch case, each block had the dispatch as a predecessor.
         A PC outside this set (computed JMP (), RTS tricks) is always safe: the switch returns, the
         interpreter executes that instruction and dispatch is tried again at the next one."""
-        ent = {self.word(0xfffc), self.word(0xfffe)}
+        ent = {self.word(0xfffc), self.word(0xfffe)} | set(self.traces)
         for a in self.code:
             mode, kind, op, b1, b2 = self.code[a]
             if mode == M_REL or op == 'JMP':
@@ -343,6 +519,15 @@ class Cart(object):
     def goto(self, a):
         if a not in self.code:
             return '{ e.PC = 0x%04x; return; }' % a
+        if self.tc is not None:
+            if a == self.tc.head:
+                return 'goto TL_%04X;' % a
+            if a in self.tc.sset and a > self.cur:
+                return 'goto TL_%04X;' % a
+        elif a in self.traces and self.trace_of.get(self.cur) == a:
+            # the generic copy of a traced loop has no back edge: the dispatcher re-enters through the trace's
+            # precondition test (which makes this copy acyclic — no irreducible loop for LLVM to repair)
+            return '{ e.PC = 0x%04x; e.pend = -2; return; }' % a
         if self.inside_edge_ok(a):
             return 'goto %s;' % self.label(a)
         return '{ e.PC = 0x%04x; /*rare*/ return; }' % a
@@ -350,7 +535,35 @@ class Cart(object):
     def fallback(self, a):
         return ['{ e.PC = 0x%04x; return; }' % a]
 
+    def rd(self, a7):
+        """static RAM read (7-bit index): the trace's scalar copy when the loop only reads that byte"""
+        if self.tc is not None and a7 in self.tc.hoist:
+            return 'h_%02x' % a7
+        return 'e.ram_rd(0x%02x)' % a7
+
+    def store_stmt(self, reg, val, pend, dc=None):
+        """the test-and-hand-over statement of a TIA register store with a CONSTANT register number: nothing
+        happens when the store changes no pixel, otherwise `pend` (a block that leaves)"""
+        tc = self.tc
+        if tc is None or reg not in tc.shadows or reg in (T_DGRP0, T_DGRP1, T_DENABL):
+            return 'if (__builtin_expect(!e.%s(0x%02x, %s), 0)) %s' % (self.store_test, reg, val, pend)
+        v = '(%s)' % val
+        if 0x06 <= reg <= 0x09:
+            v = '((%s) & 0xfe)' % val
+        if reg == 0x1b:      # Emu::tia_store_is_nop: GRP0 also latches the delayed GRP1
+            nop = '(ts_1b == v_) & (ts_%02x == ts_1c)' % T_DGRP1
+        elif reg == 0x1c:    # GRP1 also latches the delayed GRP0 and ENABL
+            nop = '(ts_1c == v_) & (ts_%02x == ts_1b) & (ts_%02x == ts_1f)' % (T_DGRP0, T_DENABL)
+        else:
+            nop = 'ts_%02x == v_' % reg
+        quiet = ''
+        if tc.quiet and 0x1d <= reg <= 0x1f:  # Emu::tia_store_quiet: D1 unchanged -> the byte is stored, no pixel changes
+            quiet = 'if (!((ts_%02x ^ v_) & 0x02)) { ts_%02x = v_; e.tset(0x%02x, v_); } else ' % (reg, reg, reg)
+        return '{ const int v_ = %s; if (__builtin_expect(!(%s), 0)) { %s%s } }' % (v, nop, quiet, pend)
+
     def emit_read_op(self, op):
+        if self.tc is not None and self.tc.d_clear and op in ('ADC', 'SBC'):
+            return 'e.%s_bin(m);' % op.lower()
         return {
             'LDA': 'e.A = m; e.set_nz(e.A);', 'LDX': 'e.X = m; e.set_nz(e.X);', 'LDY': 'e.Y = m; e.set_nz(e.Y);',
             'ORA': 'e.A |= m; e.set_nz(e.A);', 'AND': 'e.A &= m; e.set_nz(e.A);', 'EOR': 'e.A ^= m; e.set_nz(e.A);',
@@ -373,7 +586,7 @@ class Cart(object):
             elif mode == M_ZP:
                 if b1 < 0x80:
                     return fb
-                pre, dc = ['const int m = e.ram_rd(0x%02x);' % (b1 & 0x7f)], 3
+                pre, dc = ['const int m = %s;' % self.rd(b1 & 0x7f)], 3
             elif mode in (M_ZPX, M_ZPY):
                 idx = 'e.X' if mode == M_ZPX else 'e.Y'
                 # RAM, or an input port (INPTx: does not depend on the picture; Breakout polls `LDA $38,X`
@@ -389,7 +602,7 @@ class Cart(object):
                 if ea & 0x1000:
                     pre = ['const int m = 0x%02x;' % self.byte(ea)]
                 elif (ea & 0x280) == 0x80:
-                    pre = ['const int m = e.ram_rd(0x%02x);' % (ea & 0x7f)]
+                    pre = ['const int m = %s;' % self.rd(ea & 0x7f)]
                 elif (ea & 0x280) == 0x280:
                     pre, dc = ['e.cyc += 4;', 'const int m = e.riot_read(0x%04x);' % ea], 0
                 elif (ea & 0x0f) >= 8:
@@ -430,15 +643,30 @@ class Cart(object):
                 if b1 < 0x80 or b1 == 0xff:
                     return fb
                 pre = [
-                    'const int base = e.ram_rd(0x%02x) | (e.ram_rd(0x%02x) << 8);' % (b1 & 0x7f, (b1 + 1) & 0x7f),
-                    'const int ea = (base + e.Y) & 0xffff;', 'const int dc = 5 + (((ea ^ base) & 0xff00) ? 1 : 0);',
-                    'int m;', 'if (ea & 0x1000) m = e.rom_byte(ea);',
-                    'else if ((ea & 0x280) == 0x80) m = e.ram_rd(ea & 0x7f);', 'else { --n; e.PC = 0x%04x; /*rare*/ return; }' % a
-                ]
+                    'const int base = %s | (%s << 8);' % (self.rd(b1 & 0x7f), self.rd((b1 + 1) & 0x7f)),
+                    'const int ea = (base + e.Y) & 0xffff;', 'const int dc = 5 + (((ea ^ base) & 0xff00) ? 1 : 0);']
+                if self.tc is not None and b1 in self.tc.rom_ptrs:
+                    pre += ['const int m = e.rom_byte(ea);']   # the trace's precondition: base .. base+255 inside the cartridge
+                else:
+                    pre += ['int m;', 'if (ea & 0x1000) m = e.rom_byte(ea);',
+                            'else if ((ea & 0x280) == 0x80) m = e.ram_rd(ea & 0x7f);',
+                            'else { --n; e.PC = 0x%04x; /*rare*/ return; }' % a]
             elif mode == M_PULL and op == 'PLA':
                 # pull from a stack in RAM (a pull from TIA space reads collision latches: interpreter)
                 # ... or from an input-port address in TIA space (Breakout pulls from $1F inside its
                 # kernel: the read returns the bus noise = the next opcode byte and needs no picture)
+                tS = self.tc.S.get(a) if self.tc is not None else None
+                if tS is not None:
+                    k1 = (tS + 1) & 0xff
+                    if k1 & 0x80:
+                        L += ['const int m = e.ram_rd(0x%02x);' % (k1 & 0x7f), 'e.S = 0x%02x;' % k1, 'e.A = m; e.set_nz(e.A);',
+                              'e.cyc += 4;']
+                        return L
+                    if (k1 & 0x0f) >= 8:
+                        L += ['e.cyc += 4;', 'const int m = e.tia_read(0x%02x, 0x%02x);' % (k1, b1), 'e.S = 0x%02x;' % k1,
+                              'e.A = m; e.set_nz(e.A);']
+                        return L
+                    return fb
                 pre = ['const int s1 = (e.S + 1) & 0xff;', 'int dc = 4, m;']
                 h = self.s_hint.get(a)
                 hs1 = None if h is None else (h + 1) & 0xff
@@ -561,14 +789,19 @@ class Cart(object):
                     return ['if (e.tia_store_is_nop(0x%02x, %s)) e.cyc += %d;' % (reg, val, dc),
                             'else { e.cyc += %d; if (!e.pf_enqueue(0x%02x, %s)) { --n; e.pend = 0x%02x | ((%s) << 8); '
                             'e.PC = 0x%04x; return; } }' % (dc - 1, reg, val, static, val, nxt)]
-                return ['if (__builtin_expect(!e.%s(0x%02x, %s), 0)) %s' % (self.store_test, reg, val, pend % ('0x%02x' % static)),
-                        'e.cyc += %d;' % dc]
+                return [self.store_stmt(reg, val, pend % ('0x%02x' % static)), 'e.cyc += %d;' % dc]
             generic = [
                 'const int ea = %s;' % ea,
                 'if (ea & 0x80) e.ram_wr(ea & 0x7f, %s);' % val,
                 'else if (__builtin_expect(!e.%s(ea & 0x3f, %s), 0)) %s' % (self.store_test, val, pend % 'ea'),
                 ('%s e.cyc += %d;' % (dec_s, dc)).strip()
             ]
+            tS = self.tc.S.get(a) if (self.tc is not None and mode == M_PUSH) else None
+            if tS is not None and not ((tS & 0x3f) == 0x02 and not (tS & 0x80)):
+                # inside a trace the stack pointer is a FACT (precondition at the head): no guard, no generic arm
+                if tS & 0x80:
+                    return ['e.ram_wr(0x%02x, %s);' % (tS & 0x7f, val), 'e.S = 0x%02x; e.cyc += %d;' % ((tS - 1) & 0xff, dc)]
+                return [self.store_stmt(tS & 0x3f, val, pend % ('0x%02x' % tS)), 'e.S = 0x%02x; e.cyc += %d;' % ((tS - 1) & 0xff, dc)]
             h = self.s_hint.get(a) if mode == M_PUSH else None
             if h is None or (h & 0x3f) == 0x02 and not (h & 0x80):
                 return generic
@@ -595,6 +828,44 @@ class Cart(object):
             'e.cyc += %d;' % (dc + 2)
         ]
 
+    def emit_trace(self, tr):
+        """the specialised copy of a hot loop (see TRACE_LOOPS), placed at the loop head's label"""
+        out = ['  %s: {  // ---- trace of the loop %04x .. %04x (%d instructions)' % (self.label(tr.head), tr.head, tr.stream[-1], len(tr.stream))]
+        for ln in tr.prologue():
+            out.append('    ' + ln)
+        out.append('    if (__builtin_expect(%s, 1)) {' % tr.precondition())
+        self.tc = tr
+        try:
+            for i, a in enumerate(tr.stream):
+                mode, kind, op, b1, b2 = self.code[a]
+                self.cur = a
+                body = self.emit(a)
+                is_fb = len(body) == 1 and body[0].startswith('{ e.PC')
+                out.append('      TL_%04X: {  // %s mode %d' % (a, op, mode))
+                if a == tr.head:
+                    out.append('        PARLHIP_TRACE_ITER(0x%04x);' % a)  # empty on the device; the host harness counts
+                if MARKERS:
+                    out.append('        asm volatile("; @@TRC %04x");' % a)
+                if is_fb:
+                    out.append('        ' + body[0])
+                else:
+                    out.append('        ++n;')
+                    for ln in body:
+                        if ln:
+                            out.append('        ' + ln)
+                out.append('      }')
+                terminal = op in ('JMP', 'JAM', 'BRK', 'RTS', 'RTI', 'JMPI', 'JSR') or is_fb
+                nxt = (a + length(mode)) & 0xffff
+                if i + 1 == len(tr.stream) and not terminal:
+                    self.tc = None  # the edge that leaves the trace at its end is a generic edge
+                    self.cur = None
+                    out.append('      ' + self.goto(nxt))
+        finally:
+            self.tc = None
+        out.append('    }')
+        out.append('  }')
+        return out
+
     def source(self, game_const):
         addrs = sorted(self.code)
         out = []
@@ -606,6 +877,9 @@ class Cart(object):
         out.append('  if (n > kNativeInstrLimit) return;')
         if self.loops:
             out.append('  int sel = 0;  // re-entry into the middle of a loop goes through its head (find_loops)')
+        hot = sorted(self.traces, key=lambda h: -max(self.branch_taken.get(x, 0) for x in self.traces[h].stream))
+        for h in hot[:3]:  # the hottest loop heads before the compare tree of the switch (every dirty iteration re-enters here)
+            out.append('  if (e.PC == 0x%04x) goto %s;' % (h, self.label(h)))
         out.append('  switch (e.PC) {')
         entries = self.entries()
         sel_cases = {}  # loop index -> [(sel value, address)]
@@ -629,7 +903,11 @@ class Cart(object):
             body = self.emit(a)
             is_fb = len(body) == 1 and body[0].startswith('{ e.PC')
             native += 0 if is_fb else 1
-            out.append('  %s: {  // %s mode %d' % (self.label(a), op, mode))
+            if a in self.traces:
+                out += self.emit_trace(self.traces[a])
+                out.append('  {  // %s mode %d (generic copy of the trace head)' % (op, mode))
+            else:
+                out.append('  %s: {  // %s mode %d' % (self.label(a), op, mode))
             if a in head_switch:
                 out.append(head_switch[a])
             if MARKERS:

@@ -43,6 +43,33 @@ def test_entry_set_structure(name):
     src = c.source('GAME_PONG' if name == 'pong' else 'GAME_BREAKOUT')
     assert src.count('case 0x') == len(ent)
     assert 'e.pend = ' in src                        # real TIA stores are handed over, not re-decoded
+    assert set(c.traces) <= ent                      # a hot loop's trace is entered through the dispatcher
+
+
+def test_hot_loops_are_emitted_as_traces():
+    """gen_cart_native TRACE_LOOPS: Pong's scanline loop ($F5E0 .. $F63C, 91 iterations per frame) gets a specialised
+    single-entry copy in front of its generic blocks — stack pointer, binary mode and the (zp),Y pointers established
+    once at the head, the zero-page bytes the loop only reads hoisted, scalar shadows of the TIA registers its stores
+    are compared with — and the generic copy's back edge returns to the dispatcher (no cycle left in it)"""
+    g, c = _cart('pong')
+    assert 0xf5e0 in c.traces
+    tr = c.traces[0xf5e0]
+    assert tr.stream[0] == 0xf5e0 and tr.stream[-1] == 0xf63c and len(tr.stream) == 57
+    assert tr.use_S and tr.S[0xf5e0] == 0x1d and tr.S[0xf61e] == 0x1f and tr.S[0xf629] == 0x1e   # PHP -> ENAM0 / ENABL / ENAM1
+    assert tr.d_clear and tr.rom_ptrs == [0x9b, 0x9d, 0x9f]
+    assert {0x33, 0x26, 0x34, 0x27, 0x00} <= tr.hoist and not ({0x04, 0x05} & tr.hoist)   # $84 / $85 are written in the loop
+    assert {0x1b, 0x1c, 0x1d, 0x1e, 0x1f} <= tr.shadows
+    src = c.source('GAME_PONG')
+    assert 'trace of the loop f5e0 .. f63c' in src and 'TL_F5E0:' in src and 'goto TL_F5E0;' in src
+    assert 'e.sbc_bin(m);' in src and 'const int m = h_33;' in src
+    assert '{ e.PC = 0xf5e0; e.pend = -2; return; }' in src          # the generic copy's back edge
+    assert 'if (e.PC == 0xf5e0) goto L_F5E0;' in src                  # the hottest head ahead of the switch's compare tree
+    i0 = src.index('TL_F5E0:')
+    body = src[i0:src.index('generic copy of the trace head', i0)]
+    assert 'e.S ==' not in body and body.count('TL_') > 57           # no stack-pointer guards inside the trace
+    # breakout: its loops index RAM with X (nothing to hoist) and the second copy costs more than it saves (measured)
+    g, b = _cart('breakout')
+    assert not b.traces
 
 
 @pytest.mark.parametrize('name,max_wait', [('pong', 10.0), ('breakout', 10.0)])
@@ -132,6 +159,9 @@ def test_translated_cartridge_on_host_equals_oracle(tmp_path, name, game, loops)
     assert 'frames identical' in p.stdout
     translated = float(p.stdout.split('identical;')[1].split()[0])
     assert translated > 3000          # execution really goes through the translated blocks
+    if name == 'pong' and not loops:  # the product build: the scanline loop runs as a trace (counted by the harness)
+        it = [float(ln.split(':')[1].split()[0]) for ln in p.stdout.splitlines() if ln.startswith('trace f5e0')]
+        assert it and it[0] > 80, p.stdout[-500:]
 
 
 def _fn_body(text, signature):

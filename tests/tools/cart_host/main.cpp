@@ -82,7 +82,41 @@ struct Emu {
     P = (P & ~FV) | ((((old ^ m) & (old ^ A)) >> 1) & FV);
     set_nz(A);
   }
+  void adc_bin(int m) {
+    const int old = A;
+    const int sum = A + m + cf;
+    cf = (sum >> 8) & 1;
+    A = sum & 0xff;
+    P = (P & ~FV) | (((~(old ^ m) & (old ^ A)) >> 1) & FV);
+    set_nz(A);
+  }
+  void sbc_bin(int m) {
+    const int old = A;
+    const int bin = old - m - (cf ^ 1);
+    A = bin & 0xff;
+    cf = ((bin >> 8) & 1) ^ 1;
+    P = (P & ~FV) | ((((old ^ m) & (old ^ A)) >> 1) & FV);
+    set_nz(A);
+  }
   void cmp(int r, int m) { const int d = r - m; cf = ((d >> 8) & 1) ^ 1; set_nz(d & 0xff); }
+
+  // the lanes of the device's TIA register file a translated loop keeps scalar shadows of (Emu::t / tset):
+  // the write registers its stores are compared with, and the delayed-graphics latches (atari_defs.hpp TiaLane)
+  uint8_t* tia_field(int r) const {
+    switch (r) {
+      case 0x01: return &a->vblank;  case 0x04: return &a->nusiz0;  case 0x05: return &a->nusiz1;
+      case 0x06: return &a->colup0;  case 0x07: return &a->colup1;  case 0x08: return &a->colupf;
+      case 0x09: return &a->colubk;  case 0x0a: return &a->ctrlpf;  case 0x0b: return &a->refp0;
+      case 0x0c: return &a->refp1;   case 0x0d: return &a->pf0;     case 0x0e: return &a->pf1;
+      case 0x0f: return &a->pf2;     case 0x1b: return &a->grp0;    case 0x1c: return &a->grp1;
+      case 0x1d: return &a->enam0;   case 0x1e: return &a->enam1;   case 0x1f: return &a->enabl;
+      case 0x25: return &a->vdelp0;  case 0x26: return &a->vdelp1;  case 0x27: return &a->vdelbl;
+      case 0x35: return &a->dgrp0;   case 0x36: return &a->dgrp1;   case 0x37: return &a->denabl;
+      default: fprintf(stderr, "host harness: TIA lane %02x has no shadow mapping\n", r); exit(1);
+    }
+  }
+  int t(int r) const { return *tia_field(r); }
+  void tset(int r, int v) { *tia_field(r) = (uint8_t)v; }
 
   int ram_rd(int i) const { return a->ram[i & 0x7f]; }
   void ram_wr(int i, int v) { a->ram[i & 0x7f] = (uint8_t)v; }
@@ -140,6 +174,8 @@ struct Emu {
   }
 };
 
+static long g_trace_iters[65536];
+#define PARLHIP_TRACE_ITER(head) (++g_trace_iters[head])
 template <int GAME> struct NativeCart { static constexpr bool present = false; static constexpr uint32_t rom_crc32 = 0; };
 template <int GAME> inline void native_run(Emu&, int&) {}
 #include "cart_native.gen.hpp"
@@ -208,6 +244,8 @@ static int run(const uint8_t* rom, int rom_size, int frames) {
   }
   printf("ok: %d frames identical; %.0f translated instructions and %.1f deferrals per frame%s\n", frames,
          (double)native_instr / frames, (double)deferred / frames, ref.jam ? " (jam set)" : "");
+  for (int h = 0; h < 65536; ++h)
+    if (g_trace_iters[h]) printf("trace %04x: %.1f iterations per frame\n", h, (double)g_trace_iters[h] / frames);
   return 0;
 }
 
@@ -226,6 +264,12 @@ static int alu_check() {
             Emu e(&dummy);
             e.A = A; e.pset(P0);
             if (op == 0) e.adc(m); else if (op == 1) e.sbc(m); else e.cmp(A, m);
+            if (!dec && op < 2) {  // the forms translated loops use once binary mode is established at their head
+              Emu b(&dummy);
+              b.A = A; b.pset(P0);
+              if (op == 0) b.adc_bin(m); else b.sbc_bin(m);
+              if (b.pfull() != e.pfull() || b.A != e.A) { if (bad++ < 10) fprintf(stderr, "alu op %d (binary form) c %d A %02x m %02x differs\n", op, c, A, m); }
+            }
             const uint16_t want = host_alu(op, (uint8_t)A, (uint8_t)m, (uint8_t)P0);
             const int got = (e.pfull() << 8) | (e.A & 0xff);
             if (got != want && bad++ < 10)

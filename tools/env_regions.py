@@ -1,0 +1,46 @@
+"""Dev tool (GPU box): where one launch of the env kernel goes, per wave — diagnostic build with
+-DPARLHIP_ENV_REGIONS (tools/build_variant.sh regions -- -DPARLHIP_ENV_REGIONS; PARL_HIP_LIB=build_exp/regions.so):
+s_memtime clocks in the translated cartridge code, in the interpreter's step() without the picture catch-up, in
+the catch-up (tia_update / render_seg), in frame() as a whole and in the kernel as a whole, and how often each
+was entered.  The clock reads perturb the kernel by a few percent; the SPLIT is what it is for."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from parl_amd import _native as N  # noqa: E402
+from parl_amd.env import DeviceVectorEnv  # noqa: E402
+
+if __name__ == '__main__':
+    game = sys.argv[1] if len(sys.argv) > 1 else 'PongNoFrameskip-v4'
+    E = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    warm = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+    env = DeviceVectorEnv(game, E, dim=42, horizon=64, seed=1)
+    env.reset()
+    f = N.lib().parlhip_debug_env_regions
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    buf = np.zeros((E, 10), np.uint64)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    acc = []
+    for i in range(warm + 30):
+        if env.t >= env.horizon:
+            env.roll()
+        env.step_async(torch.randint(0, env.act_dim, (E, ), generator=g).to(env.device))
+        if i >= warm:
+            torch.cuda.synchronize()
+            assert f(buf.ctypes.data, E) == 0
+            acc.append(buf.astype(np.float64).copy())
+    a = np.mean(acc, axis=0)  # [E, 10] mean over launches
+    m = a.mean(axis=0)
+    frames = m[7]
+    names = ['translated code', 'interpreter step (no catch-up)', 'picture catch-up', 'frame() total', '', '', '', '', 'kernel total']
+    print('%s E=%d: per wave and launch (%.1f frames): kernel %.0f clocks' % (game, E, frames, m[8]))
+    for i in (0, 1, 2):
+        print('  %-32s %9.0f clocks = %4.1f %% of the kernel, %6.1f entries per frame, %6.0f clocks per entry' %
+              (names[i], m[i], 100 * m[i] / m[8], m[4 + i] / frames, m[i] / max(m[4 + i], 1)))
+    print('  %-32s %9.0f clocks = %4.1f %%' % ('frame() loop overhead', m[3] - m[0] - m[1] - m[2], 100 * (m[3] - m[0] - m[1] - m[2]) / m[8]))
+    print('  %-32s %9.0f clocks = %4.1f %%' % ('outside frame() (wrapper, state)', m[8] - m[3], 100 * (m[8] - m[3]) / m[8]))
