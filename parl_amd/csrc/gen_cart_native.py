@@ -30,17 +30,16 @@ import zlib
 # tools/cart_profile.py maps the compiled ISA back to 6507 addresses)
 MARKERS = bool(os.environ.get('PARLHIP_CART_MARKERS'))
 
-# Cartridges whose real playfield changes are queued by the translated code (Emu::pf_enqueue) instead
-# of handed over one by one.  Measured on MI355X, E=1024: Breakout (211 playfield changes per frame,
-# six per line in the brick band) 2.69 -> 2.11 ms per agent step; Pong (49 per frame) 1.25 -> 1.33 ms —
-# the enqueue code in the blocks of its scanline loop costs more than the hand-overs it saves.
-PF_QUEUE_GAMES = ('breakout', )
+# Real changes of the plain TIA registers and GRP0 / GRP1 are RECORDED in the emulator's write log by the translated
+# code (Emu::tia_store -> tia_log: effective colour clock, register, value) instead of being handed to the
+# interpreter one by one; the interpreter replays the log before anything that needs the picture (atari_core.hpp,
+# "The WRITE LOG").  This supersedes round 2's six-entry playfield queue of the Breakout build.
 # Cartridges that read collision latches through zp,X / zp,Y (Pong: `LDA CXM0P,X`, ~11 times a frame): for
 # them that arm is an ordinary hand-over whose successor is a dispatch entry; elsewhere it is `/*rare*/`.
 ZPX_LATCH_GAMES = ('pong', )
-# games whose ENAMx / ENABL stores go through Emu::tia_store_quiet (a byte whose D1 does not change is
-# stored without the interpreter): Pong writes them with PHP.  Breakout never does and only pays for
-# the extra test at every store site (PMC: 158.6 k -> 161.3 k instructions per frame with it on).
+# games whose ENAMx / ENABL bytes with an unchanged D1 (the one wired bit) are logged WITHOUT a catch-up request:
+# Pong writes the processor status into them with PHP.  Breakout never does and only pays for the extra test at
+# every store site (PMC: 158.6 k -> 161.3 k instructions per frame with it on).
 QUIET_STORE_GAMES = ('pong', )
 # games whose innermost 6507 loops get ONE way in (Cart.find_loops).  MEASURED AND SWITCHED OFF: it does
 # what it says — the guard-flag chains disappear from the hot path (Pong: 113.0 k -> 106.4 k instructions
@@ -274,7 +273,7 @@ class Trace(object):
     def prologue(self):
         L = ['const int h_%02x = e.ram_rd(0x%02x);' % (x, x) for x in sorted(self.hoist)]
         L += ['const int hp_%02x = h_%02x | (h_%02x << 8);' % (b1, b1 & 0x7f, (b1 + 1) & 0x7f) for b1 in self.rom_ptrs]
-        L += ['int ts_%02x = e.t(0x%02x);' % (r, r) for r in sorted(self.shadows)]
+        L += ['int ts_%02x = e.tc(0x%02x);' % (r, r) for r in sorted(self.shadows)]
         return L
 
 
@@ -282,7 +281,7 @@ class Cart(object):
     def __init__(self, name, rom):
         assert len(rom) in (2048, 4096)
         self.name, self.rom, self.mask = name, rom, len(rom) - 1
-        self.store_test = 'tia_store_quiet' if name in QUIET_STORE_GAMES else 'tia_store_is_nop'
+        self.quiet_ok = 'true' if name in QUIET_STORE_GAMES else 'false'
         self.branch_prob = {}
         if BRANCH_PGO:
             import json
@@ -541,25 +540,30 @@ class Cart(object):
             return 'h_%02x' % a7
         return 'e.ram_rd(0x%02x)' % a7
 
-    def store_stmt(self, reg, val, pend, dc=None):
-        """the test-and-hand-over statement of a TIA register store with a CONSTANT register number: nothing
-        happens when the store changes no pixel, otherwise `pend` (a block that leaves)"""
+    def store_stmt(self, reg, val, pend, dc):
+        """a TIA register store with a CONSTANT register number: complete in place (no-op rewrite, logged change,
+        HMxx ...: Emu::tia_store) or handed over through `pend` (a block that leaves); `dc` = the instruction's
+        cycles, e.cyc still at its start"""
         tc = self.tc
+        cw = 'e.cyc + %d' % (dc - 1)
         if tc is None or reg not in tc.shadows or reg in (T_DGRP0, T_DGRP1, T_DENABL):
-            return 'if (__builtin_expect(!e.%s(0x%02x, %s), 0)) %s' % (self.store_test, reg, val, pend)
-        v = '(%s)' % val
-        if 0x06 <= reg <= 0x09:
-            v = '((%s) & 0xfe)' % val
+            return 'if (__builtin_expect(!e.tia_store(0x%02x, %s, %s, %s), 0)) %s' % (reg, val, cw, self.quiet_ok, pend)
+        # inside a trace: the no-op test against the loop's scalar shadows of the CPU-side register file
+        v = '((%s) & 0xfe)' % val if 0x06 <= reg <= 0x09 else '(%s)' % val
+        upd = 'ts_%02x = v_;' % reg
         if reg == 0x1b:      # Emu::tia_store_is_nop: GRP0 also latches the delayed GRP1
             nop = '(ts_1b == v_) & (ts_%02x == ts_1c)' % T_DGRP1
+            upd += ' ts_%02x = ts_1c;' % T_DGRP1
         elif reg == 0x1c:    # GRP1 also latches the delayed GRP0 and ENABL
             nop = '(ts_1c == v_) & (ts_%02x == ts_1b) & (ts_%02x == ts_1f)' % (T_DGRP0, T_DENABL)
+            upd += ' ts_%02x = ts_1b; ts_%02x = ts_1f;' % (T_DGRP0, T_DENABL)
         else:
             nop = 'ts_%02x == v_' % reg
-        quiet = ''
-        if tc.quiet and 0x1d <= reg <= 0x1f:  # Emu::tia_store_quiet: D1 unchanged -> the byte is stored, no pixel changes
-            quiet = 'if (!((ts_%02x ^ v_) & 0x02)) { ts_%02x = v_; e.tset(0x%02x, v_); } else ' % (reg, reg, reg)
-        return '{ const int v_ = %s; if (__builtin_expect(!(%s), 0)) { %s%s } }' % (v, nop, quiet, pend)
+        quiet = 'false'
+        if tc.quiet and 0x1d <= reg <= 0x1f:  # D1 unchanged: the byte is logged without a catch-up request
+            quiet = '!((ts_%02x ^ v_) & 0x02)' % reg
+        return ('{ const int v_ = %s; if (__builtin_expect(!(%s), 0)) { if (__builtin_expect(e.tia_log(0x%02x, v_, %s, %s), 1)) { %s } else %s } }'
+                % (v, nop, reg, cw, quiet, upd, pend))
 
     def emit_read_op(self, op):
         if self.tc is not None and self.tc.d_clear and op in ('ADC', 'SBC'):
@@ -780,20 +784,11 @@ class Cart(object):
                 reg = static & 0x3f
                 if reg == 0x02:  # WSYNC
                     return ['e.wsync(e.cyc + %d);' % dc]
-                if 0x0d <= reg <= 0x0f and self.name in PF_QUEUE_GAMES:
-                    # playfield registers: a real change that needs no rendering first is QUEUED in
-                    # scalar registers (Emu::pf_enqueue; applied by the next step() / at frame end).
-                    # (Measured: applying it here — a per-lane select on the `tia` / `pfe` VGPRs — made
-                    # those VGPRs live across all ~2000 blocks: compile 1 -> 14 min, Pong 1.2 -> 9.0 ms
-                    # per step.  The translated code stays scalar-only.)
-                    return ['if (e.tia_store_is_nop(0x%02x, %s)) e.cyc += %d;' % (reg, val, dc),
-                            'else { e.cyc += %d; if (!e.pf_enqueue(0x%02x, %s)) { --n; e.pend = 0x%02x | ((%s) << 8); '
-                            'e.PC = 0x%04x; return; } }' % (dc - 1, reg, val, static, val, nxt)]
-                return [self.store_stmt(reg, val, pend % ('0x%02x' % static)), 'e.cyc += %d;' % dc]
+                return [self.store_stmt(reg, val, pend % ('0x%02x' % static), dc), 'e.cyc += %d;' % dc]
             generic = [
                 'const int ea = %s;' % ea,
                 'if (ea & 0x80) e.ram_wr(ea & 0x7f, %s);' % val,
-                'else if (__builtin_expect(!e.%s(ea & 0x3f, %s), 0)) %s' % (self.store_test, val, pend % 'ea'),
+                'else if (__builtin_expect(!e.tia_store(ea & 0x3f, %s, e.cyc + %d, %s), 0)) %s' % (val, dc - 1, self.quiet_ok, pend % 'ea'),
                 ('%s e.cyc += %d;' % (dec_s, dc)).strip()
             ]
             tS = self.tc.S.get(a) if (self.tc is not None and mode == M_PUSH) else None
@@ -801,7 +796,7 @@ class Cart(object):
                 # inside a trace the stack pointer is a FACT (precondition at the head): no guard, no generic arm
                 if tS & 0x80:
                     return ['e.ram_wr(0x%02x, %s);' % (tS & 0x7f, val), 'e.S = 0x%02x; e.cyc += %d;' % ((tS - 1) & 0xff, dc)]
-                return [self.store_stmt(tS & 0x3f, val, pend % ('0x%02x' % tS)), 'e.S = 0x%02x; e.cyc += %d;' % ((tS - 1) & 0xff, dc)]
+                return [self.store_stmt(tS & 0x3f, val, pend % ('0x%02x' % tS), dc), 'e.S = 0x%02x; e.cyc += %d;' % ((tS - 1) & 0xff, dc)]
             h = self.s_hint.get(a) if mode == M_PUSH else None
             if h is None or (h & 0x3f) == 0x02 and not (h & 0x80):
                 return generic
@@ -809,7 +804,7 @@ class Cart(object):
             if h & 0x80:
                 fast = ['e.ram_wr(0x%02x, %s);' % (h & 0x7f, val)]
             else:
-                fast = ['if (__builtin_expect(!e.%s(0x%02x, %s), 0)) %s' % (self.store_test, h & 0x3f, val, pend % ('0x%02x' % h))]
+                fast = [self.store_stmt(h & 0x3f, val, pend % ('0x%02x' % h), dc)]
             fast.append('e.S = 0x%02x; e.cyc += %d;' % ((h - 1) & 0xff, dc))
             return ['if (__builtin_expect(e.S == 0x%02x, 1)) { %s } else { %s }' % (h, ' '.join(fast), ' '.join(generic))]
         # K_RMW

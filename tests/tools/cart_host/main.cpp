@@ -123,15 +123,6 @@ struct Emu {
   int rom_byte(int ea) const { return a->rom[ea & a->rom_mask]; }
   int tia_read(int ea, int noise) { return host_tia_read(a, (uint16_t)ea, (uint8_t)noise); }
   int riot_read(int ea) { return host_riot_read(a, (uint16_t)ea); }
-  // Emu::pf_enqueue: the device queues the change for its lazy per-lane playfield; the oracle renders
-  // eagerly, so here the store simply happens (host_wr performs the write cycle) — every other time
-  // declined, so that both the queued and the hand-over path of the generated block are exercised
-  int pf_toggle = 0;
-  bool pf_enqueue(int reg, int v) {
-    if ((pf_toggle++ & 1) == 0) return false;
-    host_wr(a, (uint16_t)reg, (uint8_t)v);
-    return true;
-  }
   void wsync(int cw) {
     const int into = (cw - a->cyc0) % kCyclesPerLine;
     cyc = cw + (into ? kCyclesPerLine - into : 0);
@@ -163,13 +154,33 @@ struct Emu {
       default: return false;
     }
   }
-  // atari_core.hpp tia_store_quiet: ENAMx / ENABL bytes whose D1 does not change are stored without the
-  // interpreter (the oracle's own write would render first; with D1 unchanged that changes no pixel)
   int inpt_read(int reg, int noise) { return tia_read(reg, noise); }
-  bool tia_store_quiet(int reg, int v) {
-    if (tia_store_is_nop(reg, v)) return true;
-    uint8_t* f = reg == 0x1d ? &a->enam0 : (reg == 0x1e ? &a->enam1 : (reg == 0x1f ? &a->enabl : nullptr));
-    if (f && !((*f ^ v) & 0x02)) { *f = (uint8_t)v; return true; }
+  int tc(int r) const { return t(r); }   // the oracle writes eagerly: its register fields ARE the CPU-side file
+  // The device records real changes in its write log and replays them later (atari_core.hpp); the oracle renders
+  // eagerly, so here the write simply happens — at the cycle the device stamps the entry with (`cw` = the cycle
+  // before the write cycle; the generated block adds the instruction's cycles to e.cyc afterwards).  Every fifth
+  // request is declined so that the hand-over arm of the generated blocks stays exercised.
+  int log_calls = 0;
+  void write_at(int reg, int v, int cw) { const int c0 = cyc; cyc = cw; host_wr(a, (uint16_t)reg, (uint8_t)v); cyc = c0; }
+  bool tia_log(int reg, int v, int cw, bool quiet = false) {
+    (void)quiet;  // D1 unchanged: the oracle's own write renders first and then changes no pixel
+    if ((log_calls++ % 5) == 4) return false;
+    write_at(reg, v, cw);
+    return true;
+  }
+  // atari_core.hpp Emu::tia_store
+  bool tia_store(int reg, int v, int cw, bool quiet_ok) {
+    const bool plain = reg == 0x04 || reg == 0x05 || (reg >= 0x06 && reg <= 0x0f) || (reg >= 0x1d && reg <= 0x1f) || (reg >= 0x25 && reg <= 0x27);
+    if (plain || reg == 0x1b || reg == 0x1c) {
+      if (tia_store_is_nop(reg, v)) return true;
+      const bool quiet = quiet_ok && reg >= 0x1d && reg <= 0x1f && !((t(reg) ^ v) & 0x02);
+      return tia_log(reg, (reg >= 0x06 && reg <= 0x09) ? (v & 0xfe) : v, cw, quiet);
+    }
+    if (reg == 0x01) return tia_store_is_nop(reg, v);
+    if ((reg >= 0x20 && reg <= 0x24) || reg == 0x2b || reg == 0x03 || (reg >= 0x15 && reg <= 0x1a) || reg >= 0x2d) {
+      write_at(reg, v, cw);   // HMxx / HMCLR: stored at once on the device; audio / RSYNC / unmapped: no state there
+      return true;
+    }
     return false;
   }
 };
