@@ -118,7 +118,7 @@ DEVI void store_env(const Emu& e, const Wrap& v, uint8_t* blob, int lane) {
 __device__ unsigned long long g_env_t0[8192], g_env_t1[8192];
 #endif
 #ifdef PARLHIP_ENV_REGIONS  // diagnostic build only (tools/env_regions.py): where a wave's launch goes
-__device__ unsigned long long g_env_regions[8192][10];
+__device__ unsigned long long g_env_regions[8192][12];
 #endif
 
 // One wavefront per env.  mode STEP: VectorEnv.step; RESET: VectorEnv.reset; SNAPSHOT: wave k
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
   Wrap v;
 #ifdef PARLHIP_ENV_REGIONS
   const unsigned long long k0 = __builtin_readcyclecounter();
-  for (int i = 0; i < 4; ++i) { emu.rt[i] = 0; emu.rn[i] = 0; }
+  for (int i = 0; i < 5; ++i) { emu.rt[i] = 0; emu.rn[i] = 0; }
 #endif
   emu.romw = rom_lds;
   emu.rom_mask = prm.rom_size - 1;
@@ -427,6 +427,8 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
   if (lane == 0 && e < 8192) {
     for (int i = 0; i < 4; ++i) { g_env_regions[e][i] = emu.rt[i]; g_env_regions[e][4 + i] = (unsigned long long)emu.rn[i]; }
     g_env_regions[e][8] = __builtin_readcyclecounter() - k0;
+    g_env_regions[e][9] = emu.rt[4];
+    g_env_regions[e][10] = (unsigned long long)emu.rn[4];
   }
 #endif
 }
@@ -628,7 +630,7 @@ PARLHIP_EXPORT int parlhip_atari_vec_step_elastic(void* states, const uint32_t* 
 #ifdef PARLHIP_ENV_REGIONS
 PARLHIP_EXPORT int parlhip_debug_env_regions(unsigned long long* host, int n) {
   if (n > 8192) return PARLHIP_EINVAL;
-  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(parlhip::atari::g_env_regions), (size_t)n * 80) != hipSuccess) return PARLHIP_EINVAL;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(parlhip::atari::g_env_regions), (size_t)n * 96) != hipSuccess) return PARLHIP_EINVAL;
   return PARLHIP_OK;
 }
 #endif

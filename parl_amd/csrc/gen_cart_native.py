@@ -75,10 +75,10 @@ BRANCH_PGO = bool(int(os.environ.get('PARLHIP_BRANCH_PGO', '1')))
 TRACE_LOOPS = bool(int(os.environ.get('PARLHIP_TRACE_LOOPS', '1')))
 # Measured on MI355X, E=1024, after reset (profiles/r04_trace_loops.log): Pong 1.12 -> 1.02 ms per agent step (PMC per
 # frame: 111.8 k -> 100.5 k instructions, 13.9 k -> 12.7 k branches; the translated code's share of a frame 400 k -> 295 k
-# clocks).  Breakout 1.81 -> 1.98 ms: its loops index RAM with X (`LDA zp,X`, `DEC zp,X`: nothing to hoist), what is left
-# are the stack-pointer / binary-mode facts, and the second copy of two 40-instruction loops with the playfield queue
-# inlined takes the kernel from 669 to 1313 SGPR spills.  Per game, therefore:
-TRACE_GAMES = tuple(x for x in os.environ.get('PARLHIP_TRACE_GAMES', 'pong').split(',') if x)
+# clocks).  Breakout, whose loops index RAM with X (`LDA zp,X`, `DEC zp,X`: nothing to hoist): 1.81 -> 1.98 ms while its
+# blocks still carried round 2's playfield queue inline (669 -> 1313 SGPR spills); with the write log instead
+# 1.79 -> 1.61 ms.  Per game:
+TRACE_GAMES = tuple(x for x in os.environ.get('PARLHIP_TRACE_GAMES', 'pong,breakout').split(',') if x)
 TRACE_MIN_TAKEN = 8000   # back-edge "taken" count in cart_branch_profile.json (1600 profiled frames: >= 5 per frame)
 LOOP_REENTRY_GAMES = tuple(x for x in os.environ.get('PARLHIP_LOOP_REENTRY', '').split(',') if x)  # default: none
 
@@ -153,6 +153,7 @@ class Trace(object):
     instruction stream (forward branches only, plus the back edge(s) to the head)."""
 
     def __init__(self, cart, head, stream):
+        self.cart = cart
         self.head, self.stream, self.sset = head, stream, set(stream)
         code = cart.code
         ops = [code[a][2] for a in stream]
@@ -274,6 +275,8 @@ class Trace(object):
         L = ['const int h_%02x = e.ram_rd(0x%02x);' % (x, x) for x in sorted(self.hoist)]
         L += ['const int hp_%02x = h_%02x | (h_%02x << 8);' % (b1, b1 & 0x7f, (b1 + 1) & 0x7f) for b1 in self.rom_ptrs]
         L += ['int ts_%02x = e.tc(0x%02x);' % (r, r) for r in sorted(self.shadows)]
+        L += ['int rc_%04x_ea = -1, rc_%04x_m = 0;' % (a, a) for a in self.stream
+              if self.cart.code[a][0] == M_IZY and self.cart.code[a][1] == K_READ and self.cart.code[a][3] in self.rom_ptrs]
         return L
 
 
@@ -650,7 +653,12 @@ class Cart(object):
                     'const int base = %s | (%s << 8);' % (self.rd(b1 & 0x7f), self.rd((b1 + 1) & 0x7f)),
                     'const int ea = (base + e.Y) & 0xffff;', 'const int dc = 5 + (((ea ^ base) & 0xff00) ? 1 : 0);']
                 if self.tc is not None and b1 in self.tc.rom_ptrs:
-                    pre += ['const int m = e.rom_byte(ea);']   # the trace's precondition: base .. base+255 inside the cartridge
+                    # the trace's precondition: base .. base+255 inside the cartridge.  The byte comes from LDS
+                    # (ds_read + wait + v_readfirstlane: ~130 clocks for one wave); a table walked by a slowly moving
+                    # index (Pong's playfield rows: Y = scanline / 8) is read again and again at the same address, so
+                    # each site remembers its last (address, byte) in two scalar registers
+                    pre += ['int m;', 'if (__builtin_expect(ea == rc_%04x_ea, 1)) m = rc_%04x_m;' % (a, a),
+                            'else { m = e.rom_byte(ea); rc_%04x_ea = ea; rc_%04x_m = m; }' % (a, a)]
                 else:
                     pre += ['int m;', 'if (ea & 0x1000) m = e.rom_byte(ea);',
                             'else if ((ea & 0x280) == 0x80) m = e.ram_rd(ea & 0x7f);',

@@ -177,8 +177,10 @@ struct Emu {
       return tia_log(reg, (reg >= 0x06 && reg <= 0x09) ? (v & 0xfe) : v, cw, quiet);
     }
     if (reg == 0x01) return tia_store_is_nop(reg, v);
-    if ((reg >= 0x20 && reg <= 0x24) || reg == 0x2b || reg == 0x03 || (reg >= 0x15 && reg <= 0x1a) || reg >= 0x2d) {
-      write_at(reg, v, cw);   // HMxx / HMCLR: stored at once on the device; audio / RSYNC / unmapped: no state there
+    if ((reg >= 0x10 && reg <= 0x14) || (reg >= 0x20 && reg <= 0x24) || (reg >= 0x28 && reg <= 0x2c))
+      return tia_log(reg, v, cw);   // strobes, HMxx / HMCLR: logged with the clock of the write
+    if (reg == 0x03 || (reg >= 0x15 && reg <= 0x1a) || reg >= 0x2d) {
+      write_at(reg, v, cw);   // audio / RSYNC / unmapped: no state on the device
       return true;
     }
     return false;

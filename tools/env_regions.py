@@ -23,7 +23,7 @@ if __name__ == '__main__':
     f = N.lib().parlhip_debug_env_regions
     f.restype = ctypes.c_int
     f.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    buf = np.zeros((E, 10), np.uint64)
+    buf = np.zeros((E, 12), np.uint64)
     g = torch.Generator(device='cpu').manual_seed(0)
     acc = []
     for i in range(warm + 30):
@@ -42,5 +42,7 @@ if __name__ == '__main__':
     for i in (0, 1, 2):
         print('  %-32s %9.0f clocks = %4.1f %% of the kernel, %6.1f entries per frame, %6.0f clocks per entry' %
               (names[i], m[i], 100 * m[i] / m[8], m[4 + i] / frames, m[i] / max(m[4 + i], 1)))
+    print('  %-32s %9.0f clocks = %4.1f %% of the kernel, %6.1f entries per frame, %6.0f clocks per entry   (part of the interpreter step)' %
+          ('  of it: write-log replay', m[9], 100 * m[9] / m[8], m[10] / frames, m[9] / max(m[10], 1)))
     print('  %-32s %9.0f clocks = %4.1f %%' % ('frame() loop overhead', m[3] - m[0] - m[1] - m[2], 100 * (m[3] - m[0] - m[1] - m[2]) / m[8]))
     print('  %-32s %9.0f clocks = %4.1f %%' % ('outside frame() (wrapper, state)', m[8] - m[3], 100 * (m[8] - m[3]) / m[8]))
