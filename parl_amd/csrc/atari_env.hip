@@ -55,7 +55,7 @@ enum : int {
 enum : int { CTX_MAIN = 0, CTX_FIRE1, CTX_FIRE2, CTX_LIFE };  // who called MaxAndSkipEnv.step
 enum : int { TO_B = 0, TO_C, TO_END };                        // continuation after episodic_reset
 
-constexpr int kEnvsPerBlock = 4;   // 4 wavefronts share one LDS copy of the cartridge
+constexpr int kEnvsPerBlock = 4;   // 4 envs share one LDS copy of the cartridge: 8 wavefronts, a CPU wave and a picture wave per env
 constexpr int kMaxRomWords = 4096;
 
 DEVI int action_code(int idx) {  // ALE minimal action sets (Pong 6, Breakout the first 4)
@@ -74,14 +74,14 @@ DEVI void load_env(Emu& e, Wrap& v, const uint8_t* blob, int lane) {
   const int* s = (const int*)(blob + kOffScalars);
   e.ram_lo = blob[kOffRam + lane];
   e.ram_hi = blob[kOffRam + 64 + lane];
-  e.tia = blob[kOffTia + lane];
+  e.tiac = blob[kOffTia + lane];   // the CPU-side register file; the render-side one is wave B's
   auto L = [&](int i) { return rfl(s[i]); };
   e.A = L(S_A); e.X = L(S_X); e.Y = L(S_Y); e.S = L(S_S); e.pset(L(S_P)); e.PC = L(S_PC);
-  e.cyc = L(S_CYC); e.cyc0 = L(S_CYC0); e.last_clock = L(S_LAST_CLOCK);
+  e.cyc = L(S_CYC); e.cyc0 = L(S_CYC0);
   e.vsync_finish = L(S_VSYNC_FINISH); e.dump_dis_cyc = L(S_DUMP_DIS_CYC); e.dump_en = L(S_DUMP_EN);
   e.timer = L(S_TIMER); e.timer_shift = L(S_TIMER_SHIFT); e.timer_set_cyc = L(S_TIMER_SET_CYC);
   e.ddra = L(S_DDRA); e.ddrb = L(S_DDRB); e.swcha_out = L(S_SWCHA_OUT); e.swchb_out = L(S_SWCHB_OUT);
-  e.cx = L(S_CX); e.jam = L(S_JAM); e.stop = 0;
+  e.cx = 0; e.jam = L(S_JAM); e.stop = 0;   // (collision latches: wave B's; read through a SYNC record)
   e.pneed0 = e.pneed1 = Emu::paddle_needed(kPaddleDefault); e.fire0 = e.fire1 = e.sw_reset = 0;
   e.fb = nullptr;
   v.paddle = L(S_PADDLE); v.score = L(S_SCORE); v.terminal = L(S_TERMINAL);
@@ -96,15 +96,15 @@ DEVI void store_env(const Emu& e, const Wrap& v, uint8_t* blob, int lane) {
   int* s = (int*)(blob + kOffScalars);
   blob[kOffRam + lane] = (uint8_t)e.ram_lo;
   blob[kOffRam + 64 + lane] = (uint8_t)e.ram_hi;
-  blob[kOffTia + lane] = (uint8_t)e.tia;
+  // (TIA register bytes, collision latches, picture position: wave B stores them, Emu::render_main)
   if (lane == 0) {
     s[S_A] = e.A; s[S_X] = e.X; s[S_Y] = e.Y; s[S_S] = e.S; s[S_P] = e.pfull(); s[S_PC] = e.PC;
     s[S_BUS] = 0;
-    s[S_CYC] = e.cyc; s[S_CYC0] = e.cyc0; s[S_LAST_CLOCK] = e.last_clock;
+    s[S_CYC] = e.cyc; s[S_CYC0] = e.cyc0;
     s[S_VSYNC_FINISH] = e.vsync_finish; s[S_DUMP_DIS_CYC] = e.dump_dis_cyc; s[S_DUMP_EN] = e.dump_en;
     s[S_TIMER] = e.timer; s[S_TIMER_SHIFT] = e.timer_shift; s[S_TIMER_SET_CYC] = e.timer_set_cyc;
     s[S_DDRA] = e.ddra; s[S_DDRB] = e.ddrb; s[S_SWCHA_OUT] = e.swcha_out; s[S_SWCHB_OUT] = e.swchb_out;
-    s[S_CX] = e.cx; s[S_JAM] = e.jam;
+    s[S_JAM] = e.jam;
     s[S_PADDLE] = v.paddle; s[S_SCORE] = v.score; s[S_TERMINAL] = v.terminal;
     s[S_ALE_LIVES] = v.ale_lives; s[S_STARTED] = v.started; s[S_FRAME_NUMBER] = v.frame_number;
     s[S_LIVES] = v.lives; s[S_WAS_REAL_DONE] = v.was_real_done; s[S_HAS_EPISODE] = v.has_episode;
@@ -121,10 +121,11 @@ __device__ unsigned long long g_env_t0[8192], g_env_t1[8192];
 __device__ unsigned long long g_env_regions[8192][12];
 #endif
 
-// One wavefront per env.  mode STEP: VectorEnv.step; RESET: VectorEnv.reset; SNAPSHOT: wave k
+// Two wavefronts per env (atari_core.hpp): waves 0 .. 3 of a workgroup run the 6507 / RIOT / wrapper chain of its
+// four envs, waves 4 .. 7 their pictures.  mode STEP: VectorEnv.step; RESET: VectorEnv.reset; SNAPSHOT: env k
 // builds reset snapshot k (noops = k+1) for the O(1) real-reset path.
 template <int GAME>
-__global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
+__global__ __launch_bounds__(128 * kEnvsPerBlock) void atari_env_kernel(
     uint8_t* __restrict__ states, const uint32_t* __restrict__ romw_g, EnvParams prm,
     const long long* __restrict__ actions, uint8_t* __restrict__ frames,
     float* __restrict__ rewards, uint8_t* __restrict__ dones, uint8_t* __restrict__ obs_flags,
@@ -132,14 +133,18 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
     uint8_t* __restrict__ snap /* [30][kSnapBytes] or null */, int* __restrict__ jam_out,
     const uint8_t* __restrict__ ctl /* [E] CTL_* per env, or null */) {
   __shared__ uint32_t rom_lds[kMaxRomWords];
+  __shared__ RenderQueue rqs[kEnvsPerBlock];
   for (int i = threadIdx.x; i < prm.rom_size; i += blockDim.x) rom_lds[i] = romw_g[i];
+  if (threadIdx.x < kEnvsPerBlock) { rqs[threadIdx.x].wr = 0; rqs[threadIdx.x].rd = 0; rqs[threadIdx.x].cx = 0; }
   __syncthreads();
   // One wavefront per env is a long serial dependency chain: when other kernels (the learner's
   // GEMMs on another stream) share the SIMD, this wave should win every issue arbitration.
   __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63;
   const int wave = rfl((int)(threadIdx.x >> 6));
-  const int e = blockIdx.x * kEnvsPerBlock + wave;
+  const int slot = wave & (kEnvsPerBlock - 1);
+  const bool picture_wave = wave >= kEnvsPerBlock;
+  const int e = blockIdx.x * kEnvsPerBlock + slot;
   if (e >= prm.E) return;
   // elastic stepping: this env's rows of the batch are complete, it waits for the others (its obs_flags /
   // ep_lengths were written by elastic_pre_kernel).  The exit must be HERE: the same `return` placed
@@ -147,9 +152,24 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
   // spills and its compile from 15 s to 190 s.
   if (ctl && rfl((int)ctl[e]) == CTL_IDLE) return;
 #ifdef PARLHIP_ENV_TIMING
-  if (lane == 0 && e < 8192) g_env_t0[e] = wall_clock64();
+  if (lane == 0 && e < 8192 && !picture_wave) g_env_t0[e] = wall_clock64();
 #endif
   const int mode = prm.mode, game = prm.game;
+  if (picture_wave) {
+    // the env's picture: render-side TIA registers, collision latches, frame buffers (Emu::render_main)
+    Emu r;
+    r.lane = lane;
+    r.rq = &rqs[slot];
+    uint8_t* rblob = mode == MODE_SNAPSHOT ? snap + (size_t)e * kSnapBytes : states + (size_t)e * kStateBytes;
+#ifdef PARLHIP_ENV_REGIONS
+    r.rt[3] = r.rt[4] = 0;
+#endif
+    r.render_main(rblob, snap, kSnapBytes);
+#ifdef PARLHIP_ENV_REGIONS
+    if (lane == 0 && e < 8192) { g_env_regions[e][9] = r.rt[3]; g_env_regions[e][10] = r.rt[4]; }
+#endif
+    return;
+  }
   // translated code is only used for the cartridge it was generated from (tag set by
   // parlhip_atari_rom_table_build after a CRC match)
   const bool native_ok = NativeCart<GAME>::present && rfl((int)(rom_lds[0] >> 28)) == GAME;
@@ -164,6 +184,10 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
   emu.romw = rom_lds;
   emu.rom_mask = prm.rom_size - 1;
   emu.lane = lane;
+  emu.rq = &rqs[slot];
+  emu.rq_wr = 0;
+  emu.wqn = 0;
+  emu.wq = emu.wq2 = 0;
   uint8_t* blob;
   uint8_t *buf0, *buf1;
   unsigned long long env_id;
@@ -377,7 +401,9 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
           const long long cc = v.compat_count + delta;
           const int rc = v.reset_count + 1;
           const int jam_keep = emu.jam;
+          emu.rq_wait_idle();  // the picture wave may still be drawing into the frame pair this restore overwrites
           load_env(emu, v, src, lane);
+          emu.rq_ctl(Emu::LA_RELOAD, (uint32_t)k, 0);
           emu.jam |= jam_keep;
           v.compat_count = cc;
           v.reset_count = rc;
@@ -419,6 +445,8 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
     sc[S_SUSP_TOTAL] = skip_total; sc[S_SUSP_ACT] = skip_act;
     sc[S_SUSP_ALE_J] = ale_j; sc[S_SUSP_NOOPS] = noops_left;
   }
+  emu.rq_ctl(Emu::LA_EXIT, 0, 0);
+  emu.rq_flush();
   store_env(emu, v, blob, lane);
 #ifdef PARLHIP_ENV_TIMING
   if (lane == 0 && e < 8192) g_env_t1[e] = wall_clock64();
@@ -427,8 +455,6 @@ __global__ __launch_bounds__(64 * kEnvsPerBlock) void atari_env_kernel(
   if (lane == 0 && e < 8192) {
     for (int i = 0; i < 4; ++i) { g_env_regions[e][i] = emu.rt[i]; g_env_regions[e][4 + i] = (unsigned long long)emu.rn[i]; }
     g_env_regions[e][8] = __builtin_readcyclecounter() - k0;
-    g_env_regions[e][9] = emu.rt[4];
-    g_env_regions[e][10] = (unsigned long long)emu.rn[4];
   }
 #endif
 }
@@ -540,7 +566,7 @@ static int launch_env(int mode, void* states, const uint32_t* romw, uint32_t rom
                       uint64_t env_id0, int64_t max_steps, void* snap, int32_t* jam, hipStream_t s,
                       int budget = 0, const uint8_t* ctl = nullptr) {
   EnvParams prm{game, (int)rom_size, E, mode, seed, env_id0, (long long)max_steps, budget};
-  const dim3 grid(ceil_div(E, kEnvsPerBlock)), block(64 * kEnvsPerBlock);
+  const dim3 grid(ceil_div(E, kEnvsPerBlock)), block(128 * kEnvsPerBlock);
 #define PARLHIP_LAUNCH_ENV(G)                                                                           \
   atari_env_kernel<G><<<grid, block, 0, s>>>((uint8_t*)states, romw, prm, (const long long*)actions,     \
                                              frames, rewards, dones, obs_flags, ep_returns, ep_lengths, \

@@ -792,12 +792,16 @@ class Cart(object):
                 reg = static & 0x3f
                 if reg == 0x02:  # WSYNC
                     return ['e.wsync(e.cyc + %d);' % dc]
-                return [self.store_stmt(reg, val, pend % ('0x%02x' % static), dc), 'e.cyc += %d;' % dc]
+                out = [self.store_stmt(reg, val, pend % ('0x%02x' % static), dc), 'e.cyc += %d;' % dc]
+                if reg == 0x00:  # VSYNC may have ended the frame (Emu::tia_store sets `stop`): leave, nothing to interpret
+                    out.append('if (e.stop) { e.PC = 0x%04x; e.pend = -2; return; }' % nxt)
+                return out
             generic = [
                 'const int ea = %s;' % ea,
                 'if (ea & 0x80) e.ram_wr(ea & 0x7f, %s);' % val,
                 'else if (__builtin_expect(!e.tia_store(ea & 0x3f, %s, e.cyc + %d, %s), 0)) %s' % (val, dc - 1, self.quiet_ok, pend % 'ea'),
-                ('%s e.cyc += %d;' % (dec_s, dc)).strip()
+                ('%s e.cyc += %d;' % (dec_s, dc)).strip(),
+                'if (__builtin_expect(e.stop, 0)) { e.PC = 0x%04x; e.pend = -2; return; }' % nxt   # a run-time address can be VSYNC
             ]
             tS = self.tc.S.get(a) if (self.tc is not None and mode == M_PUSH) else None
             if tS is not None and not ((tS & 0x3f) == 0x02 and not (tS & 0x80)):

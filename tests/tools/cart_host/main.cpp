@@ -42,7 +42,8 @@ struct Emu {
   int pend;
   int jam = 0;
   int& cyc;
-  explicit Emu(Atari* m) : a(m), cyc(m->cyc) {}
+  int& stop;   // VSYNC released: the frame is over (the generated code leaves right after that store)
+  explicit Emu(Atari* m) : a(m), cyc(m->cyc), stop(m->stop) {}
 
   void load() { A = a->A; X = a->X; Y = a->Y; S = a->S; PC = a->PC; pset(a->P); pend = -1; }
   void store() { a->A = (uint8_t)A; a->X = (uint8_t)X; a->Y = (uint8_t)Y; a->S = (uint8_t)S; a->PC = (uint16_t)PC; a->P = (uint8_t)pfull(); }
@@ -176,14 +177,15 @@ struct Emu {
       const bool quiet = quiet_ok && reg >= 0x1d && reg <= 0x1f && !((t(reg) ^ v) & 0x02);
       return tia_log(reg, (reg >= 0x06 && reg <= 0x09) ? (v & 0xfe) : v, cw, quiet);
     }
-    if (reg == 0x01) return tia_store_is_nop(reg, v);
+    if (reg == 0x01 && tia_store_is_nop(reg, v)) return true;
+    if (reg == 0x00 || reg == 0x01) return tia_log(reg, v, cw);   // the oracle's write does the CPU-side part too
     if ((reg >= 0x10 && reg <= 0x14) || (reg >= 0x20 && reg <= 0x24) || (reg >= 0x28 && reg <= 0x2c))
       return tia_log(reg, v, cw);   // strobes, HMxx / HMCLR: logged with the clock of the write
     if (reg == 0x03 || (reg >= 0x15 && reg <= 0x1a) || reg >= 0x2d) {
       write_at(reg, v, cw);   // audio / RSYNC / unmapped: no state on the device
       return true;
     }
-    return false;
+    return false;   // WSYNC through a run-time address: handed over
   }
 };
 

@@ -1,8 +1,9 @@
-"""Dev tool (GPU box): where one launch of the env kernel goes, per wave — diagnostic build with
--DPARLHIP_ENV_REGIONS (tools/build_variant.sh regions -- -DPARLHIP_ENV_REGIONS; PARL_HIP_LIB=build_exp/regions.so):
-s_memtime clocks in the translated cartridge code, in the interpreter's step() without the picture catch-up, in
-the catch-up (tia_update / render_seg), in frame() as a whole and in the kernel as a whole, and how often each
-was entered.  The clock reads perturb the kernel by a few percent; the SPLIT is what it is for."""
+"""Dev tool (GPU box): where one launch of the env kernel goes, per env — diagnostic build with
+-DPARLHIP_ENV_REGIONS (tools/build_variant.sh regions -- -DPARLHIP_ENV_REGIONS; PARL_HIP_LIB=build_exp/regions.so).
+Wave A (6507 / RIOT / wrappers): s_memtime clocks in the translated cartridge code, in the interpreter's step(),
+waiting for wave B (ring full, collision-latch SYNC, snapshot restore), and how often each was entered; wave B (the
+picture): busy clocks (replaying records) and its lifetime.  The clock reads perturb the kernel by a few percent; the
+SPLIT is what it is for."""
 import ctypes
 import os
 import sys
@@ -34,15 +35,12 @@ if __name__ == '__main__':
             torch.cuda.synchronize()
             assert f(buf.ctypes.data, E) == 0
             acc.append(buf.astype(np.float64).copy())
-    a = np.mean(acc, axis=0)  # [E, 10] mean over launches
+    a = np.mean(acc, axis=0)  # [E, 12] mean over launches
     m = a.mean(axis=0)
-    frames = m[7]
-    names = ['translated code', 'interpreter step (no catch-up)', 'picture catch-up', 'frame() total', '', '', '', '', 'kernel total']
-    print('%s E=%d: per wave and launch (%.1f frames): kernel %.0f clocks' % (game, E, frames, m[8]))
-    for i in (0, 1, 2):
-        print('  %-32s %9.0f clocks = %4.1f %% of the kernel, %6.1f entries per frame, %6.0f clocks per entry' %
-              (names[i], m[i], 100 * m[i] / m[8], m[4 + i] / frames, m[i] / max(m[4 + i], 1)))
-    print('  %-32s %9.0f clocks = %4.1f %% of the kernel, %6.1f entries per frame, %6.0f clocks per entry   (part of the interpreter step)' %
-          ('  of it: write-log replay', m[9], 100 * m[9] / m[8], m[10] / frames, m[9] / max(m[10], 1)))
-    print('  %-32s %9.0f clocks = %4.1f %%' % ('frame() loop overhead', m[3] - m[0] - m[1] - m[2], 100 * (m[3] - m[0] - m[1] - m[2]) / m[8]))
-    print('  %-32s %9.0f clocks = %4.1f %%' % ('outside frame() (wrapper, state)', m[8] - m[3], 100 * (m[8] - m[3]) / m[8]))
+    frames = max(m[7], 1e-9)
+    print('%s E=%d: per env and launch (%.1f frames): wave A %.0f clocks, wave B %.0f clocks' % (game, E, frames, m[8], m[10]))
+    for i, name in ((0, 'A: translated code'), (1, 'A: interpreter step'), (2, 'A: waiting for wave B')):
+        print('  %-28s %9.0f clocks = %4.1f %% of wave A, %6.1f entries per frame, %6.0f clocks per entry' %
+              (name, m[i], 100 * m[i] / m[8], m[4 + i] / frames, m[i] / max(m[4 + i], 1)))
+    print('  %-28s %9.0f clocks = %4.1f %% of wave A' % ('A: rest (frame loop, wrapper)', m[8] - m[0] - m[1] - m[2], 100 * (m[8] - m[0] - m[1] - m[2]) / m[8]))
+    print('  %-28s %9.0f clocks = %4.1f %% of wave B\'s lifetime (the rest: polling an empty ring)' % ('B: replaying records', m[9], 100 * m[9] / max(m[10], 1)))
