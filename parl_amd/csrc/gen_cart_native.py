@@ -72,6 +72,10 @@ BRANCH_PGO = bool(int(os.environ.get('PARLHIP_BRANCH_PGO', '1')))
 #     file).  A real TIA change still leaves through `pend` exactly like the generic block — after the
 #     interpreter's TIA stages the rest of that iteration runs in the generic blocks, the next one here.
 # An oracle trace of Pong shows 79 % of the 91 iterations per frame complete without any hand-over.
+# Timer wait loops (`L: LDA INTIM; BNE L` — both cartridges burn the vertical blank this way: 116 iterations per Pong
+# frame, 399 per Breakout frame = 17 % of its instructions) run in place, and the iterations whose outcome is known
+# from the RIOT's state — the timer value stays >= 2 — are skipped in one step (PARLHIP_WAIT_LOOPS=0: off).
+WAIT_LOOPS = bool(int(os.environ.get('PARLHIP_WAIT_LOOPS', '1')))
 TRACE_LOOPS = bool(int(os.environ.get('PARLHIP_TRACE_LOOPS', '1')))
 # Measured on MI355X, E=1024, after reset (profiles/r04_trace_loops.log): Pong 1.12 -> 1.02 ms per agent step (PMC per
 # frame: 111.8 k -> 100.5 k instructions, 13.9 k -> 12.7 k branches; the translated code's share of a frame 400 k -> 295 k
@@ -308,6 +312,7 @@ class Cart(object):
                 self.branch_taken = {int(a, 16): tk for a, (nt, tk) in ent['branches'].items()}
         all_loops = self.find_loops()
         self.loops = all_loops if name in LOOP_REENTRY_GAMES else []
+        self.wait_loops = self.find_wait_loops() if WAIT_LOOPS else {}
         self.traces = {}      # loop head -> Trace
         self.trace_of = {}    # instruction start inside a traced loop -> its head
         if TRACE_LOOPS and name in TRACE_GAMES and name not in LOOP_REENTRY_GAMES:
@@ -353,6 +358,51 @@ class Cart(object):
                 if op in ('JAM', 'BRK', 'RTS', 'RTI', 'JMPI', 'JMP'):
                     break
                 a = (a + length(mode)) & 0xffff
+
+    def find_wait_loops(self):
+        """{address of `LDA abs INTIM`: (INTIM address, cycles of one iteration)} for `LDA INTIM; BNE back`"""
+        out = {}
+        for a, (mode, kind, op, b1, b2) in self.code.items():
+            ea = b1 | (b2 << 8)
+            if op != 'LDA' or mode != M_ABS or (ea & 0x1000) or (ea & 0x285) != 0x284:
+                continue
+            nx = (a + 3) & 0xffff
+            if nx not in self.code or self.code[nx][2] != 'BNE':
+                continue
+            c1 = self.code[nx][3]
+            npc = (nx + 2) & 0xffff
+            if (npc + (c1 - 256 if c1 & 0x80 else c1)) & 0xffff != a:
+                continue
+            out[a] = (ea, 4 + (4 if ((a ^ npc) & 0xff00) else 3))
+        return out
+
+    def emit_wait_loop(self, a):
+        ea, it = self.wait_loops[a]
+        nxt = (a + 5) & 0xffff
+        return [
+            '// timer wait loop (LDA INTIM; BNE back): in place; iterations during which the timer value stays >= 2 are skipped',
+            'for (;;) {',
+            '  if (__builtin_expect(n > kNativeInstrLimit, 0)) { --n; e.PC = 0x%04x; return; }' % a,
+            '  {',
+            '    const int delta = (e.cyc + 3) - e.timer_set_cyc;  // Emu::riot_read at this iteration\'s read cycle',
+            '    const int bound = (e.timer - 2) << e.timer_shift;   // the value read is >= 2 while delta < bound',
+            '    if (bound > delta) {',
+            '      int k = (bound - delta + %d) / %d;' % (it - 1, it),
+            '      const int room = (kNativeInstrLimit - n) >> 1;',
+            '      k = k > room ? room : k;',
+            '      n += 2 * k; e.cyc += %d * k;' % it,
+            '    }',
+            '  }',
+            '  e.cyc += 4;',
+            '  const int m = e.riot_read(0x%04x);' % ea,
+            '  e.A = m; e.set_nz(e.A);',
+            '  ++n;  // the BNE',
+            '  if (m == 0) { e.cyc += 2; break; }',
+            '  e.cyc += %d;' % (it - 4),
+            '  ++n;  // the next LDA',
+            '}',
+            self.goto(nxt),
+        ]
 
     def find_loops(self):
         """Innermost 6507 loops that get a single way in.  The dispatch switch of native_run enters the
@@ -582,6 +632,8 @@ class Cart(object):
     def emit(self, a):
         self.cur = a
         mode, kind, op, b1, b2 = self.code[a]
+        if self.tc is None and a in self.wait_loops:
+            return self.emit_wait_loop(a)
         L = []
         nxt = (a + length(mode)) & 0xffff
         fb = self.fallback(a)

@@ -43,7 +43,11 @@ struct Emu {
   int jam = 0;
   int& cyc;
   int& stop;   // VSYNC released: the frame is over (the generated code leaves right after that store)
-  explicit Emu(Atari* m) : a(m), cyc(m->cyc), stop(m->stop) {}
+  // RIOT timer state, read by the generated timer-wait loops to skip the iterations whose outcome is known
+  uint8_t& timer;
+  uint8_t& timer_shift;
+  int32_t& timer_set_cyc;
+  explicit Emu(Atari* m) : a(m), cyc(m->cyc), stop(m->stop), timer(m->timer), timer_shift(m->timer_shift), timer_set_cyc(m->timer_set_cyc) {}
 
   void load() { A = a->A; X = a->X; Y = a->Y; S = a->S; PC = a->PC; pset(a->P); pend = -1; }
   void store() { a->A = (uint8_t)A; a->X = (uint8_t)X; a->Y = (uint8_t)Y; a->S = (uint8_t)S; a->PC = (uint16_t)PC; a->P = (uint8_t)pfull(); }
