@@ -67,9 +67,25 @@ def test_hot_loops_are_emitted_as_traces():
     i0 = src.index('TL_F5E0:')
     body = src[i0:src.index('generic copy of the trace head', i0)]
     assert 'e.S ==' not in body and body.count('TL_') > 57           # no stack-pointer guards inside the trace
-    # breakout: its loops index RAM with X (nothing to hoist) and the second copy costs more than it saves (measured)
+    # breakout: its display loops index RAM with X and write through X (`DEC zp,X`): nothing is hoisted there, the
+    # stack-pointer / binary-mode facts and the single entry remain
     g, b = _cart('breakout')
-    assert not b.traces
+    assert {0xf040, 0xf0b1} <= set(b.traces) and not b.traces[0xf040].hoist and b.traces[0xf0b1].use_S
+
+
+def test_tia_stores_are_recorded_and_timer_wait_loops_run_in_place():
+    """round 4: a TIA store of the translated code is Emu::tia_store (no-op rewrite, or a record for the picture wave);
+    only a full local log hands over through `pend`, and a VSYNC store leaves when it ended the frame; the
+    `LDA INTIM; BNE back` wait loops of both cartridges are emitted as in-place loops that skip the iterations whose
+    outcome is known"""
+    g, c = _cart('pong')
+    src = c.source('GAME_PONG')
+    assert 'e.tia_store(0x' in src and 'tia_store_quiet' not in src and 'pf_enqueue' not in src
+    assert 'if (e.stop) { e.PC = 0x' in src
+    assert set(c.wait_loops) == {0xf094, 0xf21f} and c.wait_loops[0xf21f] == (0x0284, 7)
+    assert 'timer wait loop (LDA INTIM; BNE back)' in src and 'const int bound = (e.timer - 2) << e.timer_shift;' in src
+    g, b = _cart('breakout')
+    assert {0xf33a, 0xf611} <= set(b.wait_loops)
 
 
 @pytest.mark.parametrize('name,max_wait', [('pong', 10.0), ('breakout', 10.0)])
