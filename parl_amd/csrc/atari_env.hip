@@ -124,8 +124,13 @@ __device__ unsigned long long g_env_regions[8192][12];
 // Two wavefronts per env (atari_core.hpp): waves 0 .. 3 of a workgroup run the 6507 / RIOT / wrapper chain of its
 // four envs, waves 4 .. 7 their pictures.  mode STEP: VectorEnv.step; RESET: VectorEnv.reset; SNAPSHOT: env k
 // builds reset snapshot k (noops = k+1) for the O(1) real-reset path.
+// __launch_bounds__(512, 4 waves per SIMD) = at most 128 VGPRs (the kernel needed 160 / 139 unconstrained; no scratch
+// at 128): an env workgroup leaves half of every SIMD's register file to the learner's MFMA kernels (~200 VGPRs per
+// wave), which otherwise cannot be resident beside it at all — and since the emulator is on every CU for 80 % of an
+// env step, the learner then only ran in the gaps and the pipeline became learner-bound (measured: the actors idle
+// 9 ms of every 50 ms rollout waiting for the learner's pass; tools/actor_gaps.sh).
 template <int GAME>
-__global__ __launch_bounds__(128 * kEnvsPerBlock) void atari_env_kernel(
+__global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
     uint8_t* __restrict__ states, const uint32_t* __restrict__ romw_g, EnvParams prm,
     const long long* __restrict__ actions, uint8_t* __restrict__ frames,
     float* __restrict__ rewards, uint8_t* __restrict__ dones, uint8_t* __restrict__ obs_flags,
