@@ -144,7 +144,10 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
   __syncthreads();
   // One wavefront per env is a long serial dependency chain: when other kernels (the learner's
   // GEMMs on another stream) share the SIMD, this wave should win every issue arbitration.
-  __builtin_amdgcn_s_setprio(3);
+#ifndef PARLHIP_ENV_PRIO
+#define PARLHIP_ENV_PRIO 3
+#endif
+  __builtin_amdgcn_s_setprio(PARLHIP_ENV_PRIO);
   const int lane = threadIdx.x & 63;
   const int wave = rfl((int)(threadIdx.x >> 6));
   const int slot = wave & (kEnvsPerBlock - 1);
