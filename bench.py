@@ -84,7 +84,7 @@ def pmc_traffic(key):
     shape (profiles/r01_scan_hbm_traffic.json, produced by tools/prof_traffic.sh: separate
     FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction).  bench.py cannot run under two
     rocprofv3 passes itself; the source file is named next to the number."""
-    for name in ('r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01e_scan_hbm_traffic.json', 'r01_scan_hbm_traffic.json'):
+    for name in ('r04_hbm_traffic.json', 'r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01e_scan_hbm_traffic.json', 'r01_scan_hbm_traffic.json'):
         try:
             t = json.load(open(os.path.join(ROOT, 'profiles', name)))[key]
             return {'traffic': t['hbm_traffic_bytes'], 'traffic_source': 'profiles/%s:%s' % (name, key)}

@@ -7,11 +7,15 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -1 $O/pytest_gpu.log
-bash tools/prof_bench.sh ${TAG}_bench > /dev/null 2>&1
-bash tools/prof_bench.sh ${TAG}_bench_quick --quick > /dev/null 2>&1
+# the DRIVER's command line (round 3's verdict: the kept profile must come from it), then the same with --quick
+bash tools/prof_bench.sh ${TAG}_bench --gpus 1 --steps 20 --warmup 5 > /dev/null 2>&1
+bash tools/prof_bench.sh ${TAG}_bench_quick --gpus 1 --steps 20 --warmup 5 --quick > /dev/null 2>&1
+python bench.py --gpus 1 --steps 20 --warmup 2 --quick --no-cpu-baseline > $O/bench_quick_warmup2.json 2> /dev/null
+bash tools/actor_gaps.sh $O/actor_gaps.txt > /dev/null 2>&1
 bash tools/prof_traffic.sh > $O/traffic.log 2>&1
 bash tools/pmc_env.sh $O/env_pmc.log > /dev/null 2>&1
 (python tools/emu_bench.py PongNoFrameskip-v4 1024,4096; python tools/emu_bench.py BreakoutNoFrameskip-v4 1024,4096) 2>&1 | grep "E=" > $O/emu_bench.log
+if [ -f build_exp/regions.so ]; then (for g in PongNoFrameskip-v4 BreakoutNoFrameskip-v4; do PARL_HIP_LIB=$R/build_exp/regions.so python tools/env_regions.py $g 1024 40; done) 2>&1 | grep -v amdgpu > $O/env_regions.log; fi
 python tools/microbench.py > $O/microbench_scans.json 2> $O/microbench.err
 python tools/learner_bench.py --json $O/learner_bench.json > $O/learner_bench.log 2>&1
 (bash tools/prof_heads_alone.sh tree; python tools/heads_beside_env.py; bash tools/pmc_heads.sh $O/heads_pmc_raw.log) > $O/heads_loss.log 2>&1
