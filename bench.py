@@ -698,7 +698,7 @@ def main():
         # (no collectives), the kernel bracketed by HIP events on the learner stream.
         del pipe, rollout, envs, env, model, alg, step
         torch.cuda.empty_cache()
-        one = one_update_leg(dev, E, T, dim, args.game, 10 if (world == 1 and not args.quick) else 5, args.learn_rows,
+        one = one_update_leg(dev, E, T, dim, args.game, 20 if (world == 1 and not args.quick) else 5, args.learn_rows,
                              env_id0=rank * E)
         hl_in, hl_in_stats = one.pop('heads_loss_in_pipeline_s'), one.pop('heads_loss_in_pipeline_stats_us')
         torch.cuda.empty_cache()

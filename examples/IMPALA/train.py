@@ -245,6 +245,10 @@ if __name__ == '__main__':
     ap.add_argument('--env-dim', type=int, default=None, choices=(42, 84),
                     help='observation size: 42 (config default, AtariModel42) or 84 (AtariModel84; pipeline mode)')
     ap.add_argument('--log-interval', type=float, default=None)
+    ap.add_argument('--seed', type=int, default=None,
+                    help='seed of the network initialisation, the envs and the sampler (default: the envs / sampler use 0, '
+                    'the initialisation is unseeded as in the reference); the pipeline mode with synchronous launches '
+                    '(Pong) is then one reproducible run, elastic launches (Breakout) still follow the host\'s polling')
     ap.add_argument('--threads', action='store_true',
                     help='the reference\'s thread-per-actor structure (class Learner) instead of the stream pipeline')
     ap.add_argument('--pipeline', action='store_true', help='(default; kept for older command lines)')
@@ -261,6 +265,10 @@ if __name__ == '__main__':
     if args.env_dim:
         assert args.env_dim == 42 or not args.threads, '--env-dim 84 runs in the pipeline mode'
         config['env_dim'] = args.env_dim
+    if args.seed is not None:
+        config['seed'] = args.seed
+        torch.manual_seed(args.seed)
+        np.random.seed(args.seed)
     if not args.threads:
         learner = PipelineLearner(config)
         t0 = t_log = time.time()

@@ -194,6 +194,8 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
   emu.lane = lane;
   emu.rq = &rqs[slot];
   emu.rq_wr = 0;
+  emu.cx_spec = 0;
+  emu.cx_spec_seq = 0;
   emu.wqn = 0;
   emu.wq = emu.wq2 = 0;
   uint8_t* blob;
@@ -412,6 +414,7 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
           emu.rq_wait_idle();  // the picture wave may still be drawing into the frame pair this restore overwrites
           load_env(emu, v, src, lane);
           emu.rq_ctl(Emu::LA_RELOAD, (uint32_t)k, 0);
+          emu.cx_spec = 0;
           emu.jam |= jam_keep;
           v.compat_count = cc;
           v.reset_count = rc;

@@ -317,6 +317,8 @@ class Cart(object):
         self.trace_of = {}    # instruction start inside a traced loop -> its head
         if TRACE_LOOPS and name in TRACE_GAMES and name not in LOOP_REENTRY_GAMES:
             for h, stream in all_loops:
+                if set(stream) & set(self.wait_loops):
+                    continue  # a timer wait loop: run in place with its iterations skipped (emit_wait_loop)
                 if max(self.branch_taken.get(x, 0) for x in stream) >= TRACE_MIN_TAKEN:
                     self.traces[h] = Trace(self, h, stream)
                     for x in stream:
@@ -449,7 +451,7 @@ class Cart(object):
                         t = (x + 2 + (b1 - 256 if b1 & 0x80 else b1)) & 0xffff
                         if t <= x and t != h:
                             ok = False
-                if ok and len(stream) >= 4:
+                if ok and len(stream) >= 2:
                     cands.append((len(stream), h, stream))
                     break
         # overlapping decodes produce overlapping candidates: the longer stream wins, disjoint ones only
