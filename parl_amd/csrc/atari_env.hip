@@ -118,8 +118,36 @@ DEVI void store_env(const Emu& e, const Wrap& v, uint8_t* blob, int lane) {
 __device__ unsigned long long g_env_t0[8192], g_env_t1[8192];
 #endif
 #ifdef PARLHIP_ENV_REGIONS  // diagnostic build only (tools/env_regions.py): where a wave's launch goes
-__device__ unsigned long long g_env_regions[8192][12];
+__device__ unsigned long long g_env_regions[8192][16];
 #endif
+
+// The env's picture: render-side TIA registers, collision latches, frame buffers (Emu::render_main).  NOT inlined
+// into the env kernel: a function of its own is register-allocated on its own — inside the kernel it shared one
+// allocation with the translated cartridges (the biggest function of the library, 500-1500 SGPR spills), and the
+// sixteen scalar registers of its register file went to spill lanes.  One call per launch; the arguments arrive in
+// vector registers (the calling convention) and are made wave-uniform again.
+__device__ __attribute__((noinline)) void picture_wave_main(uint8_t* blob_v, const uint8_t* snap_v, RenderQueue* rq_v, int e_v) {
+  auto uni = [](const void* p) -> unsigned long long {
+    const unsigned long long x = (unsigned long long)(uintptr_t)p;
+    return ((unsigned long long)(uint32_t)rfl((int)(x >> 32)) << 32) | (uint32_t)rfl((int)(uint32_t)x);
+  };
+  uint8_t* blob = (uint8_t*)(uintptr_t)uni(blob_v);
+  const uint8_t* snap = (const uint8_t*)(uintptr_t)uni(snap_v);
+  Emu r;
+  r.lane = (int)(threadIdx.x & 63);
+  r.rq = (RenderQueue*)(uintptr_t)uni(rq_v);
+#ifdef PARLHIP_ENV_REGIONS
+  for (int i = 0; i < 5; ++i) { r.rt[i] = 0; r.rn[i] = 0; }
+#endif
+  r.render_main(blob, snap, kSnapBytes);
+#ifdef PARLHIP_ENV_REGIONS
+  const int e = rfl(e_v);
+  if (r.lane == 0 && e < 8192) { g_env_regions[e][9] = r.rt[3]; g_env_regions[e][10] = r.rt[4]; g_env_regions[e][11] = r.rt[0];
+    g_env_regions[e][12] = r.rt[1]; g_env_regions[e][13] = (unsigned long long)r.rn[0]; g_env_regions[e][14] = (unsigned long long)r.rn[1]; }
+#else
+  (void)e_v;
+#endif
+}
 
 // Two wavefronts per env (atari_core.hpp): waves 0 .. 3 of a workgroup run the 6507 / RIOT / wrapper chain of its
 // four envs, waves 4 .. 7 their pictures.  mode STEP: VectorEnv.step; RESET: VectorEnv.reset; SNAPSHOT: env k
@@ -164,22 +192,10 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
 #endif
   const int mode = prm.mode, game = prm.game;
   if (picture_wave) {
-    // the env's picture: render-side TIA registers, collision latches, frame buffers (Emu::render_main)
-    Emu r;
-    r.lane = lane;
-    r.rq = &rqs[slot];
     uint8_t* rblob = mode == MODE_SNAPSHOT ? snap + (size_t)e * kSnapBytes : states + (size_t)e * kStateBytes;
-#ifdef PARLHIP_ENV_REGIONS
-    r.rt[3] = r.rt[4] = 0;
-#endif
-    r.render_main(rblob, snap, kSnapBytes);
-#ifdef PARLHIP_ENV_REGIONS
-    if (lane == 0 && e < 8192) { g_env_regions[e][9] = r.rt[3]; g_env_regions[e][10] = r.rt[4]; }
-#endif
+    picture_wave_main(rblob, snap, &rqs[slot], e);
     return;
   }
-  // translated code is only used for the cartridge it was generated from (tag set by
-  // parlhip_atari_rom_table_build after a CRC match)
   const bool native_ok = NativeCart<GAME>::present && rfl((int)(rom_lds[0] >> 28)) == GAME;
   const long long max_steps = prm.max_episode_steps;
 
@@ -667,7 +683,7 @@ PARLHIP_EXPORT int parlhip_atari_vec_step_elastic(void* states, const uint32_t* 
 #ifdef PARLHIP_ENV_REGIONS
 PARLHIP_EXPORT int parlhip_debug_env_regions(unsigned long long* host, int n) {
   if (n > 8192) return PARLHIP_EINVAL;
-  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(parlhip::atari::g_env_regions), (size_t)n * 96) != hipSuccess) return PARLHIP_EINVAL;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(parlhip::atari::g_env_regions), (size_t)n * 128) != hipSuccess) return PARLHIP_EINVAL;
   return PARLHIP_OK;
 }
 #endif

@@ -24,7 +24,7 @@ if __name__ == '__main__':
     f = N.lib().parlhip_debug_env_regions
     f.restype = ctypes.c_int
     f.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    buf = np.zeros((E, 12), np.uint64)
+    buf = np.zeros((E, 16), np.uint64)
     g = torch.Generator(device='cpu').manual_seed(0)
     acc = []
     for i in range(warm + 30):
@@ -35,7 +35,7 @@ if __name__ == '__main__':
             torch.cuda.synchronize()
             assert f(buf.ctypes.data, E) == 0
             acc.append(buf.astype(np.float64).copy())
-    a = np.mean(acc, axis=0)  # [E, 12] mean over launches
+    a = np.mean(acc, axis=0)  # [E, 16] mean over launches
     m = a.mean(axis=0)
     frames = max(m[7], 1e-9)
     print('%s E=%d: per env and launch (%.1f frames): wave A %.0f clocks, wave B %.0f clocks' % (game, E, frames, m[8], m[10]))
@@ -44,3 +44,5 @@ if __name__ == '__main__':
               (name, m[i], 100 * m[i] / m[8], m[4 + i] / frames, m[i] / max(m[4 + i], 1)))
     print('  %-28s %9.0f clocks = %4.1f %% of wave A' % ('A: rest (frame loop, wrapper)', m[8] - m[0] - m[1] - m[2], 100 * (m[8] - m[0] - m[1] - m[2]) / m[8]))
     print('  %-28s %9.0f clocks = %4.1f %% of wave B\'s lifetime (the rest: polling an empty ring)' % ('B: replaying records', m[9], 100 * m[9] / max(m[10], 1)))
+    print('  %-28s %9.0f clocks in tia_update (%.1f calls per frame, %.0f clocks each), of it render_seg %.0f clocks (%.1f calls per frame, %.0f each)' %
+          ('B:', m[11], m[13] / frames, m[11] / max(m[13], 1), m[12], m[14] / frames, m[12] / max(m[14], 1)))
