@@ -420,9 +420,10 @@ class AsyncActorLearner(object):
             p.requires_grad_(False)
         dev = self.env.device
         # the rollouts are the critical path (latency-bound emulator): high-priority queues
-        self.actor_streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in self.envs]
+        ap, lp = (int(x) for x in os.environ.get('PARL_AMD_STREAM_PRIO', '-1,0').split(','))
+        self.actor_streams = [torch.cuda.Stream(device=dev, priority=ap) for _ in self.envs]
         self.actor_stream = self.actor_streams[0]
-        self.learn_stream = torch.cuda.Stream(device=dev, priority=0)
+        self.learn_stream = torch.cuda.Stream(device=dev, priority=lp)
         self.weights_ready = torch.cuda.Event()
         self.snapshot_done = torch.cuda.Event()
         G = len(self.envs)

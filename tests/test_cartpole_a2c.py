@@ -182,8 +182,8 @@ def _train(calc_gae, max_updates=200, target=150.0):
             if len(recent) >= 20 and np.mean(recent) >= target:
                 break
         assert learner.sample_total_steps == learner.updates * rows
-        print('CartPole-v1 A2C, 4 remote actors x 4 envs: (update, mean return of the last <= 40 episodes)', curve,
-              '-> %.1f after %d updates' % (np.mean(recent), learner.updates))
+        sys.__stdout__.write('\nCartPole-v1 A2C, 4 remote actors x 4 envs: (update, mean return of the last <= 40 episodes) %s '
+                             '-> %.1f after %d updates\n' % (curve, np.mean(recent), learner.updates))
         return float(np.mean(recent)), learner.updates
     finally:
         torch.set_num_threads(n0)

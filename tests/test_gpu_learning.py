@@ -37,13 +37,14 @@ def _curve(rows):
              None if r.get('kl') is None else round(r['kl'], 5)) for r in rows]
 
 
-def test_impala_pong_learns_at_the_reference_hyperparameters():
+def test_impala_pong_learns_at_the_reference_hyperparameters(capsys):
     """PongNoFrameskip-v4, 1024 actors, 42x42, T=50, train_batch_size 1000, lr 1e-3 -> 5e-4 -> 1e-4 at 20k / 40k
     updates, entropy -0.01: >= +15 (mean return of the episodes closed in the last 10 s window) after ~70 s and a
     behaviour / target KL below 0.01 (the actors' weights are at most a fraction of a rollout old)"""
     rows = _train(['--minutes', '1.2', '--log-interval', '10', '--seed', '1'], timeout=300)
-    print('\nIMPALA Pong 1024 envs (elapsed s, mean_episode_rewards, kl):', _curve(rows))
-    print('env frames/s %.0f, learner updates/s %.0f' % (rows[-1]['env_frames_per_s'], rows[-1]['learner_updates_per_s']))
+    with capsys.disabled():  # into the pytest log also when the test passes (the driver keeps that log)
+        print('\nIMPALA Pong 1024 envs (elapsed s, mean_episode_rewards, kl):', _curve(rows))
+        print('env frames/s %.0f, learner updates/s %.0f' % (rows[-1]['env_frames_per_s'], rows[-1]['learner_updates_per_s']))
     last = [r for r in rows if r['mean_episode_rewards'] is not None][-2:]
     assert max(r['mean_episode_rewards'] for r in last) >= 15.0, _curve(rows)
     assert rows[0]['mean_episode_rewards'] < 0.0, _curve(rows)  # it started from a random policy (-20.4; round 4's
@@ -53,7 +54,7 @@ def test_impala_pong_learns_at_the_reference_hyperparameters():
     assert rows[-1]['env_frames_per_s'] > 1.5e6 and rows[-1]['learner_updates_per_s'] > 400
 
 
-def test_impala_breakout_learns_with_elastic_launches():
+def test_impala_breakout_learns_with_elastic_launches(capsys):
     """BreakoutNoFrameskip-v4 (configs[3]'s game, one GPU's 1024 actors, elastic launches): game score >= 60 in
     the last window after ~55 s, from the 1.5 of random play (the reference's curve passes 100 after several minutes of
     its 32 CPU actors).  The take-off time depends on the initialisation — measured over seeds 0-3 on one MI355X: 93 /
@@ -61,6 +62,7 @@ def test_impala_breakout_learns_with_elastic_launches():
     launches still follow the host's polling, the run is not bit-reproducible."""
     rows = _train(['--env-name', 'BreakoutNoFrameskip-v4', '--minutes', '0.95', '--log-interval', '10', '--seed', '1'],
                   timeout=300)
-    print('\nIMPALA Breakout 1024 envs (elapsed s, mean_episode_rewards, kl):', _curve(rows))
+    with capsys.disabled():
+        print('\nIMPALA Breakout 1024 envs (elapsed s, mean_episode_rewards, kl):', _curve(rows))
     last = [r for r in rows if r['mean_episode_rewards'] is not None][-2:]
     assert max(r['mean_episode_rewards'] for r in last) >= 60.0, _curve(rows)
