@@ -484,8 +484,15 @@ __global__ __launch_bounds__(256, 2) void conv1_84_u8_mfma_kernel(
 //   a1 [32,20,20] (the output of conv1_84_u8_mfma_kernel) -> conv2 32->64 k4 s2 p2 + ReLU
 //   -> a2 [64,11,11] (stays in LDS) -> conv3 64->64 k3 s1 + ReLU -> a3 [64,9,9] = the 5184-wide
 //   input of the fc layer.  13.9 MFLOP per observation.
-// One workgroup per observation (grid-stride); a1 zero-padded in LDS ([32][24][24] f32, 73.7 KB),
-// a2 in LDS ([64][121], 31 KB).  The weight matrices (128 KB + 147 KB) fit neither registers nor
+// One workgroup per observation (grid-stride).  conv2 sums over its 32 input channels in channel-major k order,
+// so a1 goes through LDS EIGHT CHANNELS AT A TIME (round 4): a zero-padded [8][24][24] f32 tile (18.4 KB), four
+// passes of 32 k-steps over the same accumulators — the same sequence of FMAs as with the whole [32][24][24] tile
+// (73.7 KB, rounds 1-3): bit-identical outputs — the next quarter's 12.5 floats per thread prefetched into
+// registers while the MFMAs of the current one run.  With a2 in LDS ([64][121], 31 KB) that is 49.4 KB instead of
+// 104.7: the ACTORS' conv2 + conv3 now fits on a CU beside a learner workgroup (75-113 KB) instead of waiting for the
+// learner's persistent grids to end — at 84x84 rollout and update used to exclude each other almost completely
+// (rollout alone 55 ms + update alone 56 ms = 112-115 ms overlapped).
+// The weight matrices (128 KB + 147 KB) fit neither registers nor
 // the remaining LDS: they are STREAMED from L2 in MFMA operand order — `wt2[ks][nt][lane]`,
 // `wt3[ks][nt][lane]` (prepared by the host wrapper: one 256-byte coalesced load per wave and
 // k-step) — each wave owning one 16-channel N tile and all M tiles, so every streamed B value
@@ -496,19 +503,20 @@ __global__ __launch_bounds__(256, 2) void conv1_84_u8_mfma_kernel(
 constexpr int kA1 = 20, kA1P = 24, kA1Plane = kA1P * kA1P;      // conv1 output, padded by 2
 constexpr int kA2 = 11, kM2b = kA2 * kA2;                        // 121 conv2 outputs
 constexpr int kA3 = 9, kM3 = kA3 * kA3;                          // 81 conv3 outputs
-constexpr int kLds23Floats = 32 * kA1Plane + 64 * kM2b;          // 18,432 + 7,744 = 26,176 floats = 104,704 B
+constexpr int kA1Q = 8;                                           // a1 channels per LDS pass
+constexpr int kLds23Floats = kA1Q * kA1Plane + 64 * kM2b;        // 4,608 + 7,744 = 12,352 floats = 49,408 B
 
 __global__ __launch_bounds__(256) void conv23_84_mfma_kernel(
     const float* __restrict__ a1, const float* __restrict__ wt2, const float* __restrict__ b2,
     const float* __restrict__ wt3, const float* __restrict__ b3, float* __restrict__ a2_out,
     float* __restrict__ a3_out, int n_obs) {
   extern __shared__ float lds[];
-  float* a1p = lds;                       // [32][24][24]
-  float* a2s = lds + 32 * kA1Plane;       // [64][121]
+  float* a1p = lds;                       // [8][24][24]: one quarter of a1's channels at a time
+  float* a2s = lds + kA1Q * kA1Plane;     // [64][121]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, col = lane & 15;
   const float bias2 = b2[16 * wave + col], bias3 = b3[16 * wave + col];
-  for (int i = tid; i < 32 * kA1Plane; i += 256) a1p[i] = 0.0f;   // borders stay zero
+  for (int i = tid; i < kA1Q * kA1Plane; i += 256) a1p[i] = 0.0f;   // borders stay zero
   // conv2 gather offsets of this lane's 8 M tiles: position m -> (2*oy)*24 + 2*ox + kw (kw = q)
   int off2[8];
 #pragma unroll
@@ -528,28 +536,41 @@ __global__ __launch_bounds__(256) void conv23_84_mfma_kernel(
   }
 #pragma unroll 1
   for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
-    __syncthreads();
-    // ---- a1 -> padded LDS tile ----
-    const float4* src = reinterpret_cast<const float4*>(a1 + (size_t)n * 32 * kA1 * kA1);
-    for (int i = tid; i < 32 * kA1 * kA1 / 4; i += 256) {
-      const float4 v = src[i];
-      const int e = i * 4, c = e / (kA1 * kA1), r = e - c * kA1 * kA1, y = r / kA1, x = r - y * kA1;   // 20 % 4 == 0
-      float* d = a1p + c * kA1Plane + (y + 2) * kA1P + (x + 2);
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    __syncthreads();
-    // ---- conv2: wave = N tile (channels 16*wave ..), 8 M tiles, 128 k-steps ----
+    // ---- conv2: wave = N tile (channels 16*wave ..), 8 M tiles, 128 k-steps = 4 passes of 8 input channels ----
     {
+      constexpr int kQ4 = kA1Q * kA1 * kA1 / 4;   // 800 float4 per quarter: up to 4 per thread
+      const float4* src = reinterpret_cast<const float4*>(a1 + (size_t)n * 32 * kA1 * kA1);
+      float4 pre[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int i = tid + 256 * j; if (i < kQ4) pre[j] = src[i]; }
       f32x4 acc[8];
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* wp = wt2 + wave * 64 + lane;            // wt2[ks][nt = wave][lane]
-#pragma clang loop unroll_count(2)
-      for (int ks = 0; ks < 128; ++ks) {
-        const float b = wp[ks * 256];
-        const float* ab = a1p + (ks >> 2) * kA1Plane + (ks & 3) * kA1P;   // c = ks >> 2, kh = ks & 3
+#pragma unroll 1
+      for (int pass = 0; pass < 32 / kA1Q; ++pass) {
+        __syncthreads();   // the previous pass (or the previous observation's conv3) is done with the tile
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[off2[mt]], b, acc[mt], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          const int i = tid + 256 * j;
+          if (i < kQ4) {
+            const int e = i * 4, c = e / (kA1 * kA1), r = e - c * kA1 * kA1, y = r / kA1, x = r - y * kA1;   // 20 % 4 == 0
+            float* d = a1p + c * kA1Plane + (y + 2) * kA1P + (x + 2);
+            d[0] = pre[j].x; d[1] = pre[j].y; d[2] = pre[j].z; d[3] = pre[j].w;
+          }
+        }
+        __syncthreads();
+        if (pass + 1 < 32 / kA1Q) {   // the next quarter is in flight while this one's MFMAs run
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const int i = tid + 256 * j; if (i < kQ4) pre[j] = src[(pass + 1) * kQ4 + i]; }
+        }
+#pragma clang loop unroll_count(2)
+        for (int kq = 0; kq < 4 * kA1Q; ++kq) {
+          const float b = wp[(pass * 4 * kA1Q + kq) * 256];
+          const float* ab = a1p + (kq >> 2) * kA1Plane + (kq & 3) * kA1P;   // c = 8 * pass + (kq >> 2), kh = kq & 3
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[off2[mt]], b, acc[mt], 0, 0, 0);
+        }
       }
       float* g2 = a2_out ? a2_out + (size_t)n * 64 * kM2b : nullptr;
 #pragma unroll
@@ -1055,7 +1076,9 @@ PARLHIP_EXPORT int parlhip_atari84_conv23_f32(const float* a1, const float* wt2,
     if (rc) return rc;
     attr_set = true;
   }
-  const int grid = n_obs < kNumCU ? n_obs : kNumCU;   // 105 KB of LDS: one workgroup per CU
+  // 49 KB of LDS: up to three workgroups per CU (two are launched: more only shortens the streamed-weight reuse),
+  // one beside a learner workgroup
+  const int grid = n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU;
   conv23_84_mfma_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(a1, wt2, b2, wt3, b3, a2_out, a3_out, n_obs);
   return check_launch();
 }
