@@ -781,16 +781,16 @@ def main():
         out['roofline_frame_post'].update(pmc_traffic('frame_post_E%d_d%d' % (Eg, dim)))
         # the dominant kernel, for completeness: algorithmic HBM bytes of one VectorEnv.step launch
         # (per env: 512 B state read + written, two 33,600 B colour frames written, action / reward /
-        # done / flags) against its duration.  It is NOT HBM-bound: one wavefront per env executes the
+        # done / flags) against its duration.  It is NOT HBM-bound: one wavefront per env executes the 6507 of the
         # cartridge serially; what bounds it is single-wave instruction issue.
         envb = Eg * (2 * 512 + 2 * 33600 + 8 + 4 + 1 + 1 + 4 + 4)
         out['roofline_env_kernel'] = {
             'kernel': 'atari_env_kernel<GAME> (VectorEnv.step: 4 emulated frames for each of %d envs)' % Eg,
             'bound': 'hbm', 'achieved': envb / es / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
             'frac': envb / es / 1e9 / HBM_PEAK_GBPS, 'traffic': None, 'bytes_per_launch': envb,
-            'note': 'latency-bound, not bandwidth-bound: one wave per SIMD issues ~1 instruction per 4.5 clk and '
-                    'pays 12-30 clk per branch (profiles/r01c_issue_microbench.log); the timed call also contains '
-                    'frame_post + since_update',
+            'note': 'latency-bound, not bandwidth-bound: a single wave issues ~1 instruction per 4.5 clk and pays 12-30 clk '
+                    'per branch (profiles/r01c_issue_microbench.log); two waves per env since round 4 (6507 | picture, '
+                    'DESIGN 4.1); the timed call also contains frame_post',
         }
         out['kernels'] = {
             'env_step_ms (atari_env_kernel + frame_post + since_update, one agent step of one %d-env group; %d '

@@ -250,7 +250,9 @@ int parlhip_frame_post_step_u8(const uint8_t* frames0, const uint8_t* frames1, i
 /* ------------------------------------------------------------------------------------
  * Vectorised Atari env: VectorEnv([wrap_deepmind(gym.make(id), dim, obs_format='NCHW')]*E)
  * parl/env/vector_env.py:34-63 + parl/env/atari_wrappers.py:356-385 + the ALE emulator
- * behind gym.make (third party; restated, see oracle/atari_oracle.h).  One env per wavefront.
+ * behind gym.make (third party; restated, see oracle/atari_oracle.h).  One env per wavefront for the 6507 / RIOT /
+ * wrapper chain, plus (round 4) a second wavefront of the same workgroup that draws the env's picture from the
+ * stream of TIA register records the first one produces.
  * ------------------------------------------------------------------------------------ */
 #define PARLHIP_GAME_PONG 1
 #define PARLHIP_GAME_BREAKOUT 2

@@ -1,5 +1,5 @@
 """DeviceVectorEnv — VectorEnv([wrap_deepmind(gym.make(id), dim, obs_format='NCHW')] * E) with
-every env resident on one MI355X (one env per wavefront).
+every env resident on one MI355X (one env per wavefront pair: the 6507 on one wave, its picture on a second).
 
 Mirrors the contract of parl/env/vector_env.py:26-63 (``reset() -> obs batch``,
 ``step(actions) -> (obs, rewards, dones, infos)`` with auto-reset: the obs returned for a done

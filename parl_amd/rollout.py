@@ -384,7 +384,7 @@ class AsyncActorLearner(object):
                       per group, accumulated; [all-reduce], clip, Adam once)
 
     All of it is enqueued by one host thread; events order the streams.  The emulator kernel keeps
-    one wavefront per env busy and is latency-bound, so (a) the learner's GEMMs run in the issue
+    one wavefront pair per env busy and is latency-bound, so (a) the learner's GEMMs run in the issue
     slots it leaves free, and (b) with G >= 2 env groups the policy forward / sampling of one
     group runs while the other groups' emulator kernels are in flight (the reference gets the
     same effect from its 32 independent actor processes).  The actors' parameter snapshot plays
