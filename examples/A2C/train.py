@@ -1,7 +1,7 @@
 """A2C learner — the synchronous step() of examples/A2C/train.py:30-186 (kick off all actors,
 collect, one update) on the device path.
 
-    python examples/A2C/train.py [--max_sample_steps N] [--env-num E] [--horizon updates|samples]
+    python examples/A2C/train.py [--max_sample_steps N] [--env-num E] [--horizon updates|samples] [--seed S] [--minutes M]
 
 The config file carries the reference's `max_sample_steps` = 1e7, which its 5 x 5 CPU envs consume as 20,000
 updates of 500 rows.  An update here has env_num x actor_num x 20 rows (256 envs: 5,120), so the same number of
@@ -93,6 +93,7 @@ class Learner(object):
             'lr': self.lr,
             'entropy_coeff': self.entropy_coeff,
         }
+        metric = {k: (float(v) if isinstance(v, np.floating) else v) for k, v in metric.items()}   # plain numbers in the log
         for key, value in metric.items():
             if value is not None:
                 summary.add_scalar(key, value, self.sample_total_steps)
@@ -112,7 +113,16 @@ if __name__ == '__main__':
     parser.add_argument('--horizon', choices=('updates', 'samples'), default='updates',
                         help='what the config\'s max_sample_steps preserves when the actor pool is bigger than the '
                         'reference\'s 25 envs: the number of updates (scaled sample steps) or the sample steps')
+    parser.add_argument('--minutes', type=float, default=None, help='stop after this many minutes (the schedules keep '
+                        'their horizon: a look at the beginning of the run)')
+    parser.add_argument('--seed', type=int, default=None,
+                        help='seed of the network initialisation, the envs and the sampler (default: envs / sampler 0, '
+                        'torch\'s own default generator for the initialisation)')
     args = parser.parse_args()
+    if args.seed is not None:
+        config['seed'] = args.seed
+        torch.manual_seed(args.seed)
+        np.random.seed(args.seed)
     if args.env_num:
         config['env_num'] = args.env_num
     if args.max_sample_steps is not None:
@@ -128,7 +138,8 @@ if __name__ == '__main__':
         config['log_metrics_interval_s'] = args.log_interval
     learner = Learner(config)
     assert config['log_metrics_interval_s'] > 0
-    while not learner.should_stop():
+    deadline = time.time() + 60.0 * args.minutes if args.minutes else float('inf')
+    while not learner.should_stop() and time.time() < deadline:
         start = time.time()
         while time.time() - start < config['log_metrics_interval_s'] and not learner.should_stop():
             learner.step()

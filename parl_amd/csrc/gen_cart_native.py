@@ -646,8 +646,11 @@ class Cart(object):
                 pre, dc = ['const int m = 0x%02x;' % b1], 2
             elif mode == M_ZP:
                 if b1 < 0x80:
-                    return fb
-                pre, dc = ['const int m = %s;' % self.rd(b1 & 0x7f)], 3
+                    # a TIA read register: the collision latches wait for the picture wave to get there
+                    # (Emu::tia_read_zp), the input ports are sampled at the read cycle; no interpreter either way
+                    pre, dc = ['const int m = e.tia_read_zp(0x%02x, 0x%02x, e.cyc + 2);' % (b1, b1)], 3
+                else:
+                    pre, dc = ['const int m = %s;' % self.rd(b1 & 0x7f)], 3
             elif mode in (M_ZPX, M_ZPY):
                 idx = 'e.X' if mode == M_ZPX else 'e.Y'
                 # RAM, or an input port (INPTx: does not depend on the picture; Breakout polls `LDA $38,X`
@@ -655,7 +658,7 @@ class Cart(object):
                 pre = ['const int ea = (0x%02x + %s) & 0xff;' % (b1, idx), 'int dc = 4, m;',
                        'if (ea & 0x80) m = e.ram_rd(ea & 0x7f);',
                        'else if ((ea & 0x0f) >= 8) { e.cyc += 4; dc = 0; m = e.inpt_read(ea, 0x%02x); }' % b1,
-                       'else { --n; e.PC = 0x%04x; %sreturn; }' % (a, '' if self.name in ZPX_LATCH_GAMES else '/*rare*/ ')]
+                       'else m = e.tia_read_zp(ea, 0x%02x, e.cyc + 3);' % b1]   # a collision latch (Pong: `LDA CXM0P,X`)
                 dc = None
             elif mode == M_ABS:
                 ea = b1 | (b2 << 8)
@@ -831,6 +834,20 @@ class Cart(object):
             ea, dc, static = '((0x%02x + e.Y) & 0xff)' % b1, 4, None
         elif mode == M_PUSH:
             ea, dc, static = 'e.S', 3, None
+        elif mode in (M_ABS, M_ABX, M_ABY) and kind == K_WRITE:
+            # absolute stores (the RIOT timer, RAM / TIA through their mirrors): the address classes in the order of
+            # Emu::step's stage D; an indexed store always takes its extra cycle
+            val = {'STA': 'e.A', 'STX': 'e.X', 'STY': 'e.Y'}[op]
+            base = b1 | (b2 << 8)
+            dc = 4 if mode == M_ABS else 5
+            eaexp = '0x%04x' % base if mode == M_ABS else '((0x%04x + %s) & 0xffff)' % (base, 'e.X' if mode == M_ABX else 'e.Y')
+            pend = '{ --n; e.cyc += %d; e.pend = (ea & 0xff) | ((%s) << 8); e.PC = 0x%04x; return; }' % (dc - 1, val, nxt)
+            return ['const int ea = %s;' % eaexp,
+                    'if (ea & 0x1000) { e.cyc += %d; }' % dc,
+                    'else if (!(ea & 0x80)) { if (__builtin_expect(!e.tia_store(ea & 0x3f, %s, e.cyc + %d, %s), 0)) %s e.cyc += %d; '
+                    'if (__builtin_expect(e.stop, 0)) { e.PC = 0x%04x; e.pend = -2; return; } }' % (val, dc - 1, self.quiet_ok, pend, dc, nxt),
+                    'else if (!(ea & 0x200)) { e.ram_wr(ea & 0x7f, %s); e.cyc += %d; }' % (val, dc),
+                    'else { e.cyc += %d; e.riot_write(ea, %s); }' % (dc, val)]
         else:
             return fb
         if kind == K_WRITE:

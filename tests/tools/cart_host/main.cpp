@@ -128,6 +128,10 @@ struct Emu {
   int rom_byte(int ea) const { return a->rom[ea & a->rom_mask]; }
   int tia_read(int ea, int noise) { return host_tia_read(a, (uint16_t)ea, (uint8_t)noise); }
   int riot_read(int ea) { return host_riot_read(a, (uint16_t)ea); }
+  // the device waits for its picture wave before a collision-latch read; the oracle's read catches its own picture
+  // up to the cycle of the read (`c` = the cycle before it)
+  int tia_read_zp(int ea, int noise, int c) { const int c0 = cyc; cyc = c + 1; const int v = tia_read(ea, noise); cyc = c0; return v; }
+  void riot_write(int ea, int v) { cyc -= 1; host_wr(a, (uint16_t)ea, (uint8_t)v); }   // (host_wr counts the write cycle itself)
   void wsync(int cw) {
     const int into = (cw - a->cyc0) % kCyclesPerLine;
     cyc = cw + (into ? kCyclesPerLine - into : 0);
@@ -193,7 +197,7 @@ struct Emu {
   }
 };
 
-static long g_trace_iters[65536];
+static long g_trace_iters[65536], g_defer_pc[65536];
 #define PARLHIP_TRACE_ITER(head) (++g_trace_iters[head])
 template <int GAME> struct NativeCart { static constexpr bool present = false; static constexpr uint32_t rom_crc32 = 0; };
 template <int GAME> inline void native_run(Emu&, int&) {}
@@ -214,7 +218,7 @@ static void frame_translated(Atari* a, uint8_t* fb, long* native_instr, long* de
     if (e.pend == -2) continue;   // translated RTS / RTI: PC set, dispatch again (Emu::frame)
     if (e.pend < 0 && n >= kMaxInstrPerFrame) break;
     if (e.pend >= 0) host_wr(a, (uint16_t)(e.pend & 0xff), (uint8_t)(e.pend >> 8));   // Emu::step, pending path
-    else host_cpu_step(a);
+    else { ++g_defer_pc[a->PC]; host_cpu_step(a); }
     ++*deferred;
     ++n;
   }
@@ -265,6 +269,10 @@ static int run(const uint8_t* rom, int rom_size, int frames) {
          (double)native_instr / frames, (double)deferred / frames, ref.jam ? " (jam set)" : "");
   for (int h = 0; h < 65536; ++h)
     if (g_trace_iters[h]) printf("trace %04x: %.1f iterations per frame\n", h, (double)g_trace_iters[h] / frames);
+  if (getenv("CART_HOST_DEFERRALS"))   // which instructions still go to the interpreter (dev aid)
+    for (int h = 0; h < 65536; ++h)
+      if (g_defer_pc[h] * 10 >= frames) printf("interpreted %04x: %.1f per frame (opcode %02x)\n", h, (double)g_defer_pc[h] / frames, rom[h & (rom_size - 1)]);
+  memset(g_defer_pc, 0, sizeof(g_defer_pc)); memset(g_trace_iters, 0, sizeof(g_trace_iters));
   return 0;
 }
 
