@@ -20,6 +20,34 @@ namespace parlhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Fill phases (round 4).  Every kernel here copies its observation's inputs from HBM into LDS before its MFMA
+// phases.  Written as `for (i = tid; i < N; i += 256) lds[f(i)] = g(src[i])` the compiler kept ONE load in flight per
+// iteration (`global_load; s_waitcnt vmcnt(0); ds_write` in the ISA of rounds 1-3): N / 256 HBM round trips per
+// observation, one wave per SIMD and nobody to hide them — for conv1_84_bwd 40 round trips = 30 of the 42 us it
+// spent per observation.  A Batch issues ALL loads of a thread first (COUNT / 256 registers) and consumes them
+// afterwards; where the register file allows, the loads of the workgroup's NEXT observation are issued before the
+// MFMA phases of the current one and consumed after them (the `pre` objects below).
+template <int COUNT, typename T>
+struct Batch {
+  static constexpr int kPer = (COUNT + 255) / 256;
+  T v[kPer];
+  __device__ __forceinline__ void load(const T* __restrict__ src, int tid) {
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int i = tid + 256 * j;
+      if ((j + 1) * 256 <= COUNT || i < COUNT) v[j] = src[i];
+    }
+  }
+  template <typename F>
+  __device__ __forceinline__ void each(int tid, F&& f) const {
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int i = tid + 256 * j;
+      if ((j + 1) * 256 <= COUNT || i < COUNT) f(i, v[j]);
+    }
+  }
+};
+
 constexpr int kD = 42, kP1 = 44;          // input, zero-padded input (pad 1, +1 slack column/row)
 constexpr int kO1 = 21, kC1 = 16;         // conv1 output size / channels
 constexpr int kP2 = 25;                   // zero-padded conv1 output (pad 2)
@@ -53,21 +81,24 @@ __global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
   }
   const float bias1 = b1[col], bias20 = b2[col], bias21 = b2[16 + col];
   for (int i = tid; i < kLdsFloats; i += 256) lds[i] = 0.0f;
+  const bool words = (reinterpret_cast<uintptr_t>(obs) & 3) == 0;   // 7056 B per observation: true for all or none
+  Batch<kD * kD, uint32_t> pre;                                      // 4 * 1764 bytes = 1764 words: 7 per thread
+  if (words && (int)blockIdx.x < n_obs) pre.load(reinterpret_cast<const uint32_t*>(obs + (size_t)blockIdx.x * 4 * kD * kD), tid);
   for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
     __syncthreads();  // borders zeroed / the previous observation's conv2 gathers are done
     // ---- obs u8 -> padded float input (x / 255, the division as in the reference) ----
     const uint8_t* src = obs + (size_t)n * 4 * kD * kD;
-    if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {  // wave-uniform: 7056 B per observation
-      const uint32_t* src32 = reinterpret_cast<const uint32_t*>(src);
-      for (int wi = tid; wi < kD * kD; wi += 256) {   // 4 * 1764 bytes = 1764 words
-        const uint32_t v = src32[wi];
+    if (words) {  // wave-uniform
+      pre.each(tid, [&](int wi, uint32_t v) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int i = wi * 4 + j;
           const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
           in_pad[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = (float)((v >> (8 * j)) & 255u) / 255.0f;
         }
-      }
+      });
+      if (n + (int)gridDim.x < n_obs)   // the next observation's bytes are in flight during this one's MFMAs
+        pre.load(reinterpret_cast<const uint32_t*>(obs + (size_t)(n + gridDim.x) * 4 * kD * kD), tid);
     } else {
       for (int i = tid; i < 4 * kD * kD; i += 256) {
         const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
@@ -191,22 +222,28 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
   __syncthreads();
   lut[tid] = (float)tid / 255.0f;
   const int kh = col >> 2, kw = col & 3;   // tap of this lane's k column in (2) and (4)
+  const bool words = (reinterpret_cast<uintptr_t>(obs) & 3) == 0;   // 7056 B per observation: true for all or none
+  Batch<kD * kD, uint32_t> pre_x;                                    // the NEXT observation's inputs (see Batch)
+  Batch<kC2 * kM2, float> pre_a, pre_d;
+  if ((int)blockIdx.x < n_obs) {
+    if (words) pre_x.load(reinterpret_cast<const uint32_t*>(obs + (size_t)blockIdx.x * 4 * kD * kD), tid);
+    pre_a.load(a2 + (size_t)blockIdx.x * kC2 * kM2, tid);
+    pre_d.load(dy + (size_t)blockIdx.x * kC2 * kM2, tid);
+  }
 #pragma unroll 1
   for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
     __syncthreads();
     // ---- obs u8 -> zero-padded u8 tile ----
     const uint8_t* src = obs + (size_t)n * 4 * kD * kD;
-    if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {
-      const uint32_t* src32 = reinterpret_cast<const uint32_t*>(src);
-      for (int wi = tid; wi < kD * kD; wi += 256) {
-        const uint32_t v = src32[wi];
+    if (words) {
+      pre_x.each(tid, [&](int wi, uint32_t v) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int i = wi * 4 + j;
           const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
           in_u8[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = (uint8_t)(v >> (8 * j));
         }
-      }
+      });
     } else {
       for (int i = tid; i < 4 * kD * kD; i += 256) {
         const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
@@ -214,11 +251,19 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
       }
     }
     // ---- dz2 = dY * (a2 > 0) -> zero-padded LDS tile ----
-    const float* a2n = a2 + (size_t)n * kC2 * kM2;
-    const float* dyn = dy + (size_t)n * kC2 * kM2;
-    for (int i = tid; i < kC2 * kM2; i += 256) {
-      const int o = i / kM2, p = i - o * kM2, oy = p / kO2, ox = p - oy * kO2;
-      dz2p[o * kZ2 + oy * kZ2W + ox] = a2n[i] > 0.f ? dyn[i] : 0.f;
+#pragma unroll
+    for (int j = 0; j < pre_a.kPer; ++j) {
+      const int i = tid + 256 * j;
+      if ((j + 1) * 256 <= kC2 * kM2 || i < kC2 * kM2) {
+        const int o = i / kM2, p = i - o * kM2, oy = p / kO2, ox = p - oy * kO2;
+        dz2p[o * kZ2 + oy * kZ2W + ox] = pre_a.v[j] > 0.f ? pre_d.v[j] : 0.f;
+      }
+    }
+    if (n + (int)gridDim.x < n_obs) {
+      const size_t nn = (size_t)n + gridDim.x;
+      if (words) pre_x.load(reinterpret_cast<const uint32_t*>(obs + nn * 4 * kD * kD), tid);
+      pre_a.load(a2 + nn * kC2 * kM2, tid);
+      pre_d.load(dy + nn * kC2 * kM2, tid);
     }
     __syncthreads();
     // ---- (1) conv1 forward into c1_pad (operand values and order of conv12_u8_mfma_kernel) ----
@@ -422,18 +467,19 @@ __global__ __launch_bounds__(256, 2) void conv1_84_u8_mfma_kernel(
   }
   const float bias0 = bias[col], bias1 = bias[16 + col];
   if (tid < kGuard84 / 4) reinterpret_cast<uint32_t*>(tile)[tid] = 0u;
+  Batch<kPlane84, uint32_t> pre;   // 4 * 7056 bytes = 7056 words, 28 per thread: the NEXT observation (see Batch)
+  if ((int)blockIdx.x < n_obs) pre.load(reinterpret_cast<const uint32_t*>(obs + (size_t)blockIdx.x * 4 * kPlane84), tid);
   for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
     __syncthreads();  // the previous observation's gathers are done before the tile is rewritten
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(obs + (size_t)n * 4 * kPlane84);
     uint32_t* dstw = reinterpret_cast<uint32_t*>(tile + kGuard84);
-    for (int wi = tid; wi < kPlane84; wi += 256) {  // 4 * 7056 bytes = 7056 words; 84 % 4 == 0: a word never spans two rows
-      uint32_t v = src[wi];
+    pre.each(tid, [&](int wi, uint32_t v) {  // 84 % 4 == 0: a word never spans two rows
       const int i = wi * 4;
       const int r = i % kPlane84, y = r / kD84, x = r - y * kD84;
       v = (x == kD84 - 4) ? (v & 0x00ffffffu) : v;   // column 83 := 0 (it doubles as column -1 of the next row)
       v = (y == kD84 - 1) ? 0u : v;                  // row 83 := 0 (it doubles as row -1 of the next plane)
       dstw[wi] = v;
-    }
+    });
+    if (n + (int)gridDim.x < n_obs) pre.load(reinterpret_cast<const uint32_t*>(obs + (size_t)(n + gridDim.x) * 4 * kPlane84), tid);
     __syncthreads();
     float* dst = out + (size_t)n * kC84 * kM84;
     for (int mt = wave; mt < kM84 / 16; mt += 4) {
@@ -504,6 +550,16 @@ constexpr int kA1 = 20, kA1P = 24, kA1Plane = kA1P * kA1P;      // conv1 output,
 constexpr int kA2 = 11, kM2b = kA2 * kA2;                        // 121 conv2 outputs
 constexpr int kA3 = 9, kM3 = kA3 * kA3;                          // 81 conv3 outputs
 constexpr int kA1Q = 8;                                           // a1 channels per LDS pass
+// The streamed B operand (one coalesced 256-byte load per wave and k-step, from L2) is loaded kBPf k-steps before
+// the MFMAs that consume it: with the load and its `s_waitcnt vmcnt` in the same iteration (rounds 1-3: two k-steps
+// per iteration) every 16 MFMAs (512 clocks of the matrix pipe) waited out one L2 round trip of about the same
+// length — the ~40 % of the f32 MFMA peak these kernels measured, one wave per SIMD and nobody to hide it.  Same
+// FMAs in the same order: bit-identical.  (16 % kBPf == 0: a conv3 tap never changes inside a group.)
+#ifndef PARLHIP_BPF
+#define PARLHIP_BPF 8
+#endif
+constexpr int kBPf = PARLHIP_BPF;      // the backward kernels (one wave per SIMD by their accumulators anyway)
+constexpr int kBPfFwd = 4;             // conv23_84_mfma_kernel: 128 VGPRs, two of its waves fit beside an emulator wave pair
 constexpr int kLds23Floats = kA1Q * kA1Plane + 64 * kM2b;        // 4,608 + 7,744 = 12,352 floats = 49,408 B
 
 __global__ __launch_bounds__(256) void conv23_84_mfma_kernel(
@@ -547,6 +603,9 @@ __global__ __launch_bounds__(256) void conv23_84_mfma_kernel(
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* wp = wt2 + wave * 64 + lane;            // wt2[ks][nt = wave][lane]
+      float nb[kBPfFwd];                                      // the B operand, kBPfFwd k-steps ahead (see kBPfFwd)
+#pragma unroll
+      for (int j = 0; j < kBPfFwd; ++j) nb[j] = wp[j * 256];
 #pragma unroll 1
       for (int pass = 0; pass < 32 / kA1Q; ++pass) {
         __syncthreads();   // the previous pass (or the previous observation's conv3) is done with the tile
@@ -564,12 +623,23 @@ __global__ __launch_bounds__(256) void conv23_84_mfma_kernel(
 #pragma unroll
           for (int j = 0; j < 4; ++j) { const int i = tid + 256 * j; if (i < kQ4) pre[j] = src[(pass + 1) * kQ4 + i]; }
         }
-#pragma clang loop unroll_count(2)
-        for (int kq = 0; kq < 4 * kA1Q; ++kq) {
-          const float b = wp[(pass * 4 * kA1Q + kq) * 256];
-          const float* ab = a1p + (kq >> 2) * kA1Plane + (kq & 3) * kA1P;   // c = 8 * pass + (kq >> 2), kh = kq & 3
+#pragma unroll 1
+        for (int kq0 = 0; kq0 < 4 * kA1Q; kq0 += kBPfFwd) {
+          float cb[kBPfFwd];
 #pragma unroll
-          for (int mt = 0; mt < 8; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[off2[mt]], b, acc[mt], 0, 0, 0);
+          for (int j = 0; j < kBPfFwd; ++j) cb[j] = nb[j];
+          const int kn = pass * 4 * kA1Q + kq0 + kBPfFwd;
+          if (kn < 128) {
+#pragma unroll
+            for (int j = 0; j < kBPfFwd; ++j) nb[j] = wp[(kn + j) * 256];
+          }
+#pragma unroll
+          for (int j = 0; j < kBPfFwd; ++j) {
+            const int kq = kq0 + j;
+            const float* ab = a1p + (kq >> 2) * kA1Plane + (kq & 3) * kA1P;   // c = 8 * pass + (kq >> 2), kh = kq & 3
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[off2[mt]], cb[j], acc[mt], 0, 0, 0);
+          }
         }
       }
       float* g2 = a2_out ? a2_out + (size_t)n * 64 * kM2b : nullptr;
@@ -593,13 +663,25 @@ __global__ __launch_bounds__(256) void conv23_84_mfma_kernel(
 #pragma unroll
       for (int mt = 0; mt < 6; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* wp = wt3 + wave * 64 + lane;
-#pragma clang loop unroll_count(2)
-      for (int ks = 0; ks < 144; ++ks) {
-        const float b = wp[ks * 256];
-        const int tap = ks >> 4, kh = tap / 3, kw = tap - kh * 3;   // k' = tap*64 + c, c = 4*(ks & 15) + q
-        const float* ab = a2s + (4 * (ks & 15)) * kM2b + kh * kA2 + kw;
+      float nb[kBPfFwd];
 #pragma unroll
-        for (int mt = 0; mt < 6; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[off3[mt]], b, acc[mt], 0, 0, 0);
+      for (int j = 0; j < kBPfFwd; ++j) nb[j] = wp[j * 256];
+#pragma unroll 1
+      for (int ks0 = 0; ks0 < 144; ks0 += kBPfFwd) {
+        float cb[kBPfFwd];
+#pragma unroll
+        for (int j = 0; j < kBPfFwd; ++j) cb[j] = nb[j];
+        if (ks0 + kBPfFwd < 144) {
+#pragma unroll
+          for (int j = 0; j < kBPfFwd; ++j) nb[j] = wp[(ks0 + kBPfFwd + j) * 256];
+        }
+        const int tap = ks0 >> 4, kh = tap / 3, kw = tap - kh * 3;   // k' = tap*64 + c, c = 4*(ks & 15) + q  (16 % kBPfFwd == 0)
+#pragma unroll
+        for (int j = 0; j < kBPfFwd; ++j) {
+          const float* ab = a2s + (4 * ((ks0 + j) & 15)) * kM2b + kh * kA2 + kw;
+#pragma unroll
+          for (int mt = 0; mt < 6; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[off3[mt]], cb[j], acc[mt], 0, 0, 0);
+        }
       }
       float* g3 = a3_out + (size_t)n * 64 * kM3;
 #pragma unroll
@@ -668,16 +750,30 @@ __global__ __launch_bounds__(256) void conv3_84_bwd_kernel(
     const int y = m / kA2, x = m - y * kA2;
     aoff[mt] = (y + 2) * kZ3P + (x + 2) + q * kZ3Plane;    // + o = 4 (ks & 15) + q, - kh * 13 - kw per k-step
   }
+  Batch<64 * kM2b / 4, float4> pre_a2;      // 7,744 floats per observation (a 16-byte multiple): the NEXT observation (see Batch)
+  Batch<64 * kM3, float> pre_a3, pre_dy;
+  if ((int)blockIdx.x < n_obs) {
+    pre_a2.load(reinterpret_cast<const float4*>(a2 + (size_t)blockIdx.x * 64 * kM2b), tid);
+    pre_a3.load(a3 + (size_t)blockIdx.x * 64 * kM3, tid);
+    pre_dy.load(dy3 + (size_t)blockIdx.x * 64 * kM3, tid);
+  }
 #pragma unroll 1
   for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
     __syncthreads();
-    const float4* s2 = reinterpret_cast<const float4*>(a2 + (size_t)n * 64 * kM2b);   // 7,744 floats: 16-byte multiple
-    for (int i = tid; i < 64 * kM2b / 4; i += 256) reinterpret_cast<float4*>(a2s)[i] = s2[i];
-    const float* a3n = a3 + (size_t)n * 64 * kM3;
-    const float* dyn = dy3 + (size_t)n * 64 * kM3;
-    for (int i = tid; i < 64 * kM3; i += 256) {
-      const int o = i / kM3, p = i - o * kM3, y = p / kA3, x = p - y * kA3;
-      z3p[o * kZ3Plane + (y + 2) * kZ3P + (x + 2)] = a3n[i] > 0.f ? dyn[i] : 0.f;
+    pre_a2.each(tid, [&](int i, float4 v) { reinterpret_cast<float4*>(a2s)[i] = v; });
+#pragma unroll
+    for (int j = 0; j < pre_a3.kPer; ++j) {
+      const int i = tid + 256 * j;
+      if ((j + 1) * 256 <= 64 * kM3 || i < 64 * kM3) {
+        const int o = i / kM3, p = i - o * kM3, y = p / kA3, x = p - y * kA3;
+        z3p[o * kZ3Plane + (y + 2) * kZ3P + (x + 2)] = pre_a3.v[j] > 0.f ? pre_dy.v[j] : 0.f;
+      }
+    }
+    if (n + (int)gridDim.x < n_obs) {
+      const size_t nn = (size_t)n + gridDim.x;
+      pre_a2.load(reinterpret_cast<const float4*>(a2 + nn * 64 * kM2b), tid);
+      pre_a3.load(a3 + nn * 64 * kM3, tid);
+      pre_dy.load(dy3 + nn * 64 * kM3, tid);
     }
     __syncthreads();
     // ---- (A) dW3 ----
@@ -712,13 +808,25 @@ __global__ __launch_bounds__(256) void conv3_84_bwd_kernel(
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* wp = wt3b + wave * 64 + lane;
-#pragma clang loop unroll_count(2)
-      for (int ks = 0; ks < 144; ++ks) {
-        const float b = wp[ks * 256];
-        const int tap = ks >> 4, kh = tap / 3, kw = tap - kh * 3;
-        const float* ab = z3p + (4 * (ks & 15)) * kZ3Plane - kh * kZ3P - kw;
+      float nb[kBPf];
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[aoff[mt]], b, acc[mt], 0, 0, 0);
+      for (int j = 0; j < kBPf; ++j) nb[j] = wp[j * 256];
+#pragma unroll 1
+      for (int ks0 = 0; ks0 < 144; ks0 += kBPf) {
+        float cb[kBPf];
+#pragma unroll
+        for (int j = 0; j < kBPf; ++j) cb[j] = nb[j];
+        if (ks0 + kBPf < 144) {
+#pragma unroll
+          for (int j = 0; j < kBPf; ++j) nb[j] = wp[(ks0 + kBPf + j) * 256];
+        }
+        const int tap = ks0 >> 4, kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+        for (int j = 0; j < kBPf; ++j) {
+          const float* ab = z3p + (4 * ((ks0 + j) & 15)) * kZ3Plane - kh * kZ3P - kw;
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[aoff[mt]], cb[j], acc[mt], 0, 0, 0);
+        }
       }
       float* g = dz2 + (size_t)n * 64 * kM2b;
 #pragma unroll
@@ -793,16 +901,19 @@ __global__ __launch_bounds__(256) void conv2_84_bwd_kernel(
   }
 #pragma unroll 1
   for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
-    __syncthreads();
-    const float4* src = reinterpret_cast<const float4*>(a1 + (size_t)n * 32 * kA1 * kA1);
-    for (int i = tid; i < 32 * kA1 * kA1 / 4; i += 256) {
-      const float4 v = src[i];
-      const int e = i * 4, c = e / (kA1 * kA1), r = e - c * kA1 * kA1, y = r / kA1, x = r - y * kA1;
-      float* d = a1p + c * kA1Plane + (y + 2) * kA1P + (x + 2);
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    {  // (no room in the register file to hold the NEXT observation across the MFMA phases: batches of this one)
+      Batch<32 * kA1 * kA1 / 4, float4> ba;
+      Batch<64 * kM2b / 4, float4> bz;
+      ba.load(reinterpret_cast<const float4*>(a1 + (size_t)n * 32 * kA1 * kA1), tid);
+      bz.load(reinterpret_cast<const float4*>(dz2 + (size_t)n * 64 * kM2b), tid);
+      __syncthreads();   // the loads are in flight while the other waves finish the previous observation
+      ba.each(tid, [&](int i, float4 v) {
+        const int e = i * 4, c = e / (kA1 * kA1), r = e - c * kA1 * kA1, y = r / kA1, x = r - y * kA1;   // 20 % 4 == 0
+        float* d = a1p + c * kA1Plane + (y + 2) * kA1P + (x + 2);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      });
+      bz.each(tid, [&](int i, float4 v) { reinterpret_cast<float4*>(z2s)[i] = v; });
     }
-    const float4* sz = reinterpret_cast<const float4*>(dz2 + (size_t)n * 64 * kM2b);
-    for (int i = tid; i < 64 * kM2b / 4; i += 256) reinterpret_cast<float4*>(z2s)[i] = sz[i];
     __syncthreads();
     // ---- (A) dW2 ----
     {
@@ -837,15 +948,27 @@ __global__ __launch_bounds__(256) void conv2_84_bwd_kernel(
 #pragma unroll
       for (int mt = 0; mt < 7; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       const float* wp = wt2b + (size_t)wave * 64 * 2 * 64 + lane;   // wt2b[class][ks][nt][lane]
-#pragma clang loop unroll_count(2)
-      for (int o = 0; o < 64; ++o) {
-        const float b0 = wp[(o * 2 + 0) * 64], b1v = wp[(o * 2 + 1) * 64];
-        const float* ab = z2s + o * kM2b;
+      float nb[kBPf];
 #pragma unroll
-        for (int mt = 0; mt < 7; ++mt) {
-          const float a = ab[aoff[mt]];
-          acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[mt][0], 0, 0, 0);
-          acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1v, acc[mt][1], 0, 0, 0);
+      for (int j = 0; j < kBPf; ++j) nb[j] = wp[j * 64];
+#pragma unroll 1
+      for (int o0 = 0; o0 < 64; o0 += kBPf / 2) {
+        float cb[kBPf];
+#pragma unroll
+        for (int j = 0; j < kBPf; ++j) cb[j] = nb[j];
+        if (o0 + kBPf / 2 < 64) {
+#pragma unroll
+          for (int j = 0; j < kBPf; ++j) nb[j] = wp[((o0 + kBPf / 2) * 2 + j) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < kBPf / 2; ++j) {
+          const float* ab = z2s + (o0 + j) * kM2b;
+#pragma unroll
+          for (int mt = 0; mt < 7; ++mt) {
+            const float a = ab[aoff[mt]];
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, cb[2 * j], acc[mt][0], 0, 0, 0);
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, cb[2 * j + 1], acc[mt][1], 0, 0, 0);
+          }
         }
       }
       float* g = dz1 + (size_t)n * 32 * kA1 * kA1;
@@ -919,12 +1042,16 @@ __global__ __launch_bounds__(256) void conv1_84_bwd_kernel(
     const int nt = wave + 4 * j;
     boff[j] = (nt >> 2) * kPlane84 + (2 * (nt & 3) + (col >> 3)) * kD84 + (col & 7);
   }
+  Batch<kPlane84, uint32_t> pre_x;           // the NEXT observation's bytes and dz1 (see Batch)
+  Batch<32 * kM84 / 4, float4> pre_z;
+  if ((int)blockIdx.x < n_obs) {
+    pre_x.load(reinterpret_cast<const uint32_t*>(obs + (size_t)blockIdx.x * 4 * kPlane84), tid);
+    pre_z.load(reinterpret_cast<const float4*>(dz1 + (size_t)blockIdx.x * 32 * kM84), tid);
+  }
 #pragma unroll 1
   for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
     __syncthreads();
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(obs + (size_t)n * 4 * kPlane84);
-    for (int wi = tid; wi < kPlane84; wi += 256) {
-      const uint32_t v = src[wi];
+    pre_x.each(tid, [&](int wi, uint32_t v) {
       const int i = wi * 4;
       const int c = i / kPlane84, r = i - c * kPlane84, y = r / kD84, x = r - y * kD84;
       if (y < kD84 - 1) {
@@ -932,26 +1059,49 @@ __global__ __launch_bounds__(256) void conv1_84_bwd_kernel(
         d[0] = (uint8_t)v; d[1] = (uint8_t)(v >> 8); d[2] = (uint8_t)(v >> 16);
         if (x + 4 < kD84) d[3] = (uint8_t)(v >> 24);
       }
+    });
+    pre_z.each(tid, [&](int i, float4 v) { reinterpret_cast<float4*>(z1s)[i] = v; });
+    if (n + (int)gridDim.x < n_obs) {
+      const size_t nn = (size_t)n + gridDim.x;
+      pre_x.load(reinterpret_cast<const uint32_t*>(obs + nn * 4 * kPlane84), tid);
+      pre_z.load(reinterpret_cast<const float4*>(dz1 + nn * 32 * kM84), tid);
     }
-    const float4* sz = reinterpret_cast<const float4*>(dz1 + (size_t)n * 32 * kM84);
-    for (int i = tid; i < 32 * kM84 / 4; i += 256) reinterpret_cast<float4*>(z1s)[i] = sz[i];
     __syncthreads();
+    // The operands of k-step ks + 1 are read from LDS BEFORE the MFMAs of k-step ks are issued (round 4; rounds 1-3
+    // read a byte, then the table entry it selects, then issued the eight MFMAs that wait for both: two LDS round
+    // trips per 256 clocks of the matrix pipe, 25 % of the f32 peak), and the byte becomes (float)u / 255.0f in
+    // registers (byte_over_255: bit-identical to the division for all 256 bytes) instead of through the table.
     int ox = q, poff = q * 4;                               // p = 4 ks + q: (oy, ox) = (0, q); tile offset (4 oy) * 84 + 4 ox
+    const float* za = z1s + col * kM84 + q;
+    float a0 = za[0], a1v = za[16 * kM84];
+    uint32_t ub[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ub[j] = tile[boff[j] + poff];
 #pragma clang loop unroll(disable)
     for (int ks = 0; ks < 100; ++ks) {
-      const float a0 = z1s[col * kM84 + ks * 4 + q], a1v = z1s[(16 + col) * kM84 + ks * 4 + q];
-      dba[0] += a0;
-      dba[1] += a1v;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float b = lut[tile[boff[j] + poff]];
-        accw[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, accw[0][j], 0, 0, 0);
-        accw[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, b, accw[1][j], 0, 0, 0);
-      }
       ox += 4;
       const bool wrap = ox >= kO84;
       ox -= wrap ? kO84 : 0;
       poff += wrap ? 16 + (4 * kD84 - 4 * kO84) : 16;       // four rows down, 80 columns back
+      const bool more = ks < 99;
+      const int zn = more ? (ks + 1) * 4 : 0, pn = more ? poff : 0;   // (the last step re-reads valid addresses)
+      const float na0 = za[zn], na1 = za[16 * kM84 + zn];
+      uint32_t nb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) nb[j] = tile[boff[j] + pn];
+      __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the reads of a0 / a1v to their use in the next iteration)
+      dba[0] += a0;
+      dba[1] += a1v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float b = byte_over_255(ub[j]);
+        accw[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, accw[0][j], 0, 0, 0);
+        accw[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, b, accw[1][j], 0, 0, 0);
+      }
+      a0 = na0;
+      a1v = na1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ub[j] = nb[j];
     }
   }
   float* P = partial + (size_t)blockIdx.x * kPart1;
