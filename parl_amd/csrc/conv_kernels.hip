@@ -20,6 +20,20 @@ namespace parlhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef PARLHIP_CONV_REGIONS  // diagnostic build only (tools/conv_regions.py): s_memtime clocks per phase, summed over
+__device__ unsigned long long g_conv_regions[16];   // the workgroups' wave 0; [15] = observations
+#define CONV_REGION(i)                                                                       \
+  do {                                                                                       \
+    const unsigned long long t_ = __builtin_readcyclecounter();                              \
+    if (threadIdx.x == 0) atomicAdd(&g_conv_regions[i], t_ - creg_t);                         \
+    creg_t = t_;                                                                             \
+  } while (0)
+#define CONV_REGION_BEGIN() unsigned long long creg_t = __builtin_readcyclecounter()
+#else
+#define CONV_REGION(i) do {} while (0)
+#define CONV_REGION_BEGIN() do {} while (0)
+#endif
+
 // Fill phases (round 4).  Every kernel here copies its observation's inputs from HBM into LDS before its MFMA
 // phases.  Written as `for (i = tid; i < N; i += 256) lds[f(i)] = g(src[i])` the compiler kept ONE load in flight per
 // iteration (`global_load; s_waitcnt vmcnt(0); ds_write` in the ISA of rounds 1-3): N / 256 HBM round trips per
@@ -47,6 +61,13 @@ struct Batch {
     }
   }
 };
+
+// (float)u / 255.0f without the division: one Newton step makes the product correctly rounded for u = 0 .. 255
+__device__ __forceinline__ float byte_over_255(uint32_t u) {
+  const float x = (float)u, r = 1.0f / 255.0f;
+  const float q = x * r;
+  return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), r, q);
+}
 
 constexpr int kD = 42, kP1 = 44;          // input, zero-padded input (pad 1, +1 slack column/row)
 constexpr int kO1 = 21, kC1 = 16;         // conv1 output size / channels
@@ -230,9 +251,11 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
     pre_a.load(a2 + (size_t)blockIdx.x * kC2 * kM2, tid);
     pre_d.load(dy + (size_t)blockIdx.x * kC2 * kM2, tid);
   }
+  CONV_REGION_BEGIN();
 #pragma unroll 1
   for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
     __syncthreads();
+    CONV_REGION(0);   // waiting for the other waves (end of the previous observation)
     // ---- obs u8 -> zero-padded u8 tile ----
     const uint8_t* src = obs + (size_t)n * 4 * kD * kD;
     if (words) {
@@ -266,6 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
       pre_d.load(dy + nn * kC2 * kM2, tid);
     }
     __syncthreads();
+    CONV_REGION(1);   // fill
     // ---- (1) conv1 forward into c1_pad (operand values and order of conv12_u8_mfma_kernel) ----
 #pragma unroll 1
     for (int t = wave; t < 28; t += 4) {
@@ -290,6 +314,7 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
       }
     }
     __syncthreads();
+    CONV_REGION(2);   // (1) conv1 recompute
     // ---- (2) dW2: this wave owns input channels 4*wave .. 4*wave+3 (k tiles), both o tiles ----
     // position p = 4*ps + q walks the 11 x 11 outputs; offsets advance incrementally (no divides).
     // The loop stays ROLLED: unrolled (even by 2) the scheduler hoists the LDS gathers of all
@@ -319,6 +344,7 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
       }
     }
     __syncthreads();   // all patch2 gathers done before dz1 overwrites a1
+    CONV_REGION(3);   // (2) dW2
     // ---- (3) dz1 for this wave's parity class, in place over a1 ----
     {
       const int ny = kO2 - py, nx = kO2 - px, M = ny * nx;   // y = 2*iy + py < 21, x = 2*ix + px < 21
@@ -345,26 +371,53 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
       }
     }
     __syncthreads();
+    CONV_REGION(4);   // (3) dz1 (incl. its barrier)
     // ---- (4) dW1: this wave owns input channel `wave` (16 taps = one k tile) ----
     {
+      // One accumulator, 111 dependent MFMAs: what the loop has to hide is the LDS latency of its operands.  Rounds
+      // 1-3 read a1, a byte and the table entry the byte selects right in front of EVERY MFMA (two LDS round trips
+      // per 32 clocks of matrix work: ~13 us per observation, a third of the kernel).  Now the operands of the
+      // next kG4 positions are read before the MFMAs of the current kG4 are issued, and the byte becomes
+      // (float)u / 255.0f in registers (byte_over_255: the table's values bit for bit).  Same FMAs, same order.
+      constexpr int kG4 = 4;
       int x = q;                                              // y = 0
       int aoff = col * kP2 * kP2 + 2 * kP2 + 2 + q;           // c1_pad[col][y + 2][x + 2]
       int boff = wave * kP1 * kP1 + kh * kP1 + 2 * q + kw;    // in_u8[wave][2*y + kh][2*x + kw]
+      int ps_rd = 0;                                          // the next position group to READ
+      float ca[kG4], na[kG4];
+      uint32_t cb[kG4], nb[kG4];
+      auto read_group = [&](float (&a)[kG4], uint32_t (&b)[kG4]) {
+#pragma unroll
+        for (int g = 0; g < kG4; ++g) {
+          const bool valid = ((ps_rd < 110) | (q == 0)) & (ps_rd < 111);   // p < 441 (groups past the end read the borders)
+          a[g] = c1_pad[valid ? aoff : col * kP2 * kP2];      // [col][0][0] is border: 0
+          b[g] = in_u8[valid ? boff : 0];                     // [0][0][0] is padding: 0
+          ++ps_rd;
+          x += 4;
+          const bool wrap = x >= kO1;
+          x -= wrap ? kO1 : 0;
+          aoff += wrap ? 4 + (kP2 - kO1) : 4;
+          boff += wrap ? 8 + (2 * kP1 - 2 * kO1) : 8;
+        }
+      };
+      read_group(ca, cb);
 #pragma clang loop unroll(disable)
-      for (int ps = 0; ps < 111; ++ps) {
-        const bool valid = (ps < 110) | (q == 0);             // p < 441
-        const float a = c1_pad[valid ? aoff : col * kP2 * kP2];   // [col][0][0] is border: 0
-        const float b = lut[in_u8[valid ? boff : 0]];
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc1, 0, 0, 0);
-        x += 4;
-        const bool wrap = x >= kO1;
-        x -= wrap ? kO1 : 0;
-        aoff += wrap ? 4 + (kP2 - kO1) : 4;
-        boff += wrap ? 8 + (2 * kP1 - 2 * kO1) : 8;
+      for (int ps0 = 0; ps0 < 111; ps0 += kG4) {
+        read_group(na, nb);
+        asm volatile("" ::: "memory");   // the reads above stay above: the scheduler otherwise sinks them to their use
+#pragma unroll
+        for (int g = 0; g < kG4; ++g)
+          if (ps0 + g < 111) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[g], byte_over_255(cb[g]), acc1, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < kG4; ++g) { ca[g] = na[g]; cb[g] = nb[g]; }
       }
     }
+    CONV_REGION(5);   // (4) dW1
   }
   // ---- this workgroup's partial sums ----
+#ifdef PARLHIP_CONV_REGIONS
+  if (threadIdx.x == 0) atomicAdd(&g_conv_regions[15], (unsigned long long)((n_obs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x));
+#endif
   float* P = partial + (size_t)blockIdx.x * kBwdPartial;
 #pragma unroll
   for (int r = 0; r < 4; ++r) P[kBwdDW1 + (4 * q + r) * kK1 + 16 * wave + col] = acc1[r];
@@ -443,13 +496,6 @@ constexpr int kK84 = 4 * 8 * 8;          // 256
 constexpr int kPlane84 = kD84 * kD84;    // 7056
 constexpr int kGuard84 = 88;                                     // zero bytes in front of plane 0 (>= 85, 4-byte multiple)
 constexpr int kLds84u8Bytes = kGuard84 + 4 * kPlane84 + 8;       // 28,320
-
-// (float)u / 255.0f without the division: one Newton step makes the product correctly rounded for u = 0 .. 255
-__device__ __forceinline__ float byte_over_255(uint32_t u) {
-  const float x = (float)u, r = 1.0f / 255.0f;
-  const float q = x * r;
-  return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), r, q);
-}
 
 __global__ __launch_bounds__(256, 2) void conv1_84_u8_mfma_kernel(
     const uint8_t* __restrict__ obs, const float* __restrict__ w, const float* __restrict__ bias,
@@ -1017,7 +1063,7 @@ __global__ __launch_bounds__(256) void conv2_84_bwd_kernel(
 constexpr int kLds1bFloats = (4 * kPlane84) / 4 + 256 + 32 * kM84 + 64;   // 7,056 + 256 + 12,800 + 64 floats = 80,704 B
 constexpr int kPart1 = 32 * 256 + 32;
 
-__global__ __launch_bounds__(256) void conv1_84_bwd_kernel(
+__global__ __launch_bounds__(256, 2) void conv1_84_bwd_kernel(
     const uint8_t* __restrict__ obs, const float* __restrict__ dz1, float* __restrict__ partial, int n_obs) {
   extern __shared__ float lds[];
   uint8_t* tile = reinterpret_cast<uint8_t*>(lds);        // [4][84][84] uint8, shifted by the padding
@@ -1288,8 +1334,12 @@ PARLHIP_EXPORT int parlhip_atari84_conv2_bwd_f32(const float* a1, const float* d
   return check_launch();
 }
 
+// conv1_84_bwd_kernel: 80.7 KB of LDS and <= 256 VGPRs — two workgroups per CU, each one's fill and store phases under
+// the other's MFMAs (conv3 / conv2: 276+ VGPRs of accumulators, one wave per SIMD whatever the grid)
+static int bwd84_conv1_grid(int n_obs) { return n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU; }
+
 PARLHIP_EXPORT size_t parlhip_atari84_conv1_bwd_workspace_bytes(int n_obs) {
-  return n_obs <= 0 ? 0 : (size_t)bwd84_grid(n_obs) * kPart1 * sizeof(float);
+  return n_obs <= 0 ? 0 : (size_t)bwd84_conv1_grid(n_obs) * kPart1 * sizeof(float);
 }
 
 PARLHIP_EXPORT int parlhip_atari84_conv1_bwd_f32(const uint8_t* obs, const float* dz1, int n_obs, float* workspace,
@@ -1306,10 +1356,21 @@ PARLHIP_EXPORT int parlhip_atari84_conv1_bwd_f32(const uint8_t* obs, const float
     if (rc) return rc;
     attr_set = true;
   }
-  const int grid = bwd84_grid(n_obs);
+  const int grid = bwd84_conv1_grid(n_obs);
   conv1_84_bwd_kernel<<<grid, 256, lds_bytes, s>>>(obs, dz1, workspace, n_obs);
   int rc = check_launch();
   if (rc) return rc;
   partial_sum_kernel<<<(kPart1 + 15) / 16, 256, 0, s>>>(workspace, grid, kPart1, dw1_db1);
   return check_launch();
 }
+
+#ifdef PARLHIP_CONV_REGIONS
+PARLHIP_EXPORT int parlhip_debug_conv_regions(unsigned long long* host, int reset) {
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(parlhip::g_conv_regions), 128) != hipSuccess) return PARLHIP_EINVAL;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(parlhip::g_conv_regions), z, 128) != hipSuccess) return PARLHIP_EINVAL;
+  }
+  return PARLHIP_OK;
+}
+#endif
