@@ -34,6 +34,10 @@ __device__ unsigned long long g_conv_regions[16];   // the workgroups' wave 0; [
 #define CONV_REGION_BEGIN() do {} while (0)
 #endif
 
+// The LDS reads above this line are ISSUED above it (the compiler may not move memory operations across): with the
+// register file nearly full the scheduler otherwise places every read right in front of the MFMA that waits for it.
+#define LDS_FENCE() asm volatile("" ::: "memory")
+
 // Fill phases (round 4).  Every kernel here copies its observation's inputs from HBM into LDS before its MFMA
 // phases.  Written as `for (i = tid; i < N; i += 256) lds[f(i)] = g(src[i])` the compiler kept ONE load in flight per
 // iteration (`global_load; s_waitcnt vmcnt(0); ds_write` in the ISA of rounds 1-3): N / 256 HBM round trips per
@@ -73,7 +77,7 @@ constexpr int kD = 42, kP1 = 44;          // input, zero-padded input (pad 1, +1
 constexpr int kO1 = 21, kC1 = 16;         // conv1 output size / channels
 constexpr int kP2 = 25;                   // zero-padded conv1 output (pad 2)
 constexpr int kO2 = 11, kC2 = 32;         // conv2 output size / channels
-constexpr int kM1 = kO1 * kO1, kM2 = kO2 * kO2;
+constexpr int kM2 = kO2 * kO2;
 constexpr int kK1 = 64, kK2 = 256;
 constexpr int kLdsIn = 4 * kP1 * kP1;     // 7744 floats
 constexpr int kLdsC1 = kC1 * kP2 * kP2;   // 10000
@@ -101,6 +105,9 @@ __global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
     bw2[ks][1] = w2[(16 + col) * kK2 + ks * 4 + q];
   }
   const float bias1 = b1[col], bias20 = b2[col], bias21 = b2[16 + col];
+  // conv1: position m = 16 wave + col (gathers) and 16 wave + 4 q (first D row) of this wave's first tile
+  const int oy1 = (16 * wave + col) / kO1, ox1 = (16 * wave + col) - oy1 * kO1;
+  const int ey1 = (16 * wave + 4 * q) / kO1, ex1 = (16 * wave + 4 * q) - ey1 * kO1;
   for (int i = tid; i < kLdsFloats; i += 256) lds[i] = 0.0f;
   const bool words = (reinterpret_cast<uintptr_t>(obs) & 3) == 0;   // 7056 B per observation: true for all or none
   Batch<kD * kD, uint32_t> pre;                                      // 4 * 1764 bytes = 1764 words: 7 per thread
@@ -128,25 +135,37 @@ __global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
     }
     __syncthreads();
     // ---- conv1: 28 M-tiles of 16 positions, 7 per wave ----
-    for (int t = wave; t < 28; t += 4) {
-      int m = t * 16 + col;
-      m = m < kM1 ? m : kM1 - 1;
-      const int oy = m / kO1, ox = m - oy * kO1;
-      const float* a_base = in_pad + (2 * oy) * kP1 + 2 * ox + q;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // Positions advance incrementally (a tile is 64 positions further = 3 rows + 1 column of 21; rounds 1-3 divided
+    // by 21 five times per tile), and a tile's 16 operands are all read before its MFMAs (sched_group_barrier:
+    // left alone the scheduler reads one pair ahead, 64 clocks of cover for an LDS round trip of ~130).
+    {
+      int oy = oy1, ox = ox1, ey = ey1, ex = ex1;
+#pragma unroll 1
+      for (int t = wave; t < 28; t += 4) {
+        const bool in = oy < kO1;                             // m < 441 (the last tile: clamp to the last position)
+        const float* a_base = in_pad + (2 * (in ? oy : kO1 - 1)) * kP1 + 2 * (in ? ox : kO1 - 1) + q;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const float a = a_base[(ks >> 2) * kP1 * kP1 + (ks & 3) * kP1];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw1[ks], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int mo = t * 16 + q * 4 + r;  // D row
-        if (mo < kM1) {
-          const int y = mo / kO1, x = mo - y * kO1;
-          const float v = acc[r] + bias1;
-          c1_pad[col * kP2 * kP2 + (y + 2) * kP2 + (x + 2)] = v > 0.f ? v : 0.f;
+        for (int ks = 0; ks < 16; ++ks) {
+          const float a = a_base[(ks >> 2) * kP1 * kP1 + (ks & 3) * kP1];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw1[ks], acc, 0, 0, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    // (ds_read2: two operands per instruction)
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        float* crow = c1_pad + col * kP2 * kP2 + (ey + 2) * kP2 + (ex + 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                         // rows 4q + r of D: positions (ey, ex + r), wrapping into the next row
+          const bool w = ex + r >= kO1;
+          const int yy = ey + (w ? 1 : 0);
+          if (yy < kO1) {
+            const float v = acc[r] + bias1;
+            crow[r + (w ? kP2 - kO1 : 0)] = v > 0.f ? v : 0.f;
+          }
+        }
+        oy += 3; ox += 1;                                     // 64 positions further
+        if (ox >= kO1) { ox -= kO1; oy += 1; }
+        ey += 3; ex += 1;
+        if (ex >= kO1) { ex -= kO1; ey += 1; }
       }
     }
     __syncthreads();
@@ -164,6 +183,15 @@ __global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw2[ks][0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw2[ks][1], acc1, 0, 0, 0);
       }
+      // the order of the block for the scheduler (ds_read2: two operands per instruction): 8 operands, then seven times
+      // [the next 8 | the 16 MFMAs of the 8 before them], then the last 16 MFMAs — 16 operand registers in flight
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int g = 0; g < 7; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
       // D: column = channel, rows 4q..4q+3 = 4 consecutive positions of the [32][121] row
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -243,6 +271,11 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
   __syncthreads();
   lut[tid] = (float)tid / 255.0f;
   const int kh = col >> 2, kw = col & 3;   // tap of this lane's k column in (2) and (4)
+  // (1): position m = 16 wave + col (gathers) and 16 wave + 4 q (first D row) of this wave's first tile; (3): m = col, 4 q
+  const int oy1 = (16 * wave + col) / kO1, ox1 = (16 * wave + col) - oy1 * kO1;
+  const int ey1 = (16 * wave + 4 * q) / kO1, ex1 = (16 * wave + 4 * q) - ey1 * kO1;
+  const int iy3 = col / (kO2 - px), ix3 = col - iy3 * (kO2 - px);
+  const int jy3 = (4 * q) / (kO2 - px), jx3 = 4 * q - jy3 * (kO2 - px);
   const bool words = (reinterpret_cast<uintptr_t>(obs) & 3) == 0;   // 7056 B per observation: true for all or none
   Batch<kD * kD, uint32_t> pre_x;                                    // the NEXT observation's inputs (see Batch)
   Batch<kC2 * kM2, float> pre_a, pre_d;
@@ -291,56 +324,77 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
     __syncthreads();
     CONV_REGION(1);   // fill
     // ---- (1) conv1 forward into c1_pad (operand values and order of conv12_u8_mfma_kernel) ----
+    // Round 4: the phases below spent 3/4 of their time on index arithmetic, not on MFMAs (per-phase clocks of
+    // tools/conv_regions.py: 94 k clocks per observation for 23 k clocks of matrix work per wave) — divisions by 21 /
+    // 11 / a run-time nx per tile and per output row, a wrap test per position.  Positions now advance
+    // incrementally ((1), (3): a tile is 64 positions further = 3 rows + 1 column of 21), and the two weight-gradient
+    // loops walk ROWS padded to a multiple of 4 positions ((2): 11 -> 12, (4): 21 -> 24): the padding positions read
+    // the zero borders of the dz tiles (A = 0) and any finite B, so they add exact zeros, and every LDS offset
+    // inside a row is an immediate.
+    {
+      int oy = oy1, ox = ox1, ey = ey1, ex = ex1;             // tile t = wave: gather position / first output row of this lane
 #pragma unroll 1
-    for (int t = wave; t < 28; t += 4) {
-      int m = t * 16 + col;
-      m = m < kM1 ? m : kM1 - 1;
-      const int oy = m / kO1, ox = m - oy * kO1;
-      const uint8_t* a_base = in_u8 + (2 * oy) * kP1 + 2 * ox + q;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int t = wave; t < 28; t += 4) {
+        const bool in = oy < kO1;                             // m < 441 (the last tile: clamp to the last position)
+        const uint8_t* a_base = in_u8 + (2 * (in ? oy : kO1 - 1)) * kP1 + 2 * (in ? ox : kO1 - 1) + q;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // all 16 bytes, then all 16 table entries, then the MFMAs (LDS_FENCE: with the register file nearly full
+        // the scheduler otherwise issues each read right in front of the MFMA that waits for it)
+        uint32_t ub[16];
+        float av[16];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const float a = lut[a_base[(ks >> 2) * kP1 * kP1 + (ks & 3) * kP1]];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw1[ks], acc, 0, 0, 0);
-      }
+        for (int ks = 0; ks < 16; ++ks) ub[ks] = a_base[(ks >> 2) * kP1 * kP1 + (ks & 3) * kP1];
+        LDS_FENCE();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int mo = t * 16 + q * 4 + r;
-        if (mo < kM1) {
-          const int y = mo / kO1, x = mo - y * kO1;
-          const float v = acc[r] + bias1;
-          c1_pad[col * kP2 * kP2 + (y + 2) * kP2 + (x + 2)] = v > 0.f ? v : 0.f;
+        for (int ks = 0; ks < 16; ++ks) av[ks] = lut[ub[ks]];
+        LDS_FENCE();
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bw1[ks], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // the order of the block for the scheduler: byte reads,
+        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // table reads,
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // MFMAs
+        float* crow = c1_pad + col * kP2 * kP2 + (ey + 2) * kP2 + (ex + 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                         // rows 4q + r of D: positions (ey, ex + r), wrapping into the next row
+          const bool w = ex + r >= kO1;
+          const int yy = ey + (w ? 1 : 0);
+          if (yy < kO1) {
+            const float v = acc[r] + bias1;
+            crow[r + (w ? kP2 - kO1 : 0)] = v > 0.f ? v : 0.f;
+          }
         }
+        oy += 3; ox += 1;                                     // 64 positions further
+        if (ox >= kO1) { ox -= kO1; oy += 1; }
+        ey += 3; ex += 1;
+        if (ex >= kO1) { ex -= kO1; ey += 1; }
       }
     }
     __syncthreads();
     CONV_REGION(2);   // (1) conv1 recompute
     // ---- (2) dW2: this wave owns input channels 4*wave .. 4*wave+3 (k tiles), both o tiles ----
-    // position p = 4*ps + q walks the 11 x 11 outputs; offsets advance incrementally (no divides).
-    // The loop stays ROLLED: unrolled (even by 2) the scheduler hoists the LDS gathers of all
-    // iterations, needs > 256 VGPRs + scratch and the kernel runs 8.0 instead of 5.4 ms.
+    // 11 rows of 12 positions (ox = 11: dz2p column 11 is zero), three k-steps per row with immediate offsets.
+    // The loop over rows stays ROLLED (unrolled the scheduler hoists the LDS gathers of all iterations: > 256 VGPRs).
     {
-      int ox = q, zoff = q;                                   // oy = 0
-      int boff = (4 * wave) * kP2 * kP2 + kh * kP2 + 2 * q + kw;   // c1_pad[(4w)][2*oy + kh][2*ox + kw]
+      const float* za = dz2p + col * kZ2 + q;                 // dz2p[col][oy][4 xs + q]
+      const float* bb = c1_pad + (4 * wave) * kP2 * kP2 + kh * kP2 + 2 * q + kw;   // c1_pad[4w + j][2 oy + kh][2 (4 xs + q) + kw]
 #pragma clang loop unroll(disable)
-      for (int ps = 0; ps < 31; ++ps) {
-        const bool valid = (ps < 30) | (q == 0);              // p < 121
-        const int zo = valid ? zoff : 11 * kZ2W;              // row 11 of the padded tile is zero
-        const float a0 = dz2p[col * kZ2 + zo], a1v = dz2p[(16 + col) * kZ2 + zo];
-        db2a0 += a0;
-        db2a1 += a1v;
-        const float* bb = c1_pad + (valid ? boff : 0);
+      for (int oy = 0; oy < kO2; ++oy) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float b = bb[j * kP2 * kP2];
-          acc2[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc2[0][j], 0, 0, 0);
-          acc2[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, b, acc2[1][j], 0, 0, 0);
+        for (int xs = 0; xs < 3; ++xs) {
+          const float a0 = za[4 * xs], a1v = za[16 * kZ2 + 4 * xs];
+          db2a0 += a0;
+          db2a1 += a1v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float b = bb[j * kP2 * kP2 + 8 * xs];
+            acc2[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc2[0][j], 0, 0, 0);
+            acc2[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, b, acc2[1][j], 0, 0, 0);
+          }
         }
-        ox += 4;
-        const bool wrap = ox >= kO2;
-        ox -= wrap ? kO2 : 0;
-        zoff += wrap ? 4 + (kZ2W - kO2) : 4;                  // next row of the 13-wide tile
-        boff += wrap ? 8 + (2 * kP2 - 2 * kO2) : 8;           // two rows down, 22 columns back
+        __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);   // the row's 18 operand reads, then its 24 MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+        za += kZ2W;
+        bb += 2 * kP2;
       }
     }
     __syncthreads();   // all patch2 gathers done before dz1 overwrites a1
@@ -348,68 +402,92 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
     // ---- (3) dz1 for this wave's parity class, in place over a1 ----
     {
       const int ny = kO2 - py, nx = kO2 - px, M = ny * nx;   // y = 2*iy + py < 21, x = 2*ix + px < 21
+      int iy = iy3, ix = ix3, jy = jy3, jx = jx3;             // tile 0: gather position (m = col) / first output row (4 q)
 #pragma unroll 1
       for (int t = 0; t * 16 < M; ++t) {
-        int m = t * 16 + col;
-        m = m < M ? m : M - 1;
-        const int iy = m / nx, ix = m - iy * nx;
-        const float* ab = dz2p + (iy + 1 - ta) * kZ2W + (ix + 1 - tb);
+        const bool in = iy < ny;                              // m < M (clamp to the last position)
+        const float* ab = dz2p + ((in ? iy : ny - 1) + 1 - ta) * kZ2W + ((in ? ix : nx - 1) + 1 - tb);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // the a1 values under this tile's outputs (for the ReLU mask) are read first, the A operands eight k-steps
+        // ahead of their MFMAs (LDS_FENCE, see (1))
+        float* pz[4];
+        float a1v[4];
+        bool ok[4];
 #pragma unroll
-        for (int o = 0; o < 32; ++o) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[o * kZ2], bt[o], acc, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) {                         // positions (jy, jx + r), wrapping into the next row
+          const bool w = jx + r >= nx;
+          const int yy = jy + (w ? 1 : 0), xx = jx + r - (w ? nx : 0);
+          ok[r] = yy < ny;
+          pz[r] = c1_pad + col * kP2 * kP2 + (ok[r] ? (2 * yy + py + 2) * kP2 + (2 * xx + px + 2) : 0);   // [col][0][0]: border
+          a1v[r] = *pz[r];
+        }
+        float av[2][8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) av[0][o] = ab[o * kZ2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (g < 3) {
+#pragma unroll
+            for (int o = 0; o < 8; ++o) av[(g + 1) & 1][o] = ab[(8 * (g + 1) + o) * kZ2];
+          }
+          LDS_FENCE();
+#pragma unroll
+          for (int o = 0; o < 8; ++o) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][o], bt[8 * g + o], acc, 0, 0, 0);
+        }
+        // the order of the block for the scheduler: the a1 reads + the first eight A operands (ds_read2: two values
+        // per instruction), then three times [the next eight operands | eight MFMAs], then the last eight MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int mo = t * 16 + q * 4 + r;
-          if (mo < M) {
-            const int jy = mo / nx, jx = mo - jy * nx;
-            float* pz = c1_pad + col * kP2 * kP2 + (2 * jy + py + 2) * kP2 + (2 * jx + px + 2);
-            const float v = *pz > 0.f ? acc[r] : 0.f;
-            *pz = v;
+          if (ok[r]) {
+            const float v = a1v[r] > 0.f ? acc[r] : 0.f;
+            *pz[r] = v;
             db1a += v;
           }
         }
+        iy += 1; ix += 16 - nx;                               // 16 positions further (nx = 10 or 11)
+        if (ix >= nx) { ix -= nx; iy += 1; }
+        jy += 1; jx += 16 - nx;
+        if (jx >= nx) { jx -= nx; jy += 1; }
       }
     }
     __syncthreads();
     CONV_REGION(4);   // (3) dz1 (incl. its barrier)
     // ---- (4) dW1: this wave owns input channel `wave` (16 taps = one k tile) ----
+    // 21 rows of 24 positions (x = 21 .. 23: the zero border of c1_pad / column 0 of its next row), six k-steps per
+    // row with immediate offsets; ONE accumulator (the order of the sum is the order of the positions).
     {
-      // One accumulator, 111 dependent MFMAs: what the loop has to hide is the LDS latency of its operands.  Rounds
-      // 1-3 read a1, a byte and the table entry the byte selects right in front of EVERY MFMA (two LDS round trips
-      // per 32 clocks of matrix work: ~13 us per observation, a third of the kernel).  Now the operands of the
-      // next kG4 positions are read before the MFMAs of the current kG4 are issued, and the byte becomes
-      // (float)u / 255.0f in registers (byte_over_255: the table's values bit for bit).  Same FMAs, same order.
-      constexpr int kG4 = 4;
-      int x = q;                                              // y = 0
-      int aoff = col * kP2 * kP2 + 2 * kP2 + 2 + q;           // c1_pad[col][y + 2][x + 2]
-      int boff = wave * kP1 * kP1 + kh * kP1 + 2 * q + kw;    // in_u8[wave][2*y + kh][2*x + kw]
-      int ps_rd = 0;                                          // the next position group to READ
-      float ca[kG4], na[kG4];
-      uint32_t cb[kG4], nb[kG4];
-      auto read_group = [&](float (&a)[kG4], uint32_t (&b)[kG4]) {
+      const float* pa = c1_pad + col * kP2 * kP2 + 2 * kP2 + 2 + q;     // c1_pad[col][y + 2][4 xs + q + 2]
+      const uint8_t* pb = in_u8 + wave * kP1 * kP1 + kh * kP1 + 2 * q + kw;   // in_u8[wave][2 y + kh][2 (4 xs + q) + kw]
+      // Two rows per iteration, ping-pong: the operands of the next row are read before the MFMAs of the current one
+      // are issued (sched_group_barrier), and the byte becomes (float)u / 255.0f in registers (byte_over_255: the table's
+      // values bit for bit) while they run.  22 rows: row 21 reads the zero border rows of c1_pad (A = 0).
+      float ca[6], na[6];
+      uint32_t cb[6], nb[6];
 #pragma unroll
-        for (int g = 0; g < kG4; ++g) {
-          const bool valid = ((ps_rd < 110) | (q == 0)) & (ps_rd < 111);   // p < 441 (groups past the end read the borders)
-          a[g] = c1_pad[valid ? aoff : col * kP2 * kP2];      // [col][0][0] is border: 0
-          b[g] = in_u8[valid ? boff : 0];                     // [0][0][0] is padding: 0
-          ++ps_rd;
-          x += 4;
-          const bool wrap = x >= kO1;
-          x -= wrap ? kO1 : 0;
-          aoff += wrap ? 4 + (kP2 - kO1) : 4;
-          boff += wrap ? 8 + (2 * kP1 - 2 * kO1) : 8;
-        }
-      };
-      read_group(ca, cb);
+      for (int xs = 0; xs < 6; ++xs) { ca[xs] = pa[4 * xs]; cb[xs] = pb[8 * xs]; }
 #pragma clang loop unroll(disable)
-      for (int ps0 = 0; ps0 < 111; ps0 += kG4) {
-        read_group(na, nb);
-        asm volatile("" ::: "memory");   // the reads above stay above: the scheduler otherwise sinks them to their use
+      for (int y = 0; y < kO1 + 1; y += 2) {
 #pragma unroll
-        for (int g = 0; g < kG4; ++g)
-          if (ps0 + g < 111) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[g], byte_over_255(cb[g]), acc1, 0, 0, 0);
+        for (int xs = 0; xs < 6; ++xs) { na[xs] = pa[kP2 + 4 * xs]; nb[xs] = pb[2 * kP1 + 8 * xs]; }
 #pragma unroll
-        for (int g = 0; g < kG4; ++g) { ca[g] = na[g]; cb[g] = nb[g]; }
+        for (int xs = 0; xs < 6; ++xs) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[xs], byte_over_255(cb[xs]), acc1, 0, 0, 0);
+        pa += 2 * kP2;
+        pb += 4 * kP1;
+#pragma unroll
+        for (int xs = 0; xs < 6; ++xs) { ca[xs] = pa[4 * xs]; cb[xs] = pb[8 * xs]; }
+#pragma unroll
+        for (int xs = 0; xs < 6; ++xs) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(na[xs], byte_over_255(nb[xs]), acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);    // the order of the block for the scheduler: reads of row
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    // y + 1, MFMAs of row y, reads of row y + 2, MFMAs of y + 1
+        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
       }
     }
     CONV_REGION(5);   // (4) dW1
