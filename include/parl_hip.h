@@ -463,6 +463,28 @@ int parlhip_ppo_sample_batch_f32(const float* obs, const float* actions, const f
                                  float* out_values, int64_t N, int64_t M, int obs_dim, int act_dim,
                                  parlhip_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * The learner's parameter update: global-norm gradient clipping + Adam
+ * parl/algorithms/paddle/impala.py:113-117 (Adam(learning_rate, grad_clip=ClipGradByGlobalNorm(40))),
+ * parl/algorithms/torch/a2c.py:76-78 (clip_grad_norm_(parameters, 40); optimizer.step())
+ * ------------------------------------------------------------------------------------ */
+/* n_tensors <= 16 parameter tensors (more: PARLHIP_ENOSUP, callers keep the framework's optimizer).  HOST arrays of
+ * n_tensors DEVICE pointers: params, grads, exp_avg, exp_avg_sq float32 [numel[i]], steps float32 [1] each (torch's
+ * capturable Adam state: the step counter of a parameter is a float32 scalar tensor); lr: DEVICE float32 scalar.
+ * Two launches on `stream`, no host synchronisation (capturable in a hipGraph: pointers and scalars are kernel
+ * arguments): steps[i] += 1; norm = sqrt(sum of g^2 over all tensors); g *= min(1, max_norm / (norm + 1e-6)) in
+ * place (torch.nn.utils.clip_grad_norm_); m += (1-beta1)(g-m); v = beta2 v + (1-beta2) g^2;
+ * p -= lr / (1-beta1^step) * m / (sqrt(v) / sqrt(1-beta2^step) + eps) (torch.optim.Adam, no weight decay / amsgrad;
+ * the hyper-parameters are doubles as torch's are: 1 - beta and the bias corrections are formed in double, the element
+ * arithmetic is float32).
+ * workspace: parlhip_clip_adam_workspace_bytes(...) bytes; norm_out: optional DEVICE float32 [1] (the norm before
+ * clipping).  Deterministic (per-workgroup partial sums added in one fixed order).                                */
+size_t parlhip_clip_adam_workspace_bytes(int n_tensors, const int64_t* numel);
+int parlhip_clip_adam_f32(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                          float* const* exp_avg_sq, float* const* steps, const int64_t* numel, const float* lr,
+                          double beta1, double beta2, double eps, double max_norm, float* workspace, float* norm_out,
+                          parlhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,8 @@ SIGNATURES = {
     (_i, [_p] * 10 + [_i, _i, _i, _i, _f, _f, _f, _p]),
     'parlhip_impala_heads_loss_workspace_bytes': (_sz, [_i, _i]),
     'parlhip_impala_heads_loss_f32': (_i, [_p] * 15 + [_i, _i, _i, _i, _f, _f, _f, _f, _f, _p]),
+    'parlhip_clip_adam_workspace_bytes': (_sz, [_i, _p]),
+    'parlhip_clip_adam_f32': (_i, [_i] + [_p] * 7 + [_d, _d, _d, _d, _p, _p, _p]),
     'parlhip_impala_loss_f32': (_i, [_p] * 11 + [_i, _i, _i, _i, _f, _f, _f, _f, _f, _p]),
     'parlhip_gae_f32': (_i, [_p] * 7 + [_i, _i, _f, _f, _i, _i, _p]),
     'parlhip_gae_workspace_bytes': (_sz, [_i, _i]),

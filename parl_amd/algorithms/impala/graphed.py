@@ -23,6 +23,8 @@ issues (tests/test_gpu_graphed.py compares parameters and losses of both over se
 """
 import torch
 
+from ... import ops
+
 __all__ = ['GraphedLearn', 'make_capturable', 'load_optimizer_state_inplace']
 
 
@@ -111,6 +113,7 @@ def _guard_load_state_dict(optimizer):
 class GraphedLearn(object):
     def __init__(self, alg, B, obs_shape, act_dim, entropy_coeff=-0.01, pool=None):
         self.alg, self.B, self.T = alg, int(B), int(alg.sample_batch_steps)
+        self._clip_adam = None   # ops.ClipAdam once the optimizer is capturable (False: not covered)
         dev = next(alg.model.parameters()).device
         assert dev.type == 'cuda', 'GraphedLearn needs the device path (there is no CPU fallback)'
         self.device = dev
@@ -172,7 +175,16 @@ class GraphedLearn(object):
         self.acc.add_(self.out)
 
     def _clip_and_step(self):
+        """global-norm clip + Adam: two launches of ops.ClipAdam on the optimizer's own state tensors where it covers
+        the optimizer (torch.optim.Adam, one group, <= 16 parameters — every model of this path), else the framework
+        pair (~12 launches, one of them 39 us: torch's fused Adam gives each workgroup a 65,536-element chunk)"""
         alg = self.alg
+        if self._clip_adam is None and ops.ClipAdam.supported(alg.optimizer):
+            self._clip_adam = ops.ClipAdam(alg.optimizer, alg.grad_clip_norm)
+        if self._clip_adam:
+            self._clip_adam.step()
+            return
+        self._clip_adam = False
         torch.nn.utils.clip_grad_norm_(alg.model.parameters(), max_norm=alg.grad_clip_norm)
         alg.optimizer.step()
 

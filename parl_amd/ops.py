@@ -266,6 +266,87 @@ def adv_normalize(adv, idx=None, eps=1e-8, return_stats=False):
     return out
 
 
+class ClipAdam(object):
+    """torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step() as TWO launches
+    (parlhip_clip_adam_f32; the pair parl/algorithms/paddle/impala.py:113-117 configures) over the optimizer's OWN
+    state tensors — `exp_avg`, `exp_avg_sq`, the float32 device `step` scalars and the device `lr` scalar of a
+    capturable torch Adam (graphed.make_capturable): state_dict(), checkpoints and load_optimizer_state_inplace see
+    nothing new.  Missing state is created as torch's first step would (zeros).  `ClipAdam.supported(optimizer)`
+    says whether the optimizer is one this covers (one param group, <= 16 float32 parameters, no weight decay /
+    amsgrad / maximize); callers keep the framework pair otherwise."""
+
+    MAX_TENSORS = 16
+
+    @staticmethod
+    def supported(optimizer):
+        if not isinstance(optimizer, torch.optim.Adam) or type(optimizer) is not torch.optim.Adam:
+            return False
+        if len(optimizer.param_groups) != 1:
+            return False
+        g = optimizer.param_groups[0]
+        ps = [p for p in g['params'] if p.requires_grad]
+        if not ps or len(ps) > ClipAdam.MAX_TENSORS:
+            return False
+        if g.get('weight_decay', 0) or g.get('amsgrad', False) or g.get('maximize', False):
+            return False
+        if g.get('decoupled_weight_decay', False) or g.get('differentiable', False):
+            return False
+        if not isinstance(g['lr'], torch.Tensor) or not g['lr'].is_cuda or g['lr'].dtype != torch.float32:
+            return False
+        return all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps)
+
+    def __init__(self, optimizer, max_norm):
+        import ctypes
+        assert ClipAdam.supported(optimizer)
+        self.optimizer, self.max_norm = optimizer, float(max_norm)
+        g = optimizer.param_groups[0]
+        self.params = [p for p in g['params'] if p.requires_grad]
+        dev = self.params[0].device
+        for p in self.params:  # torch.optim.Adam._init_group for a capturable optimizer
+            st = optimizer.state[p]
+            if len(st) == 0:
+                st['step'] = torch.zeros((), dtype=torch.float32, device=dev)
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if not (st['step'].is_cuda and st['step'].dtype == torch.float32):
+                raise N.ParlHipError('ClipAdam: the optimizer is not capturable (graphed.make_capturable first)')
+        n = len(self.params)
+        self._numel = (ctypes.c_int64 * n)(*[p.numel() for p in self.params])
+        wsb = N.lib().parlhip_clip_adam_workspace_bytes(n, ctypes.cast(self._numel, ctypes.c_void_p))
+        self.workspace = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=dev)
+        self.norm = torch.zeros(1, dtype=torch.float32, device=dev)   # the global norm before clipping, last step
+        self._ct = ctypes
+        self._tables = None
+
+    def _pointer_tables(self):
+        """HOST arrays of device pointers (rebuilt when a tensor moved: p.grad is re-created by zero_grad(set_to_none))"""
+        ct, opt = self._ct, self.optimizer
+        for p in self.params:
+            if p.grad is None or not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
+                raise N.ParlHipError('ClipAdam.step: every parameter needs a contiguous float32 .grad')
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in self.params)
+        if self._tables is None or self._tables[0] != key:
+            n = len(self.params)
+            cols = ([p.data_ptr() for p in self.params], [p.grad.data_ptr() for p in self.params],
+                    [opt.state[p]['exp_avg'].data_ptr() for p in self.params],
+                    [opt.state[p]['exp_avg_sq'].data_ptr() for p in self.params],
+                    [opt.state[p]['step'].data_ptr() for p in self.params])
+            self._tables = (key, [(ct.c_void_p * n)(*c) for c in cols])
+        return self._tables[1]
+
+    @torch.no_grad()
+    def step(self):
+        ct = self._ct
+        g = self.optimizer.param_groups[0]
+        b1, b2 = g['betas']
+        tp, tg, tm, tv, ts = self._pointer_tables()
+        cast = lambda a: ct.cast(a, ct.c_void_p)  # noqa: E731
+        N.check(N.lib().parlhip_clip_adam_f32(len(self.params), cast(tp), cast(tg), cast(tm), cast(tv), cast(ts),
+                                              cast(self._numel), N.ptr(g['lr']), float(b1), float(b2), float(g['eps']),
+                                              self.max_norm, N.ptr(self.workspace), N.ptr(self.norm), N.stream_ptr()),
+                'parlhip_clip_adam_f32')
+
+
 def categorical_sample(probs, uniforms):
     """np.random.choice(A, 1, p=prob) per row given explicit float64 uniforms
     (examples/IMPALA/atari_agent.py:38-40).  Returns int64 [B]."""
