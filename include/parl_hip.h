@@ -367,6 +367,16 @@ int parlhip_atari42_conv12_u8_f32(const uint8_t* obs, const float* w1, const flo
                                   const float* w2, const float* b2, float* out, int n_obs,
                                   parlhip_stream_t stream);
 
+/* The same two layers for the CURRENT observation of every env of a rollout ring, read in place
+ * (parl/env/atari_wrappers.py FrameStack as the ring keeps it, no materialised stack): ring u8
+ * [num_slots, E, 42*42] single frames, since u8 [num_slots, E] = steps since the env's last reset,
+ * clamped at 3; frame j (0 = oldest) of env n's stack at `slot` is the frame min(3 - j, since[slot][n])
+ * slots back (circular) — the rule of parlhip_stack_gather_ring_u8 without link table.  out f32 [E, 3872].
+ * Bit-identical to parlhip_stack_gather_ring_u8 + parlhip_atari42_conv12_u8_f32.                       */
+int parlhip_atari42_conv12_ring_u8_f32(const uint8_t* ring, const uint8_t* since, int num_slots, int E,
+                                       int slot, const float* w1, const float* b1, const float* w2,
+                                       const float* b2, float* out, parlhip_stream_t stream);
+
 /* The LEARNER's gradient of the same two layers (IMPALA.learn, parl/algorithms/paddle/impala/
  * impala.py:148-149,205-215 backpropagates through AtariModel.policy / .value; the reference leaves
  * it to the framework's conv backward): d loss / d (w1, b1, w2, b2) given the forward output

@@ -82,6 +82,7 @@ SIGNATURES = {
     'parlhip_stack_since_update_u8': (_i, [_p, _p, _p, _i, _p]),
     'parlhip_stack_gather_u8': (_i, [_p, _p, _i, _i, _p, _p, _i64, _p, _p]),
     'parlhip_atari42_conv12_u8_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _p]),
+    'parlhip_atari42_conv12_ring_u8_f32': (_i, [_p, _p, _i, _i, _i] + [_p] * 6),
     'parlhip_atari84_conv1_u8_f32': (_i, [_p, _p, _p, _p, _i, _p]),
     'parlhip_atari84_conv23_f32': (_i, [_p] * 7 + [_i, _p]),
     'parlhip_atari84_conv3_bwd_workspace_bytes': (_sz, [_i]),

@@ -56,6 +56,14 @@ struct Batch {
       if ((j + 1) * 256 <= COUNT || i < COUNT) v[j] = src[i];
     }
   }
+  template <typename L>
+  __device__ __forceinline__ void load_by(int tid, L&& address_of) {   // address_of(i) -> const T*
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int i = tid + 256 * j;
+      if ((j + 1) * 256 <= COUNT || i < COUNT) v[j] = *address_of(i);
+    }
+  }
   template <typename F>
   __device__ __forceinline__ void each(int tid, F&& f) const {
 #pragma unroll
@@ -87,8 +95,19 @@ constexpr int kLdsFloats = kLdsIn + kLdsC1;  // 17,744 floats = 70,976 B: two wo
 // workgroup), so an MFMA needs one LDS gather (conv1) or half of one (conv2: both N-tiles reuse
 // the A value); outputs leave the accumulators straight for HBM; the zero borders of the two LDS
 // tiles are written once and never touched again (only interiors are rewritten per observation).
+// RING: the observation of env n is not a materialised [4,42,42] stack but the four frames of the rollout ring it
+// consists of (FrameStack as the ring keeps it: frame j of the stack at `slot` is the frame `min(3 - j, since)` slots
+// back, `since` = the env's steps since its last reset, clamped at 3 — stack_gather_kernel's rule): the actors' step
+// reads them in place and the gather launch (11 us + a launch gap per env step) goes away.
+struct RingObs {
+  const uint8_t* ring;     // [num_slots][E][42*42]
+  const uint8_t* since;    // [num_slots][E]
+  int num_slots, E, slot;
+};
+
+template <bool RING>
 __global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
-    const uint8_t* __restrict__ obs, const float* __restrict__ w1, const float* __restrict__ b1,
+    const uint8_t* __restrict__ obs, RingObs ro, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ out, int n_obs) {
   extern __shared__ float lds[];
   float* in_pad = lds;                  // [4][44][44]
@@ -109,9 +128,28 @@ __global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
   const int oy1 = (16 * wave + col) / kO1, ox1 = (16 * wave + col) - oy1 * kO1;
   const int ey1 = (16 * wave + 4 * q) / kO1, ex1 = (16 * wave + 4 * q) - ey1 * kO1;
   for (int i = tid; i < kLdsFloats; i += 256) lds[i] = 0.0f;
-  const bool words = (reinterpret_cast<uintptr_t>(obs) & 3) == 0;   // 7056 B per observation: true for all or none
+  const bool words = RING || (reinterpret_cast<uintptr_t>(obs) & 3) == 0;   // 7056 B per observation: true for all or none
   Batch<kD * kD, uint32_t> pre;                                      // 4 * 1764 bytes = 1764 words: 7 per thread
-  if (words && (int)blockIdx.x < n_obs) pre.load(reinterpret_cast<const uint32_t*>(obs + (size_t)blockIdx.x * 4 * kD * kD), tid);
+  auto fetch = [&](int n) {
+    if constexpr (RING) {
+      const int sr = ro.since[(size_t)ro.slot * ro.E + n];           // wave-uniform
+      const uint32_t* fr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int from = ro.slot - (3 - j < sr ? 3 - j : sr);
+        from += from < 0 ? ro.num_slots : 0;
+        fr[j] = reinterpret_cast<const uint32_t*>(ro.ring + ((size_t)from * ro.E + n) * (kD * kD));   // 1764 B: a word multiple
+      }
+      pre.load_by(tid, [&](int wi) {
+        const int c = wi / (kD * kD / 4);
+        const uint32_t* f = c == 0 ? fr[0] : (c == 1 ? fr[1] : (c == 2 ? fr[2] : fr[3]));
+        return f + (wi - c * (kD * kD / 4));
+      });
+    } else {
+      pre.load(reinterpret_cast<const uint32_t*>(obs + (size_t)n * 4 * kD * kD), tid);
+    }
+  };
+  if (words && (int)blockIdx.x < n_obs) fetch(blockIdx.x);
   for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
     __syncthreads();  // borders zeroed / the previous observation's conv2 gathers are done
     // ---- obs u8 -> padded float input (x / 255, the division as in the reference) ----
@@ -125,8 +163,7 @@ __global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
           in_pad[c * kP1 * kP1 + (y + 1) * kP1 + (x + 1)] = (float)((v >> (8 * j)) & 255u) / 255.0f;
         }
       });
-      if (n + (int)gridDim.x < n_obs)   // the next observation's bytes are in flight during this one's MFMAs
-        pre.load(reinterpret_cast<const uint32_t*>(obs + (size_t)(n + gridDim.x) * 4 * kD * kD), tid);
+      if (n + (int)gridDim.x < n_obs) fetch(n + gridDim.x);   // the next observation's bytes are in flight during this one's MFMAs
     } else {
       for (int i = tid; i < 4 * kD * kD; i += 256) {
         const int c = i / (kD * kD), r = i - c * kD * kD, y = r / kD, x = r - y * kD;
@@ -1267,13 +1304,34 @@ PARLHIP_EXPORT int parlhip_atari42_conv12_u8_f32(const uint8_t* obs, const float
   static bool attr_set = false;
   const size_t lds_bytes = kLdsFloats * sizeof(float);
   if (!attr_set) {
-    int rc = check(hipFuncSetAttribute((const void*)conv12_u8_mfma_kernel,
+    int rc = check(hipFuncSetAttribute((const void*)conv12_u8_mfma_kernel<false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     if (rc) return rc;
     attr_set = true;
   }
   const int grid = n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU;  // 71 KB of LDS: two workgroups per CU
-  conv12_u8_mfma_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(obs, w1, b1, w2, b2, out, n_obs);
+  conv12_u8_mfma_kernel<false><<<grid, 256, lds_bytes, (hipStream_t)stream>>>(obs, RingObs{}, w1, b1, w2, b2, out, n_obs);
+  return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_atari42_conv12_ring_u8_f32(const uint8_t* ring, const uint8_t* since, int num_slots, int E,
+                                                      int slot, const float* w1, const float* b1, const float* w2,
+                                                      const float* b2, float* out, parlhip_stream_t stream) {
+  if (E < 0 || num_slots < 4 || slot < 0 || slot >= num_slots) return PARLHIP_EINVAL;
+  if (E == 0) return PARLHIP_OK;
+  if (!ring || !since || !w1 || !b1 || !w2 || !b2 || !out) return PARLHIP_EINVAL;
+  if ((uintptr_t)ring & 3u) return PARLHIP_EINVAL;
+  static bool attr_set = false;
+  const size_t lds_bytes = kLdsFloats * sizeof(float);
+  if (!attr_set) {
+    int rc = check(hipFuncSetAttribute((const void*)conv12_u8_mfma_kernel<true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int grid = E < 2 * kNumCU ? E : 2 * kNumCU;
+  conv12_u8_mfma_kernel<true><<<grid, 256, lds_bytes, (hipStream_t)stream>>>(nullptr, RingObs{ring, since, num_slots, E, slot},
+                                                                            w1, b1, w2, b2, out, E);
   return check_launch();
 }
 

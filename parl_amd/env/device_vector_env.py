@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from .. import _native as N
+from .. import ops
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(os.path.dirname(_HERE))
@@ -146,6 +147,13 @@ class DeviceVectorEnv(object):
             slots = torch.full((self.envs_num, ), self.t + 3, dtype=torch.int32, device=self.device)
             self._slot_const[self.t] = slots
         return self.gather(slots, self._env_idx, out)
+
+    def current_obs_ref(self, out=None):
+        """the current observation for a consumer that can read the ring in place (ops.RingObservation; its
+        materialize() is current_obs(out)); with elastic launches (gaps in the ring: `link`) the materialised stack"""
+        if self.link is not None:
+            return self.current_obs(out)
+        return ops.RingObservation(self.ring, self.since, self.t + 3, self.dim, lambda o=None: self.current_obs(o if o is not None else out))
 
     def accumulate_episode_stats(self, acc3):
         """acc3 (f64 [3] on the device) += (episodes closed by the last step, their unclipped

@@ -91,10 +91,14 @@ class AtariModel42(Model):
             nn.init.normal_(fc.weight, 0.0, 1.0)
             nn.init.normal_(fc.bias, 0.0, 1.0)
 
+    reads_ring = True   # the actors' step may hand _trunk an ops.RingObservation (DeviceRollout.collect_step)
+
     def _trunk(self, obs):
+        if isinstance(obs, ops.RingObservation) and (torch.is_grad_enabled() or obs.dim != 42 or obs.shape[0] == 0):
+            obs = obs.materialize()
         if (not torch.is_grad_enabled()) and obs.dtype == torch.uint8 and obs.is_cuda and obs.shape[0] > 0:
             # the actors' path (no autograd): conv1+conv2 as one fused MFMA kernel on the uint8
-            # observations (ops.atari42_conv12), conv3 is a 3872 -> 256 linear layer
+            # observations (ops.atari42_conv12; a RingObservation is read in place), conv3 is a 3872 -> 256 linear layer
             h = ops.atari42_conv12(obs, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
             # conv3 + ReLU as ONE GEMM with a ReLU epilogue (hipBLASLt) instead of addmm + clamp
             return torch._addmm_activation(self.conv3.bias, h, self.conv3.weight.flatten(1).t(), use_gelu=False)

@@ -417,10 +417,40 @@ def policy_head_sample_into(hidden, w_policy, b_policy, logits_out, actions_out,
     return True
 
 
+class RingObservation(object):
+    """The CURRENT stacked observation of every env of a rollout ring, not materialised: ring u8 [S, E, d*d] single
+    frames, since u8 [S, E] (steps since the env's last reset, clamped at 3), `slot` the ring position of the newest
+    frame — frame j of env n's stack is the frame min(3 - j, since[slot, n]) slots back (FrameStack,
+    parl/env/atari_wrappers.py, as DeviceVectorEnv keeps it).  atari42_conv12 reads it in place (one launch less per
+    env step); `materialize()` is the gather every other consumer gets."""
+
+    def __init__(self, ring, since, slot, dim, gather):
+        self.ring, self.since, self.slot, self.dim = ring, since, int(slot), int(dim)
+        self._gather = gather
+        self.shape = (ring.shape[1], 4, self.dim, self.dim)
+        self.dtype, self.device, self.is_cuda = torch.uint8, ring.device, ring.is_cuda
+
+    def materialize(self, out=None):
+        return self._gather(out)
+
+
 def atari42_conv12(obs, conv1_weight, conv1_bias, conv2_weight, conv2_bias, out=None):
     """conv1 + ReLU + conv2 + ReLU of the IMPALA Atari network (examples/IMPALA/atari_model.py:59-71)
     for uint8 observations [n,4,42,42], as ONE fused MFMA kernel (inference only).  Returns f32
-    [n, 3872] = the NCHW-flattened [n,32,11,11] activation."""
+    [n, 3872] = the NCHW-flattened [n,32,11,11] activation.  `obs` may be a RingObservation (the actors' step)."""
+    if isinstance(obs, RingObservation):
+        if obs.dim != 42 or tuple(conv1_weight.shape) != (16, 4, 4, 4) or tuple(conv2_weight.shape) != (32, 16, 4, 4):
+            raise N.ParlHipError('atari42_conv12: a 42x42 ring and weights [16,4,4,4], [32,16,4,4]')
+        S, E = obs.ring.shape[0], obs.ring.shape[1]
+        if out is None:
+            out = torch.empty((E, 32 * 11 * 11), dtype=torch.float32, device=obs.device)
+        w1, b1 = _f32(conv1_weight.detach(), 'conv1_weight'), _f32(conv1_bias.detach(), 'conv1_bias')
+        w2, b2 = _f32(conv2_weight.detach(), 'conv2_weight'), _f32(conv2_bias.detach(), 'conv2_bias')
+        N.check(
+            N.lib().parlhip_atari42_conv12_ring_u8_f32(N.ptr(obs.ring), N.ptr(obs.since), S, E, obs.slot, N.ptr(w1),
+                                                      N.ptr(b1), N.ptr(w2), N.ptr(b2), N.ptr(out), N.stream_ptr()),
+            'parlhip_atari42_conv12_ring_u8_f32')
+        return out
     if obs.dtype != torch.uint8 or obs.dim() != 4 or tuple(obs.shape[1:]) != (4, 42, 42):
         raise N.ParlHipError('atari42_conv12: obs must be uint8 [n,4,42,42]')
     if tuple(conv1_weight.shape) != (16, 4, 4, 4) or tuple(conv2_weight.shape) != (32, 16, 4, 4):

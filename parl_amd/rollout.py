@@ -76,7 +76,8 @@ class DeviceRollout(object):
     @torch.no_grad()
     def collect_step(self, model, t):
         env = self.env
-        obs = env.current_obs(self._obs_step)
+        # a model whose trunk reads the ring in place gets a reference (one launch less per env step), any other the stack
+        obs = env.current_obs_ref(self._obs_step) if getattr(model, 'reads_ring', False) else env.current_obs(self._obs_step)
         logits = self.behaviour_logits[t]
         _policy_and_draw(model, obs, logits, self.actions[t], self.seed, self.step_count, env.env_id0)
         env.step_async(self.actions[t], self.rewards[t], self.dones[t], ep_acc=self.ep_stats)

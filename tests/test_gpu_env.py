@@ -124,6 +124,57 @@ def test_stack_ring_matches_framestack_semantics(dev):
     assert torch.equal(env.current_obs(), prev)  # rolling the ring keeps the history
 
 
+def test_conv12_reads_the_ring_like_the_gathered_stack(dev):
+    """The actors' conv1 + conv2 on an ops.RingObservation (four single frames of the ring, FrameStack's repeat of
+    the first frame after a reset through the `since` byte) against the same kernel on the materialised stack:
+    bit-identical, over the steps after a reset (since = 0, 1, 2, 3), across episode ends and a ring roll; and the
+    rollout's step with a ring-reading model draws the actions of the stack-reading one."""
+    from parl_amd import ops
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel42
+    from parl_amd.rollout import DeviceRollout
+    E = 37
+    env = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=42, horizon=12, seed=5, device=dev, rom_bytes=_rom('breakout'),
+                          max_episode_steps=40)
+    torch.manual_seed(0)
+    m = AtariModel42(env.act_dim).to(dev)
+    w = (m.conv1.weight, m.conv1.bias, m.conv2.weight, m.conv2.bias)
+    env.reset()
+    g = torch.Generator(device='cpu').manual_seed(2)
+    seen = set()
+    for i in range(30):
+        if env.t >= env.horizon:
+            env.roll()
+        ref = env.current_obs_ref()
+        assert isinstance(ref, ops.RingObservation) and ref.shape == (E, 4, 42, 42)
+        stack = env.current_obs()
+        assert torch.equal(ref.materialize(), stack)
+        a, b = ops.atari42_conv12(ref, *w), ops.atari42_conv12(stack, *w)
+        assert torch.equal(a, b), 'step %d' % i
+        seen.update(int(x) for x in env.since[env.t + 3].unique().tolist())
+        with torch.no_grad():
+            assert torch.equal(m.policy(ref), m.policy(stack))
+        env.step_async(torch.randint(0, env.act_dim, (E, ), generator=g).to(dev))
+    assert seen == {0, 1, 2, 3}, seen            # stacks right after a reset were among them
+
+    class StackOnly(torch.nn.Module):            # the same network behind the stack-reading interface
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def policy_sample_into(self, obs, *a):
+            assert torch.is_tensor(obs)
+            return self.inner.policy_sample_into(obs, *a)
+
+    outs = []
+    for model in (m, StackOnly(m)):
+        env2 = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=42, horizon=8, seed=5, device=dev, rom_bytes=_rom('breakout'))
+        ro = DeviceRollout(env2, 8, seed=3)
+        batch = ro.collect(model)
+        outs.append({k: v.clone() for k, v in batch.items()})
+    assert all(torch.equal(outs[0][k], outs[1][k]) for k in outs[0])
+
+
 @pytest.mark.parametrize('game', ['pong', 'breakout'])
 def test_translated_cartridge_equals_interpreter(dev, game):
     """The statically translated cartridge code (csrc/gen_cart_native.py) and the 6507 interpreter
