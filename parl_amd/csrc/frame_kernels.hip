@@ -63,25 +63,6 @@ __global__ __launch_bounds__(512) void frame_post_kernel(
     const int p = since_prev ? since_prev[e] : 0;
     since_next[e] = (flags[e] & 2) ? 0 : (uint8_t)(p + 1 > 3 ? 3 : p + 1);
   }
-  // fmt 1 (one colour byte per pixel): both frames' 16-byte words are loaded FIRST, five per thread and frame, and
-  // are in flight while the header, palette and tap tables below are fetched and staged (round 4; the loop that
-  // used to follow the staging kept one pair of loads in flight per iteration: with the dependent header -> table
-  // pointer -> table chain in front of it the kernel was ~10 HBM round trips long and nothing else — every
-  // workgroup of a 1024-env launch is resident at once, the launch takes as long as one workgroup's chain)
-  constexpr int kFrameWords = kFrameBytes / 16;             // 2,100
-  constexpr int kPerThread = (kFrameWords + 511) / 512;     // 5
-  const bool single = (frames1 == nullptr) || (flags && (flags[e] & 1));
-  const uint8_t* f0 = frames0 + (size_t)e * in_stride;
-  const uint8_t* f1 = single ? f0 : frames1 + (size_t)e * in_stride;
-  const bool batched = fmt == 1 && blockDim.x == 512;
-  uint4 fa[kPerThread], fb[kPerThread];
-  if (batched) {
-#pragma unroll
-    for (int j = 0; j < kPerThread; ++j) {
-      const int i = threadIdx.x + 512 * j;
-      if (i < kFrameWords) { fa[j] = ((const uint4*)f0)[i]; fb[j] = ((const uint4*)f1)[i]; }
-    }
-  }
   const int* hdr = (const int*)blob;
   const int* xstart = (const int*)(blob + hdr[3]);
   const int* ystart = (const int*)(blob + hdr[4]);
@@ -98,6 +79,9 @@ __global__ __launch_bounds__(512) void frame_post_kernel(
     for (int i = threadIdx.x; i < ny; i += blockDim.x) s_yt[i] = yt[i];
   }
   __syncthreads();
+  const bool single = (frames1 == nullptr) || (flags && (flags[e] & 1));
+  const uint8_t* f0 = frames0 + (size_t)e * in_stride;
+  const uint8_t* f1 = single ? f0 : frames1 + (size_t)e * in_stride;
   if (fmt == 1) {
     // gray of ONE colour byte (both frames agree: the static part of every picture) from a 128-entry
     // table built here from the palette with the same integer formula; 16 pixels per lane and step,
@@ -110,7 +94,12 @@ __global__ __launch_bounds__(512) void frame_post_kernel(
     __syncthreads();
     const uint4* a4 = (const uint4*)f0;
     const uint4* b4 = (const uint4*)f1;
-    auto gray16 = [&](int i, const uint4 a, const uint4 b) {
+    // (Round 4 measured issuing these loads up front — four passes per thread and frame in registers, in flight during
+    // the header / table staging above — on the idea that the kernel is one chain of HBM round trips: A/B on one box
+    // 26.4 -> 29.4 us alone and 664 -> 669 us for env step + frame_post; the extra registers (34 -> 63) cost more
+    // than the overlap buys, the four resident workgroups per CU already hide each other's loads.  Not kept.)
+    for (int i = threadIdx.x; i < kFrameBytes / 16; i += blockDim.x) {
+      const uint4 a = a4[i], b = b4[i];
       const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
       uint32_t ow[4];
       const bool same = (((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) & 0xfefefefeu) == 0u;
@@ -133,17 +122,6 @@ __global__ __launch_bounds__(512) void frame_post_kernel(
         }
       }
       ((uint4*)gray)[i] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-    };
-    if (batched) {
-#pragma unroll
-      for (int j = 0; j < kPerThread; ++j) {
-        const int i = threadIdx.x + 512 * j;
-        // (the ballot inside gray16 is per wave: a wave is either wholly inside the frame or, in the last pass, the
-        // lanes past its end are simply off)
-        if (i < kFrameWords) gray16(i, fa[j], fb[j]);
-      }
-    } else {
-      for (int i = threadIdx.x; i < kFrameWords; i += blockDim.x) gray16(i, a4[i], b4[i]);
     }
   } else {
     for (int i = threadIdx.x; i < kFrameBytes; i += blockDim.x) {
