@@ -398,6 +398,11 @@ int parlhip_atari42_conv12_bwd_f32(const uint8_t* obs, const float* w1, const fl
  * per observation on v_mfma_f32_16x16x4_f32; obs must be 4-byte and out 16-byte aligned.       */
 int parlhip_atari84_conv1_u8_f32(const uint8_t* obs, const float* w1, const float* b1, float* out,
                                  int n_obs, parlhip_stream_t stream);
+/* The same layer for the CURRENT observation of every env of an 84x84 rollout ring, read in place (ring u8
+ * [num_slots, E, 84*84], since u8 [num_slots, E]; the frame rule of parlhip_atari42_conv12_ring_u8_f32).
+ * out f32 [E,32,20,20].  Bit-identical to parlhip_stack_gather_ring_u8 + parlhip_atari84_conv1_u8_f32.        */
+int parlhip_atari84_conv1_ring_u8_f32(const uint8_t* ring, const uint8_t* since, int num_slots, int E, int slot,
+                                      const float* w1, const float* b1, float* out, parlhip_stream_t stream);
 
 /* examples/A2C/atari_model.py:21-104 (AtariModel trunk), second and third layer, fused:
  * conv2 32->64 k4 s2 p2 + ReLU (20x20 -> 11x11), conv3 64->64 k3 s1 + ReLU (-> 9x9).

@@ -100,7 +100,7 @@ constexpr int kLdsFloats = kLdsIn + kLdsC1;  // 17,744 floats = 70,976 B: two wo
 // back, `since` = the env's steps since its last reset, clamped at 3 — stack_gather_kernel's rule): the actors' step
 // reads them in place and the gather launch (11 us + a launch gap per env step) goes away.
 struct RingObs {
-  const uint8_t* ring;     // [num_slots][E][42*42]
+  const uint8_t* ring;     // [num_slots][E][d*d] (d = 42: conv12_u8_mfma_kernel, d = 84: conv1_84_u8_mfma_kernel)
   const uint8_t* since;    // [num_slots][E]
   int num_slots, E, slot;
 };
@@ -612,8 +612,9 @@ constexpr int kPlane84 = kD84 * kD84;    // 7056
 constexpr int kGuard84 = 88;                                     // zero bytes in front of plane 0 (>= 85, 4-byte multiple)
 constexpr int kLds84u8Bytes = kGuard84 + 4 * kPlane84 + 8;       // 28,320
 
+template <bool RING>   // RING: the four 84x84 frames of env n read from the rollout ring in place (see RingObs)
 __global__ __launch_bounds__(256, 2) void conv1_84_u8_mfma_kernel(
-    const uint8_t* __restrict__ obs, const float* __restrict__ w, const float* __restrict__ bias,
+    const uint8_t* __restrict__ obs, RingObs ro, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, int n_obs) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
   uint8_t* tile = lds8;                                          // [88 guard][4][84][84]
@@ -629,7 +630,26 @@ __global__ __launch_bounds__(256, 2) void conv1_84_u8_mfma_kernel(
   const float bias0 = bias[col], bias1 = bias[16 + col];
   if (tid < kGuard84 / 4) reinterpret_cast<uint32_t*>(tile)[tid] = 0u;
   Batch<kPlane84, uint32_t> pre;   // 4 * 7056 bytes = 7056 words, 28 per thread: the NEXT observation (see Batch)
-  if ((int)blockIdx.x < n_obs) pre.load(reinterpret_cast<const uint32_t*>(obs + (size_t)blockIdx.x * 4 * kPlane84), tid);
+  auto fetch = [&](int n) {
+    if constexpr (RING) {
+      const int sr = ro.since[(size_t)ro.slot * ro.E + n];           // wave-uniform
+      const uint32_t* fr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int from = ro.slot - (3 - j < sr ? 3 - j : sr);
+        from += from < 0 ? ro.num_slots : 0;
+        fr[j] = reinterpret_cast<const uint32_t*>(ro.ring + ((size_t)from * ro.E + n) * kPlane84);   // 7056 B: a word multiple
+      }
+      pre.load_by(tid, [&](int wi) {
+        const int c = wi / (kPlane84 / 4);
+        const uint32_t* f = c == 0 ? fr[0] : (c == 1 ? fr[1] : (c == 2 ? fr[2] : fr[3]));
+        return f + (wi - c * (kPlane84 / 4));
+      });
+    } else {
+      pre.load(reinterpret_cast<const uint32_t*>(obs + (size_t)n * 4 * kPlane84), tid);
+    }
+  };
+  if ((int)blockIdx.x < n_obs) fetch(blockIdx.x);
   for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
     __syncthreads();  // the previous observation's gathers are done before the tile is rewritten
     uint32_t* dstw = reinterpret_cast<uint32_t*>(tile + kGuard84);
@@ -640,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void conv1_84_u8_mfma_kernel(
       v = (y == kD84 - 1) ? 0u : v;                  // row 83 := 0 (it doubles as row -1 of the next plane)
       dstw[wi] = v;
     });
-    if (n + (int)gridDim.x < n_obs) pre.load(reinterpret_cast<const uint32_t*>(obs + (size_t)(n + gridDim.x) * 4 * kPlane84), tid);
+    if (n + (int)gridDim.x < n_obs) fetch(n + gridDim.x);
     __syncthreads();
     float* dst = out + (size_t)n * kC84 * kM84;
     for (int mt = wave; mt < kM84 / 16; mt += 4) {
@@ -1346,13 +1366,34 @@ PARLHIP_EXPORT int parlhip_atari84_conv1_u8_f32(const uint8_t* obs, const float*
   static bool attr_set = false;
   const size_t lds_bytes = kLds84u8Bytes;
   if (!attr_set) {
-    int rc = check(hipFuncSetAttribute((const void*)conv1_84_u8_mfma_kernel,
+    int rc = check(hipFuncSetAttribute((const void*)conv1_84_u8_mfma_kernel<false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     if (rc) return rc;
     attr_set = true;
   }
   const int grid = n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU;  // 28 KB of LDS, <= 256 VGPRs: two workgroups per CU
-  conv1_84_u8_mfma_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(obs, w1, b1, out, n_obs);
+  conv1_84_u8_mfma_kernel<false><<<grid, 256, lds_bytes, (hipStream_t)stream>>>(obs, RingObs{}, w1, b1, out, n_obs);
+  return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_atari84_conv1_ring_u8_f32(const uint8_t* ring, const uint8_t* since, int num_slots, int E,
+                                                     int slot, const float* w1, const float* b1, float* out,
+                                                     parlhip_stream_t stream) {
+  if (E < 0 || num_slots < 4 || slot < 0 || slot >= num_slots) return PARLHIP_EINVAL;
+  if (E == 0) return PARLHIP_OK;
+  if (!ring || !since || !w1 || !b1 || !out) return PARLHIP_EINVAL;
+  if (((uintptr_t)ring & 3u) || ((uintptr_t)out & 15u)) return PARLHIP_EINVAL;
+  static bool attr_set = false;
+  const size_t lds_bytes = kLds84u8Bytes;
+  if (!attr_set) {
+    int rc = check(hipFuncSetAttribute((const void*)conv1_84_u8_mfma_kernel<true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int grid = E < 2 * kNumCU ? E : 2 * kNumCU;
+  conv1_84_u8_mfma_kernel<true><<<grid, 256, lds_bytes, (hipStream_t)stream>>>(nullptr, RingObs{ring, since, num_slots, E, slot},
+                                                                              w1, b1, out, E);
   return check_launch();
 }
 

@@ -150,7 +150,11 @@ class AtariModel84(Model):
         self.policy_fc = nn.Linear(512, act_dim)
         self.value_fc = nn.Linear(512, 1)
 
+    reads_ring = True   # the actors' step may hand _trunk an ops.RingObservation (DeviceRollout / DeviceA2CRollout)
+
     def _trunk(self, obs):
+        if isinstance(obs, ops.RingObservation) and (torch.is_grad_enabled() or obs.dim != 84 or obs.shape[0] == 0):
+            obs = obs.materialize()
         if (not torch.is_grad_enabled()) and obs.dtype == torch.uint8 and obs.is_cuda and obs.shape[0] > 0:
             # the actors' / bootstrap-value path (no autograd): the 84x84 -> 20x20 contraction as one
             # MFMA kernel on the uint8 observations with /255, bias and ReLU fused (ops.atari84_conv1)

@@ -319,14 +319,15 @@ class DeviceA2CRollout(object):
             self.started = True
         else:
             env.roll()
+        ring = getattr(model, 'reads_ring', False)   # a trunk that reads the ring in place: one launch less per step
         for t in range(self.T):
-            obs = env.current_obs(self._obs_step)
+            obs = env.current_obs_ref(self._obs_step) if ring else env.current_obs(self._obs_step)
             logits, values = model.policy_and_value(obs)
             self.values[t].copy_(values)
             ops.policy_sample_into(logits, self.actions[t], self.seed, self.step_count, env.env_id0)
             env.step_async(self.actions[t], self.rewards[t], self.dones[t], ep_acc=self.ep_stats)
             self.step_count += 1
-        next_value = model.value(env.current_obs(self._obs_step))  # ignored where the last step was terminal
+        next_value = model.value(env.current_obs_ref(self._obs_step) if ring else env.current_obs(self._obs_step))  # ignored where the last step was terminal
         adv, target = ops.gae(self.rewards, self.values, self.dones, next_value, self.gamma, self.lam)
         env.gather(self._slots, self._envs, self.obs)
         n = self.T * env.envs_num

@@ -175,6 +175,58 @@ def test_conv12_reads_the_ring_like_the_gathered_stack(dev):
     assert all(torch.equal(outs[0][k], outs[1][k]) for k in outs[0])
 
 
+def test_conv1_84_reads_the_ring_like_the_gathered_stack(dev):
+    """the 84x84 model's first layer on an ops.RingObservation against the materialised stack (bit-identical, the
+    steps after resets included), and DeviceA2CRollout's batch with the ring-reading model against a stack-reading
+    wrapper of it"""
+    from parl_amd import ops
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel84
+    from parl_amd.rollout import DeviceA2CRollout
+    E = 21
+    env = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=84, horizon=10, seed=6, device=dev, rom_bytes=_rom('breakout'),
+                          max_episode_steps=40)
+    torch.manual_seed(0)
+    m = AtariModel84(env.act_dim).to(dev)
+    env.reset()
+    g = torch.Generator(device='cpu').manual_seed(3)
+    seen = set()
+    for i in range(24):
+        if env.t >= env.horizon:
+            env.roll()
+        ref, stack = env.current_obs_ref(), env.current_obs()
+        assert isinstance(ref, ops.RingObservation) and ref.shape == (E, 4, 84, 84)
+        assert torch.equal(ops.atari84_conv1(ref, m.conv1.weight, m.conv1.bias),
+                           ops.atari84_conv1(stack, m.conv1.weight, m.conv1.bias)), 'step %d' % i
+        seen.update(int(x) for x in env.since[env.t + 3].unique().tolist())
+        with torch.no_grad():
+            (la, va), (lb, vb) = m.policy_and_value(ref), m.policy_and_value(stack)
+            assert torch.equal(la, lb) and torch.equal(va, vb)
+        env.step_async(torch.randint(0, env.act_dim, (E, ), generator=g).to(dev))
+    assert seen == {0, 1, 2, 3}, seen
+
+    class StackOnly(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def policy_and_value(self, obs):
+            assert torch.is_tensor(obs)
+            return self.inner.policy_and_value(obs)
+
+        def value(self, obs):
+            assert torch.is_tensor(obs)
+            return self.inner.value(obs)
+
+    outs = []
+    for model in (m, StackOnly(m)):
+        env2 = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=84, horizon=6, seed=6, device=dev, rom_bytes=_rom('breakout'))
+        ro = DeviceA2CRollout(env2, 6, 0.99, 1.0, seed=4)
+        batch = ro.collect(model)
+        outs.append({k: v.clone() for k, v in batch.items()})
+    assert all(torch.equal(outs[0][k], outs[1][k]) for k in outs[0])
+
+
 @pytest.mark.parametrize('game', ['pong', 'breakout'])
 def test_translated_cartridge_equals_interpreter(dev, game):
     """The statically translated cartridge code (csrc/gen_cart_native.py) and the 6507 interpreter
