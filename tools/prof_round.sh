@@ -20,4 +20,8 @@ python tools/microbench.py > $O/microbench_scans.json 2> $O/microbench.err
 python tools/learner_bench.py --json $O/learner_bench.json > $O/learner_bench.log 2>&1
 (bash tools/prof_heads_alone.sh tree; python tools/heads_beside_env.py; bash tools/pmc_heads.sh $O/heads_pmc_raw.log) > $O/heads_loss.log 2>&1
 (python tools/ref_batch_probe.py; python tools/actor_chain_probe.py 1024 42; python tools/actor_chain_probe.py 1024 84) 2>&1 | grep -v amdgpu > $O/learner_actor_probes.log
+(bash tools/learn84_prof.sh $O/learn84_kernels.txt 84 5120; bash tools/learn84_prof.sh $O/learn42_kernels.txt 42) > /dev/null 2>&1
+if [ -f build_exp/convreg.so ]; then PARL_HIP_LIB=$R/build_exp/convreg.so python tools/conv_regions.py 51200 2>&1 | grep -v amdgpu > $O/conv12_bwd_regions.log; fi
+python tools/ref_batch_probe.py 2>&1 | grep -v amdgpu | tail -5 > $O/ref_batch_probe.log
+timeout 230 python examples/A2C/train.py --log-interval 10 --minutes 3.2 2>&1 | grep -v amdgpu > $O/learn_a2c_pong_256envs_first_3min.log
 ls $O
