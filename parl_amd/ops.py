@@ -319,18 +319,18 @@ class ClipAdam(object):
         self._tables = None
 
     def _pointer_tables(self):
-        """HOST arrays of device pointers (rebuilt when a tensor moved: p.grad is re-created by zero_grad(set_to_none))"""
+        """HOST arrays of device pointers, rebuilt when a tensor moved (p.grad is re-created by zero_grad(set_to_none))"""
         ct, opt = self._ct, self.optimizer
         for p in self.params:
             if p.grad is None or not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
                 raise N.ParlHipError('ClipAdam.step: every parameter needs a contiguous float32 .grad')
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in self.params)
+        cols = ([p.data_ptr() for p in self.params], [p.grad.data_ptr() for p in self.params],
+                [opt.state[p]['exp_avg'].data_ptr() for p in self.params],
+                [opt.state[p]['exp_avg_sq'].data_ptr() for p in self.params],
+                [opt.state[p]['step'].data_ptr() for p in self.params])
+        key = tuple(tuple(c) for c in cols)   # (a plain optimizer.load_state_dict before a capture replaces state tensors)
         if self._tables is None or self._tables[0] != key:
             n = len(self.params)
-            cols = ([p.data_ptr() for p in self.params], [p.grad.data_ptr() for p in self.params],
-                    [opt.state[p]['exp_avg'].data_ptr() for p in self.params],
-                    [opt.state[p]['exp_avg_sq'].data_ptr() for p in self.params],
-                    [opt.state[p]['step'].data_ptr() for p in self.params])
             self._tables = (key, [(ct.c_void_p * n)(*c) for c in cols])
         return self._tables[1]
 

@@ -111,7 +111,8 @@ def test_a2c_rollout_rows_are_aligned(dev):
 
     def recording(obs):
         logits, values = inner(obs)
-        seen.append(obs.clone())
+        # (the model reads the frame ring in place: what it saw is the materialised stack of that reference)
+        seen.append(obs.materialize().clone() if hasattr(obs, 'materialize') else obs.clone())
         outs.append((logits.clone(), values.clone()))
         return logits, values
 
