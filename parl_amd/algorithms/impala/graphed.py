@@ -21,6 +21,8 @@ and replayed per update: one host call, no Python between the kernels.
 Same arithmetic as IMPALA.learn(time_major=True): the graph replays exactly the kernels that call
 issues (tests/test_gpu_graphed.py compares parameters and losses of both over several updates).
 """
+import os
+
 import torch
 
 from ... import ops
@@ -179,7 +181,7 @@ class GraphedLearn(object):
         the optimizer (torch.optim.Adam, one group, <= 16 parameters — every model of this path), else the framework
         pair (~12 launches, one of them 39 us: torch's fused Adam gives each workgroup a 65,536-element chunk)"""
         alg = self.alg
-        if self._clip_adam is None and ops.ClipAdam.supported(alg.optimizer):
+        if self._clip_adam is None and os.environ.get('PARL_AMD_CLIP_ADAM', '1') != '0' and ops.ClipAdam.supported(alg.optimizer):
             self._clip_adam = ops.ClipAdam(alg.optimizer, alg.grad_clip_norm)
         if self._clip_adam:
             self._clip_adam.step()
