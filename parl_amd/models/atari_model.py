@@ -87,6 +87,9 @@ class AtariModel42(Model):
         self.conv3 = GemmConv2d(32, 256, kernel_size=11, stride=1, padding=0)
         self.policy_fc = nn.Linear(256, act_dim)
         self.value_fc = nn.Linear(256, 1)
+        # (the three convolutions keep torch's default initialisation — the reference's take Paddle's, see
+        # paddle_default_init_ below; this model's learning curves (tests/test_gpu_learning.py, profiles/) were all
+        # measured with torch's and pass the reference's published ones, so it was left alone)
         for fc in (self.policy_fc, self.value_fc):  # paddle Normal() initializer: N(0, 1)
             nn.init.normal_(fc.weight, 0.0, 1.0)
             nn.init.normal_(fc.bias, 0.0, 1.0)
@@ -140,6 +143,29 @@ class AtariModel42(Model):
         return self.policy_fc(h), self.value_fc(h).squeeze(1)
 
 
+def paddle_default_init_(module):
+    """The initialisation the reference's model gets: examples/A2C/atari_model.py:21-104 names no initializer, so its
+    layers take PADDLE's defaults — nn.Conv2D: weight ~ Normal(0, sqrt(2 / (k_h k_w in_channels))) (He), nn.Linear:
+    weight ~ Xavier uniform U(+-sqrt(6 / (fan_in + fan_out))), every bias 0.  torch's own defaults
+    (kaiming_uniform(a=sqrt(5)): U(+-1/sqrt(fan_in)) for weights AND biases) are 2.3-2.4x smaller per layer; four
+    layers deep that leaves pre-activations so small that the first Adam steps at the reference's lr = 1e-3 — each
+    moves every weight by the full learning rate — can switch off every ReLU of the 512-unit layer for good:
+    with torch's defaults `examples/A2C/train.py --seed 1` never left the uniform policy (critic loss flat at the 425
+    of a constant prediction; profiles/README.md, the r04 A2C rows)."""
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, nn.Conv2d):
+                fan_in = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
+                m.weight.normal_(0.0, (2.0 / fan_in) ** 0.5)
+                if m.bias is not None:
+                    m.bias.zero_()
+            elif isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    m.bias.zero_()
+    return module
+
+
 class AtariModel84(Model):
     def __init__(self, act_dim):
         super(AtariModel84, self).__init__()
@@ -149,6 +175,7 @@ class AtariModel84(Model):
         self.fc = nn.Linear(5184, 512)
         self.policy_fc = nn.Linear(512, act_dim)
         self.value_fc = nn.Linear(512, 1)
+        paddle_default_init_(self)
 
     reads_ring = True   # the actors' step may hand _trunk an ops.RingObservation (DeviceRollout / DeviceA2CRollout)
 

@@ -71,25 +71,24 @@ def test_impala_breakout_learns_with_elastic_launches(capsys):
 def test_a2c_value_function_fits_at_the_reference_hyperparameters(capsys):
     """examples/A2C/train.py (configs[1]: 256 on-device envs, 84x84, 20-step returns, Adam 1e-3, clip 40) for 20 s:
     the critic's loss — 0.5 * sum of squared errors over the 5,120 rows of an update, window mean of 100 updates —
-    falls from the ~425 of a constant prediction to below 330 within 4e6 sample steps (profiles/r04_a2c_first_30s_four_runs.log:
-    234 - 264 at 15 s).  The score itself needs 2e7 steps to leave -20 (profiles/r04_learn_a2c_pong_256envs_first_3min.log:
-    +20.4 after 200 s) — too long for this suite; a learner whose updates do nothing shows here first.
+    falls from the ~425 of a constant prediction to below 300 within 4e6 sample steps (measured with this seed on one
+    MI355X: 293 after 1e6 steps, 193 after 2.2e6, the score leaving -20 after 5e6).  The score itself needs a few
+    minutes (profiles/r04_learn_a2c_pong_256envs_first_3min.log: +20.4 after 200 s with the earlier initialisation);
+    a learner whose updates do nothing shows here first.
 
-    UP TO THREE ATTEMPTS (seeds 2, 3, 1), and that is a statement about the reference's hyper-parameters, not about the
-    kernels: with Adam at 1e-3 on a sum-reduced loss the first updates move every weight by the full learning rate and
-    in roughly one run in four (2 of 7 observed on MI355X boxes this round, profiles/README.md) every ReLU of the 512-unit layer is
-    dead after them — constant outputs, vf_loss stays at 425, the run never recovers.  The kernels are bit-for-bit
-    deterministic and agree with the GEMM-lowered float path to 1e-4 on this batch (profiles/r04_a2c_diag_kernel_vs_float.log);
-    rocBLAS's reductions are not, which is what makes two runs of one seed differ.  All attempts are printed."""
+    The seed is the one that did NOT start with torch's default initialisation: there the first Adam steps at 1e-3
+    switched off every ReLU of the 512-unit layer (critic loss flat at 425 for good, --seed 1, reproducibly).  The
+    reference's model takes PADDLE's defaults (He-normal convolutions, Xavier-uniform linear layers, zero biases:
+    models.atari_model.paddle_default_init_), 2.3-2.4x larger per layer; AtariModel84 has them since.  A second seed
+    is tried before failing; all attempts are printed."""
     tried = []
-    for seed in (2, 3, 1):   # (seed 1 is a known collapsed start at this code version, seed 2 a known good one)
+    for seed in (1, 2):
         rows = _train(['--seed', str(seed), '--minutes', '0.33', '--log-interval', '5'], timeout=300, script='examples/A2C/train.py')
         vf = [(r['sample_steps'], round(float(r['vf_loss']), 1)) for r in rows]
         tried.append((seed, vf))
         with capsys.disabled():
             print('\nA2C Pong 256 envs, seed %d (sample steps, vf_loss):' % seed, vf, ' env frames/s %.0f' % rows[-1]['env_frames_per_s'])
-        assert vf[0][1] > 350.0, vf
         assert rows[-1]['env_frames_per_s'] > 4e5
-        if min(v for _, v in vf[-2:]) < 330.0:
+        if min(v for _, v in vf[-2:]) < 300.0:
             return
-    raise AssertionError('the critic never started to fit in three attempts: %r' % (tried, ))
+    raise AssertionError('the critic never started to fit: %r' % (tried, ))
