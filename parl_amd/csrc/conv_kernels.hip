@@ -1193,8 +1193,8 @@ __global__ __launch_bounds__(256) void conv2_84_bwd_kernel(
 // conv1_84_bwd_kernel: dW1[c][k] += sum_p dz1[c][p] x[ci][4 oy + kh - 1][4 ox + kw - 1] / 255
 //   [32 x 400] x [400 x 256], k = ci*64 + kh*8 + kw; the observation stays uint8 in LDS (a tile
 //   shifted by the padding: tile[c][py][px] = obs[c][py-1][px-1], row 0 / column 0 = 0; input row / column 83
-//   lie outside every window) next to the (float)u / 255.0f table; wave w owns the k tiles
-//   {w, w+4, w+8, w+12} x 2 c tiles.
+//   lie outside every window); wave w owns the k tiles {w, w+4, w+8, w+12} x 2 c tiles.  (The (float)u / 255.0f table
+//   of rounds 1-3 still has its 1 KB in the LDS layout; since round 4 the byte is converted in registers, see the loop.)
 constexpr int kLds1bFloats = (4 * kPlane84) / 4 + 256 + 32 * kM84 + 64;   // 7,056 + 256 + 12,800 + 64 floats = 80,704 B
 constexpr int kPart1 = 32 * 256 + 32;
 
