@@ -1,6 +1,7 @@
 """ops.ClipAdam (parlhip_clip_adam_f32: global-norm clip + Adam in two launches) against the pair it replaces in the
 graphed learner — torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(capturable, fused).step(), the host mirror of
-parl/algorithms/paddle/impala.py:113-117 (Adam + ClipGradByGlobalNorm(40)).  -m gpu."""
+parl/algorithms/paddle/impala.py:113-117 (Adam + ClipGradByGlobalNorm(40)) — and against the CPU oracle
+(oracle/optim_oracle.py).  -m gpu."""
 import copy
 
 import pytest
@@ -65,6 +66,45 @@ def test_clip_adam_matches_torch_clip_and_fused_adam(grad_scale):
     torch.cuda.synchronize()
     for p, q in zip(pa, pc):
         assert torch.equal(p.detach(), q.detach())
+
+
+@pytest.mark.parametrize('grad_scale', [0.01, 30.0])
+def test_clip_adam_matches_the_cpu_oracle(grad_scale):
+    """the same kernels against oracle/optim_oracle.py (numpy float32 restatement, pinned on torch's host
+    clip_grad_norm_ + Adam in tests/test_optim_oracle.py) on the same seeded inputs: six steps, a changing learning
+    rate, tensors that are no multiple of the 2,048-element chunk"""
+    import numpy as np
+    from oracle import optim_oracle
+    from parl_amd import ops
+    from parl_amd.algorithms.impala.graphed import make_capturable, set_lr
+    dev = torch.device('cuda', 0)
+    shapes = [(16, 4, 4, 4), (16, ), (32, 16, 4, 4), (32, ), (256, 3872), (6, 256), (6, ), (1, 256), (1, ), (2049, ),
+              (4095, 3), (1, )]
+    pa, _ = _models(shapes, dev, 0)
+    oa = torch.optim.Adam(pa, lr=1e-3)
+    make_capturable(oa, dev)
+    ca = ops.ClipAdam(oa, 40.0)
+    P = [p.detach().cpu().numpy().copy() for p in pa]
+    M, V, S = [np.zeros_like(x) for x in P], [np.zeros_like(x) for x in P], [0.0] * len(P)
+    g = torch.Generator(device='cpu').manual_seed(1)
+    for it in range(6):
+        lr = 1e-3 if it < 3 else 5e-4
+        set_lr(oa, lr)
+        grads = [torch.randn(s, generator=g) * grad_scale for s in shapes]
+        G = [x.numpy().copy() for x in grads]
+        for p, gr in zip(pa, grads):
+            p.grad = gr.to(dev)
+        ca.step()
+        norm_o = optim_oracle.clip_adam_step(P, G, M, V, S, lr, max_norm=40.0)
+        torch.cuda.synchronize()
+        assert abs(float(ca.norm) - norm_o) <= 4e-6 * norm_o
+        for i, p in enumerate(pa):
+            st = oa.state[p]
+            assert float(st['step']) == S[i] == it + 1
+            np.testing.assert_allclose(p.grad.cpu().numpy(), G[i], rtol=6e-6, atol=0)
+            np.testing.assert_allclose(st['exp_avg'].cpu().numpy(), M[i], rtol=2e-5, atol=2e-6 * grad_scale)
+            np.testing.assert_allclose(st['exp_avg_sq'].cpu().numpy(), V[i], rtol=2e-5, atol=2e-7 * grad_scale ** 2)
+            np.testing.assert_allclose(p.detach().cpu().numpy(), P[i], rtol=0, atol=4e-7)
 
 
 def test_clip_adam_covers_what_it_says():
