@@ -12,7 +12,7 @@ def main(asm, histf, kidx=0, top=22):
     cnt, kinds, blk = collections.Counter(), collections.defaultdict(collections.Counter), None
     for l in lines[starts[kidx]:]:
         t = l.strip()
-        if 's_endpgm' in t:
+        if t.startswith('.Lfunc_end'):   # (not the first s_endpgm: the picture waves of a two-wave kernel leave early)
             break
         m = re.match(r'; @@(BLK|TRC) ([0-9a-f]{4})', t)
         if m:
