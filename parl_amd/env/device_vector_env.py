@@ -142,10 +142,14 @@ class DeviceVectorEnv(object):
         return out
 
     def current_obs(self, out=None):
-        slots = self._slot_const.get(self.t)
+        return self._obs_at(self.t, out)
+
+    def _obs_at(self, t, out=None):
+        """the stacked observation whose newest frame lies in ring slot t + 3"""
+        slots = self._slot_const.get(t)
         if slots is None:  # one constant index tensor per ring position, made once
-            slots = torch.full((self.envs_num, ), self.t + 3, dtype=torch.int32, device=self.device)
-            self._slot_const[self.t] = slots
+            slots = torch.full((self.envs_num, ), t + 3, dtype=torch.int32, device=self.device)
+            self._slot_const[t] = slots
         return self.gather(slots, self._env_idx, out)
 
     def current_obs_ref(self, out=None):
@@ -153,7 +157,9 @@ class DeviceVectorEnv(object):
         materialize() is current_obs(out)); with elastic launches (gaps in the ring: `link`) the materialised stack"""
         if self.link is not None:
             return self.current_obs(out)
-        return ops.RingObservation(self.ring, self.since, self.t + 3, self.dim, lambda o=None: self.current_obs(o if o is not None else out))
+        t = self.t   # the reference names THIS position: materialising it after further steps still gives this stack
+        return ops.RingObservation(self.ring, self.since, t + 3, self.dim,
+                                   lambda o=None: self._obs_at(t, o if o is not None else out))
 
     def accumulate_episode_stats(self, acc3):
         """acc3 (f64 [3] on the device) += (episodes closed by the last step, their unclipped
