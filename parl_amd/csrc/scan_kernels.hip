@@ -1245,8 +1245,14 @@ __device__ __forceinline__ V heads_row_sums(const float2 (&hr)[TMAX], V wx, V wy
 // without the forward 25.5.  The phases of a wave do not overlap and neither staggering half of the
 // workgroups nor more ILP (two outputs in flight, packed backward) moves the total: what is left is per-wave
 // latency, two waves per SIMD.
+// (PARLHIP_HEADS_MIN_WAVES: A/B switch.  Since round 4 the emulator holds two 128-VGPR waves per SIMD, so only ONE
+// 168-VGPR wave of this kernel fits beside it; at 4 (<= 128 VGPRs) two would, at the price of 42 spilled registers
+// — compiled, not yet measured: tools/build_obj_variant.sh heads4 scan_kernels.hip -DPARLHIP_HEADS_MIN_WAVES=4)
+#ifndef PARLHIP_HEADS_MIN_WAVES
+#define PARLHIP_HEADS_MIN_WAVES 3
+#endif
 template <int A_CT, int TMAX>  // TMAX >= T: rows held in registers (2 VGPRs each)
-__global__ __launch_bounds__(256, 3) void impala_heads_loss_kernel(
+__global__ __launch_bounds__(256, PARLHIP_HEADS_MIN_WAVES) void impala_heads_loss_kernel(
     const float* __restrict__ h, const float* __restrict__ wpi, const float* __restrict__ bpi,
     const float* __restrict__ wv, const float* __restrict__ bv, const float* __restrict__ blog,
     const int64_t* __restrict__ actions, const float* __restrict__ rew, const uint8_t* __restrict__ dones,
