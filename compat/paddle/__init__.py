@@ -10,7 +10,9 @@ MI355X path (tests/test_reference_scripts.py).  It is an import alias for the ho
 names, not a second backend: there is no Paddle here and nothing falls back to it.
 
 Semantics kept: `to_tensor(x, dtype=...)` returns a tensor on the default device (Paddle places tensors on the
-GPU when there is one); layers create their parameters there too; `Normal()` is N(0, 1)
+GPU when there is one); layers create their parameters there too, with PADDLE's default initialisation where the
+script names none (Conv2D: Normal(0, sqrt(2 / (k_h k_w in_channels))), Linear: Xavier uniform, biases 0 — torch's own
+defaults are 2.3-2.4x smaller per layer, which matters for how the A2C example starts); `Normal()` is N(0, 1)
 (paddle.nn.initializer.Normal defaults); `Conv2D` is this repository's GEMM-lowered convolution (the image ships
 no MIOpen kernel database for gfx950).  Parameter LAYOUT differs from Paddle's for `Linear` (torch keeps
 [out, in]) — invisible to the examples, which exchange weights only between their own models.
