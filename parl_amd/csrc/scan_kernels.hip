@@ -1403,13 +1403,315 @@ __global__ __launch_bounds__(256, PARLHIP_HEADS_MIN_WAVES) void impala_heads_los
   if (threadIdx.x < 4) atomicAdd(sums + threadIdx.x, (double)redb[0][NO + threadIdx.x] + (double)redb[1][NO + threadIdx.x]);
 }
 
-// out[k] = sum over workgroup partials, fixed order: 16 outputs x 16 slices of the partials per block
+// ----------------------------------------------------------------------------------------
+// Round 5: FOUR wavefronts per sequence, rows across the lane groups.
+//
+// The two-wave kernel above spends ~3,800 VALU instructions per wave around an 18.5 us memory part and
+// holds only two waves per SIMD, so its load / compute / store phases do not overlap (33 us).  Here a
+// wave owns 64 columns of its sequence and lane (n = lane & 15, kk = lane >> 4) holds columns
+// 64 w + 4 n .. + 3 (one float4) of the rows t = 4 G + kk, G = 0 .. NG-1: one dwordx4 load per row group (four
+// rows x 256 contiguous bytes), NG = 13 registers-of-four for T <= 52.
+//  * head outputs: the lane's 4-column dot product per (G, j), then a butterfly over the 16 lanes of a DPP
+//    row only (the four lane groups hold DIFFERENT rows: nothing to reduce across them) — stages 8, 4, 2, 1 as
+//    row_mirror / row_half_mirror / quad_perm adds over 16 leaves (2 row groups x 8 output slots) per result
+//    register, depth first, in row-group order (= load order: the waits for the loads are progressive).
+//    The four column quarters meet in LDS, ONE wave per sequence runs the loss math lane-per-step and hands
+//    d total / d (logits, value) back through LDS in the row-group layout.
+//  * backward: every lane group reads ITS row's 8 gradients (two ds_read_b128, a broadcast inside the group)
+//    — no v_readlane broadcasts — and does 2 x 14 v_pk_fma_f32 per row group: d h (one float4 store, 4 rows x
+//    256 B per instruction) and the weight gradient of its 4 columns.  The four lane groups' weight
+//    gradients are folded with v_permlane32_swap / v_permlane16_swap (two registers per swap + add).
+// Two sequences (eight waves) per workgroup: the partial layout, workspace and heads_partial_sum_kernel
+// are those of the two-wave kernel.  <= 128 VGPRs: four waves per SIMD alone, two beside the emulator.
+// ----------------------------------------------------------------------------------------
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+template <int A_CT, int NG, int I>
+__device__ __forceinline__ float hq_leaf(const f4v (&hr)[NG], const f4v (&wj)[A_CT + 1]) {
+  constexpr int G = I >> 3, j = I & 7;
+  if constexpr (G < NG && j <= A_CT) {
+    f2v p = f2v{hr[G].x, hr[G].y} * f2v{wj[j].x, wj[j].y};
+    p = __builtin_elementwise_fma(f2v{hr[G].z, hr[G].w}, f2v{wj[j].z, wj[j].w}, p);
+    return p.x + p.y;
+  } else {
+    return 0.f;
+  }
+}
+// Stages 8 and 4 of the butterfly without selects (BM): the lanes that keep x are whole DPP banks (4 lanes) —
+// banks 0,1 | 2,3 at stage 8, banks 0,2 | 1,3 at stage 4 — so "x + partner's x where I keep x, y + partner's y
+// where I keep y" is two v_add_f32_dpp with complementary bank masks writing one register (2 instead of 3 ops).
+template <int OFF>
+__device__ __forceinline__ float stage_combine_banks(float x, float y) {
+  float r;
+  if constexpr (OFF == 8)
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_mirror row_mask:0xf bank_mask:0xc" : "=&v"(r) : "v"(x), "v"(y));
+  else
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa" : "=&v"(r) : "v"(x), "v"(y));
+  return r;
+}
+// sum over the 16 lanes of a DPP row of 16 leaves: lane n ends with the row sum of leaf I + n
+template <int A_CT, int NG, int OFF, int I, bool BM>
+__device__ __forceinline__ float hq_tree(const f4v (&hr)[NG], const f4v (&wj)[A_CT + 1], int lane) {
+  if constexpr (OFF == 16) {
+    return hq_leaf<A_CT, NG, I>(hr, wj);
+  } else {
+    const float x = hq_tree<A_CT, NG, OFF * 2, I, BM>(hr, wj, lane);
+    const float y = hq_tree<A_CT, NG, OFF * 2, I + OFF, BM>(hr, wj, lane);
+    if constexpr (BM && OFF >= 4) {
+      return stage_combine_banks<OFF>(x, y);
+    } else {
+      constexpr int ctrl = OFF == 8 ? 0x140 : (OFF == 4 ? 0x141 : (OFF == 2 ? 0x4e : 0xb1));
+      return stage_combine<ctrl>(x, y, (lane & OFF) != 0);
+    }
+  }
+}
+
+template <int A_CT, int NG, bool BM>  // 4 NG >= T rows; BM: bank-masked DPP adds in the butterfly
+__global__ __launch_bounds__(512, 4) void impala_heads_loss_q_kernel(
+    const float* __restrict__ h, const float* __restrict__ wpi, const float* __restrict__ bpi,
+    const float* __restrict__ wv, const float* __restrict__ bv, const float* __restrict__ blog,
+    const int64_t* __restrict__ actions, const float* __restrict__ rew, const uint8_t* __restrict__ dones,
+    float* __restrict__ vs, float* __restrict__ pg, float* __restrict__ dh, float* __restrict__ wpart,
+    double* __restrict__ sums, int T, int B, float gamma, float clip_rho, float clip_pg, float vf_coeff,
+    float ent_coeff, int* __restrict__ err, int stagger) {
+  constexpr int NO = A_CT + 1, H = kHeadsHidden, NR = 4 * NG, NQ = (NG + 1) / 2, NRP = 8 * NQ;  // NRP: rows incl. the padding group
+  static_assert(NO <= 8, "eight output slots per row");
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int w = wid & 3, sq = wid >> 2;
+  const int n = lane & 15, kk = lane >> 4;
+  const int blk = xcd_chunk_block(blockIdx.x, gridDim.x);
+  const int64_t b_raw = (int64_t)blk * 2 + sq;
+  const bool live = b_raw < B;
+  const int64_t b = live ? b_raw : (int64_t)B - 1;
+  const int Tm = T - 1;
+  __shared__ __attribute__((aligned(16))) float xl[2][4][NRP * 8];  // [sequence][column quarter][row][output slot]
+  __shared__ __attribute__((aligned(16))) float gl[2][NR * 8];      // [sequence][row][output slot]: d total / d output
+  __shared__ __attribute__((aligned(16))) float redw[2][NO][H];
+  __shared__ float redb[2][NO + 4];
+
+  // Two cohorts: every workgroup is resident at once (1024 sequences = four waves per SIMD), so without this all
+  // of them load, then all compute, then all store, and the HBM idles while the VALUs work.  The second half of
+  // the grid (the second workgroup of every CU) starts `stagger` x 1024 clocks later: its loads stream in under
+  // the first cohort's arithmetic, its arithmetic runs under the first cohort's stores.
+  if (stagger > 0) {  // stagger = clocks / 1024 (+ 1000: alternate workgroups of an XCD instead of grid halves)
+    const bool late = stagger >= 1000 ? ((blockIdx.x >> 3) & 1) != 0 : blockIdx.x >= (gridDim.x >> 1);
+    if (late)
+      for (int i = 0; i < stagger % 1000; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+  // ---- 1. loads: row group G = rows 4G + kk, this wave's 64 columns.  Rows past T-1 re-read row T-1: their head
+  // outputs are never used, their output gradients are zero (so they add nothing to the weight gradients) and
+  // their d h rows are not stored — no zero fill, no divergent branch.
+  const size_t BH = (size_t)B * H;
+  const float* hb = h + b * H + 64 * w + 4 * n;
+  f4v hr[NG];
+#pragma unroll
+  for (int G = 0; G < NG; ++G) hr[G] = *(const f4v*)(hb + (size_t)min(4 * G + kk, Tm) * BH);
+  f4v wj[NO];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) wj[j] = *(const f4v*)((j < A_CT ? wpi + (size_t)j * H : wv) + 64 * w + 4 * n);
+  // ---- 2. head outputs of this column quarter: result register q, lane (n, kk) = row 4 (2q + (n >> 3)) + kk, slot n & 7
+  {
+    float* xw = &xl[sq][w][32 * (n >> 3) + 8 * kk + (n & 7)];
+#define HQ_TREE(Q) if constexpr (Q < NQ) { xw[64 * Q] = hq_tree<A_CT, NG, 1, 16 * Q, BM>(hr, wj, lane); }
+    HQ_TREE(0) HQ_TREE(1) HQ_TREE(2) HQ_TREE(3) HQ_TREE(4) HQ_TREE(5) HQ_TREE(6) HQ_TREE(7)
+#undef HQ_TREE
+  }
+  __syncthreads();
+  // ---- 3. the loss on ONE wave per sequence, lane per step (impala_loss_wave_kernel, K = 1)
+  float g[NO];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) g[j] = 0.f;
+  float pi = 0.f, vf = 0.f, ent = 0.f, kl = 0.f;
+  if (w == ((int)b_raw & 3)) {  // the loss wave of sequence b (spread over the SIMDs)
+    const int t = lane;
+    const bool in_t = t < T, valid1 = t < Tm;
+    const int tr = t < NR ? t : 0;
+    float o8[8];
+    {
+      const f4v* x0 = (const f4v*)&xl[sq][0][tr * 8];
+      const f4v* x1 = (const f4v*)&xl[sq][1][tr * 8];
+      const f4v* x2 = (const f4v*)&xl[sq][2][tr * 8];
+      const f4v* x3 = (const f4v*)&xl[sq][3][tr * 8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f4v s = (x0[q] + x1[q]) + (x2[q] + x3[q]);
+        o8[4 * q] = s.x; o8[4 * q + 1] = s.y; o8[4 * q + 2] = s.z; o8[4 * q + 3] = s.w;
+      }
+    }
+    float outv[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) outv[j] = o8[j] + (j < A_CT ? bpi[j] : bv[0]);
+    const int64_t i = (int64_t)(in_t ? t : 0) * B + b;
+    const float v_own = outv[A_CT];
+    const float bootstrap = __shfl(v_own, Tm, 64);
+    float lp[A_CT], p[A_CT], blp[A_CT];
+    {
+      float tl[A_CT];
+#pragma unroll
+      for (int j = 0; j < A_CT; ++j) tl[j] = outv[j];
+      log_softmax_regs<A_CT>(tl, lp);
+      log_softmax_row<A_CT>(blog + i * A_CT, blp);
+    }
+    float Hh = 0.f;
+#pragma unroll
+    for (int j = 0; j < A_CT; ++j) {
+      p[j] = expf(lp[j]);
+      Hh -= p[j] * lp[j];
+      kl += p[j] * (lp[j] - blp[j]);
+    }
+    if (!in_t || !live) kl = 0.f;
+    float rho[1] = {1.f}, dsc[1] = {0.f}, v[1] = {0.f}, r[1] = {0.f}, vst[1], pgv[1];
+    bool valid[1] = {valid1};
+    int act = 0;
+    float tlp = 0.f;
+    if (valid1) {
+      int a = (int)actions[i];
+      if (a < 0 || a >= A_CT) { *err = 1; a = 0; }
+      act = a;
+      float ta = lp[0], ba = blp[0];
+#pragma unroll
+      for (int j = 1; j < A_CT; ++j) { ta = (j == a) ? lp[j] : ta; ba = (j == a) ? blp[j] : ba; }
+      tlp = ta;
+      dsc[0] = dones[i] ? 0.f : gamma;
+      rho[0] = expf(ta - ba);
+      v[0] = v_own;
+      r[0] = rew[i];
+    }
+    vtrace_wave_core<1>(rho, dsc, v, r, valid, lane, Tm, bootstrap, clip_rho, clip_pg, vst, pgv);
+    if (valid1 && live) {
+      const float dv = v[0] - vst[0];
+#pragma unroll
+      for (int j = 0; j < A_CT; ++j)
+        g[j] = -pgv[0] * ((j == act ? 1.f : 0.f) - p[j]) - ent_coeff * (p[j] * (lp[j] + Hh));
+      g[A_CT] = vf_coeff * dv;
+      const int64_t o = (int64_t)t * B + b;
+      pg[o] = pgv[0];
+      vs[o] = vst[0];
+      pi = -tlp * pgv[0];
+      vf = 0.5f * dv * dv;
+      ent = Hh;
+    }
+    if (t < NR) {
+      f4v* go = (f4v*)&gl[sq][t * 8];
+      go[0] = f4v{g[0], NO > 1 ? g[NO > 1 ? 1 : 0] : 0.f, NO > 2 ? g[NO > 2 ? 2 : 0] : 0.f, NO > 3 ? g[NO > 3 ? 3 : 0] : 0.f};
+      go[1] = f4v{NO > 4 ? g[NO > 4 ? 4 : 0] : 0.f, NO > 5 ? g[NO > 5 ? 5 : 0] : 0.f, NO > 6 ? g[NO > 6 ? 6 : 0] : 0.f,
+                  NO > 7 ? g[NO > 7 ? 7 : 0] : 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+      const float s = wave_sum(g[j]);
+      if (lane == 0) redb[sq][j] = s;
+    }
+    pi = wave_sum(pi); vf = wave_sum(vf); ent = wave_sum(ent); kl = wave_sum(kl);
+    if (lane == 0) { redb[sq][NO] = pi; redb[sq][NO + 1] = vf; redb[sq][NO + 2] = ent; redb[sq][NO + 3] = kl; }
+  }
+  __syncthreads();
+  // ---- 4. backward in two passes over the row groups (each reads its row's 8 gradients from LDS: two
+  // ds_read_b128, a broadcast inside the lane group), so that the head weights (28 registers) and the weight
+  // gradient accumulators (28) are never live together:  (a) d h = sum_j g_j W_j, stored as it is formed (the
+  // stores drain under pass b);  (b) d W_j += g_j h for this lane's four columns.
+  {
+    const float* wq = wpi;  // opaque copies: the weights are RE-loaded here (L1 / L2 hits) instead of living across the loss
+    const float* vq = wv;
+    asm volatile("" : "+s"(wq), "+s"(vq));
+    f4v w2[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) w2[j] = *(const f4v*)((j < A_CT ? wq + (size_t)j * H : vq) + 64 * w + 4 * n);
+    float* dhb = dh + b * H + 64 * w + 4 * n;
+#pragma unroll
+    for (int G = 0; G < NG; ++G) {
+      const f4v* gp = (const f4v*)&gl[sq][(4 * G + kk) * 8];
+      const f4v g0 = gp[0], g1 = gp[1];
+      const float gr[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      f2v d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NO; ++j) {
+        const f2v gg = {gr[j], gr[j]};
+        d0 = __builtin_elementwise_fma(gg, f2v{w2[j].x, w2[j].y}, d0);
+        d1 = __builtin_elementwise_fma(gg, f2v{w2[j].z, w2[j].w}, d1);
+      }
+      if (live && 4 * G + kk < T) *(f4v*)(dhb + (size_t)(4 * G + kk) * BH) = f4v{d0.x, d0.y, d1.x, d1.y};
+    }
+  }
+  f2v acc[NO][2];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) acc[j][0] = acc[j][1] = f2v{0.f, 0.f};
+#pragma unroll
+  for (int G = 0; G < NG; ++G) {
+    const f4v* gp = (const f4v*)&gl[sq][(4 * G + kk) * 8];
+    const f4v g0 = gp[0], g1 = gp[1];
+    const float gr[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const f2v h0 = {hr[G].x, hr[G].y}, h1 = {hr[G].z, hr[G].w};
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+      const f2v gg = {gr[j], gr[j]};
+      acc[j][0] = __builtin_elementwise_fma(gg, h0, acc[j][0]);
+      acc[j][1] = __builtin_elementwise_fma(gg, h1, acc[j][1]);
+    }
+  }
+  // ---- 5. fold the four lane groups (rows mod 4): register r = 7 c + j holds column component c of output j;
+  // swap32 + add folds registers r | r + 2 NO (lanes < 32 keep r), swap16 + add r | r + NO: lane group kk ends
+  // with component c = kk of every output: d W[j][64 w + 4 n + kk]
+  {
+    float v[4 * NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+      v[j] = acc[j][0].x; v[NO + j] = acc[j][0].y; v[2 * NO + j] = acc[j][1].x; v[3 * NO + j] = acc[j][1].y;
+    }
+    float u[2 * NO];
+#pragma unroll
+    for (int i = 0; i < 2 * NO; ++i) {
+      lane_swap32(v[i], v[i + 2 * NO]);
+      u[i] = v[i] + v[i + 2 * NO];
+    }
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+      lane_swap16(u[j], u[j + NO]);
+      redw[sq][j][64 * w + 4 * n + kk] = u[j] + u[j + NO];
+    }
+  }
+  __syncthreads();
+  float* wp = wpart + (size_t)blk * (NO * H + NO);
+  for (int k = threadIdx.x; k < NO * (H / 4); k += 512) {
+    const f4v a0 = ((const f4v*)&redw[0][0][0])[k], a1 = ((const f4v*)&redw[1][0][0])[k];
+    ((f4v*)wp)[k] = a0 + a1;
+  }
+  if (threadIdx.x < NO) wp[NO * H + threadIdx.x] = redb[0][threadIdx.x] + redb[1][threadIdx.x];
+  if (threadIdx.x < 4) atomicAdd(sums + threadIdx.x, (double)redb[0][NO + threadIdx.x] + (double)redb[1][NO + threadIdx.x]);
+}
+
+// out[k] = sum over workgroup partials, fixed order.  This launch is a chain of dependent HBM round trips (the
+// partials were written by other XCDs), so what counts is how many rounds a thread needs: 16 outputs x 16 slices
+// per block (partial_sum16: eight rounds of four loads at 512 partials) took 4.3-5 us; with 8 outputs x 32
+// slices and up to 16 loads of a thread in flight at once it is one round for <= 512 partials.
 __global__ __launch_bounds__(256) void heads_partial_sum_kernel(const float* __restrict__ wpart, int nblk, int n,
                                                                 float* __restrict__ out) {
   __shared__ float red[256];
-  const int k = blockIdx.x * 16 + (threadIdx.x & 15);
-  const float t = partial_sum16(wpart, nblk, n, k, red);
-  if (threadIdx.x < 16 && k < n) out[k] = t;
+  const int kk = threadIdx.x & 7, qs = threadIdx.x >> 3;   // output within the block, slice 0..31
+  const int k = blockIdx.x * 8 + kk;
+  float acc = 0.f;
+  if (k < n) {
+    for (int q0 = qs; q0 < nblk; q0 += 32 * 16) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int q = q0 + 32 * i;
+        v[i] = q < nblk ? wpart[(size_t)q * n + k] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc += v[i];
+    }
+  }
+  red[qs * 8 + kk] = acc;
+  __syncthreads();
+  if (qs == 0 && k < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += red[i * 8 + kk];
+    out[k] = t;
+  }
 }
 
 PARLHIP_EXPORT size_t parlhip_impala_heads_loss_workspace_bytes(int B, int A) {
@@ -1445,7 +1747,17 @@ PARLHIP_EXPORT int parlhip_impala_heads_loss_f32(const float* hidden, const floa
   impala_heads_loss_kernel<AA, TT><<<nblk, 256, 0, s>>>(hidden, w_policy, b_policy, w_value, b_value,         \
       behaviour_logits, actions, rewards, dones, vs, pg, grad_hidden, wpart, sums, T, B, gamma, clip_rho,     \
       clip_pg, vf_coeff, ent_coeff, err)
-#define HL(AA) do { if (small) HLT(AA, 50); else HLT(AA, 64); } while (0)
+#define HQT(AA, NGG, BMM)                                                                                      \
+  impala_heads_loss_q_kernel<AA, NGG, BMM><<<nblk, 512, 0, s>>>(hidden, w_policy, b_policy, w_value, b_value,      \
+      behaviour_logits, actions, rewards, dones, vs, pg, grad_hidden, wpart, sums, T, B, gamma, clip_rho,     \
+      clip_pg, vf_coeff, ent_coeff, err, stagger)
+  static const int stagger = [] { const char* e = getenv("PARLHIP_HEADS_STAGGER"); return e ? atoi(e) : 0; }();
+  // A/B switch while both layouts are measured: PARLHIP_HEADS_KERNEL=2 selects the two-waves-per-sequence kernel
+  static const int variant = [] { const char* e = getenv("PARLHIP_HEADS_KERNEL"); return e ? atoi(e) : 4; }();
+  if (B > (1 << 20)) return PARLHIP_ENOSUP;  // 32-bit lane offsets of the row-group layout
+#define HL(AA) do { if (variant == 2) { if (small) HLT(AA, 50); else HLT(AA, 64); }                            \
+                    else if (variant == 5) { if (T <= 52) HQT(AA, 13, true); else HQT(AA, 16, true); }        \
+                    else { if (T <= 52) HQT(AA, 13, false); else HQT(AA, 16, false); } } while (0)
   switch (A) {
     case 4: HL(4); break;
     case 6: HL(6); break;
@@ -1453,7 +1765,8 @@ PARLHIP_EXPORT int parlhip_impala_heads_loss_f32(const float* hidden, const floa
   }
 #undef HL
 #undef HLT
+#undef HQT
   const int n = (A + 1) * kHeadsHidden + (A + 1);
-  heads_partial_sum_kernel<<<ceil_div(n, 16), 256, 0, s>>>(wpart, nblk, n, grad_heads);
+  heads_partial_sum_kernel<<<ceil_div(n, 8), 256, 0, s>>>(wpart, nblk, n, grad_heads);
   return check_launch();
 }

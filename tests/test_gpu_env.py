@@ -352,3 +352,90 @@ def test_step_with_folded_episode_stats_equals_separate_accumulation(dev):
     np.testing.assert_allclose(a0[1], a1[1], rtol=1e-12)
     for e in envs:
         e.check_faults()
+
+
+def _long_parity(dev, oracle, game, E, dim, steps, seed, ids=None, max_episode_steps=400000):
+    """Whole games: the device vector and one single-env oracle per checked env id (the oracle's C code releases
+    the GIL: one thread per env, running while the device steps) on the same pre-drawn random actions.  Returns per
+    checked env (dones seen, MonitorEnv episodes [(step, return, length)]) after asserting obs / reward / done /
+    episode records equal at every step."""
+    from concurrent.futures import ThreadPoolExecutor
+    from parl_amd.env import DeviceVectorEnv
+    rom = _rom(game)
+    ids = list(range(E)) if ids is None else list(ids)
+    env = DeviceVectorEnv(GAMES[game], E, dim=dim, horizon=8, seed=seed, device=dev, rom_bytes=rom,
+                          max_episode_steps=max_episode_steps)
+    rng = np.random.default_rng(seed)
+    acts = rng.integers(0, env.act_dim, (steps, E))
+    orcs = [oracle.VecEnv(rom, game, 1, dim, seed=seed, env_id0=i, max_episode_steps=max_episode_steps) for i in ids]
+
+    def run_oracle(k):
+        o, e = orcs[k], ids[k]
+        obs = np.zeros((steps + 1, 4, dim, dim), np.uint8)
+        rew, done, eps = np.zeros(steps, np.float32), np.zeros(steps, np.uint8), []
+        obs[0] = o.reset()[0]
+        for t in range(steps):
+            oo, r, d = o.step(acts[t, e:e + 1])
+            obs[t + 1], rew[t], done[t] = oo[0], r[0], d[0]
+            eps += [(t, ret, ln) for ret, ln in o.pop_episodes(0)]
+        return obs, rew, done, eps
+
+    sel = torch.tensor(ids, device=dev)
+    with ThreadPoolExecutor(min(8, len(ids))) as ex:
+        futs = [ex.submit(run_oracle, k) for k in range(len(ids))]
+        d_obs = [env.reset()[sel].cpu().numpy()]
+        d_rew, d_done, d_eps = [], [], [[] for _ in ids]
+        for t in range(steps):
+            o, r, d, info = env.step(torch.from_numpy(acts[t]).to(dev))
+            d_obs.append(o[sel].cpu().numpy())
+            d_rew.append(r[sel].cpu().numpy())
+            d_done.append(d[sel].cpu().numpy().astype(np.uint8))
+            ln, rt = info['episode_lengths'][sel].cpu().numpy(), info['episode_returns'][sel].cpu().numpy()
+            for k in range(len(ids)):
+                if ln[k]:
+                    d_eps[k].append((t, float(rt[k]), int(ln[k])))
+        res = [f.result() for f in futs]
+    env.check_faults()
+    out = []
+    for k, (obs, rew, done, eps) in enumerate(res):
+        for t in range(steps):
+            assert d_rew[t][k] == rew[t], 'reward, env %d step %d' % (ids[k], t)
+            assert d_done[t][k] == done[t], 'done, env %d step %d' % (ids[k], t)
+            assert np.array_equal(d_obs[t + 1][k], obs[t + 1]), 'obs, env %d step %d' % (ids[k], t)
+        assert np.array_equal(d_obs[0][k], obs[0])
+        assert d_eps[k] == [(t, float(r), int(n)) for t, r, n in eps], 'MonitorEnv records, env %d' % ids[k]
+        out.append((int(done.sum()), eps))
+    return out
+
+
+def test_pong_whole_games_match_oracle(dev, oracle):
+    """Long horizon (the windows above are 24-260 steps): 1200 agent steps x 4 envs of Pong under random play.
+    Every env plays a WHOLE game to 21 points — the cartridge's terminal -> EpisodicLifeEnv's was_real_done ->
+    the real reset (ALE reset + noops, parl/env/atari_wrappers.py:103-133,177-211) -> the next game's first
+    ~100+ steps — bit-exact against the oracle at every step."""
+    res = _long_parity(dev, oracle, 'pong', E=4, dim=42, steps=1200, seed=3)
+    for nd, eps in res:
+        assert nd >= 1 and len(eps) >= 1
+        t_end, ret, ln = eps[0]
+        assert ret <= -15 and t_end <= 1100, (t_end, ret, ln)   # a game LOST 21 : x, not a TimeLimit cut,
+        assert ln > 3000                                        # with >= 100 steps of the next game after it
+
+
+def test_breakout_whole_games_match_oracle(dev, oracle):
+    """700 agent steps x 4 envs of Breakout: every env sees several REAL game overs (fifth life lost ->
+    was_real_done -> ALE reset + noops + FIRE) and, between them, the life-loss branch of EpisodicLifeEnv.reset
+    (a NOOP step instead of a reset, atari_wrappers.py:200-211) followed by FireResetEnv's two steps (:163-171)."""
+    res = _long_parity(dev, oracle, 'breakout', E=4, dim=84, steps=700, seed=3)
+    for nd, eps in res:
+        assert len(eps) >= 2, eps               # real game overs (MonitorEnv sits below EpisodicLifeEnv)
+        assert nd >= len(eps) + 8, (nd, eps)    # dones that were life losses, not game overs
+
+
+@pytest.mark.parametrize('game,E,steps', [('pong', 1024, 50), ('breakout', 256, 150)])
+def test_full_size_vector_84_matches_oracle_on_a_subset_of_envs(dev, oracle, game, E, steps):
+    """the 84x84 frame size at full vector width: 1024 envs (configs[2] at the north-star frame size) and
+    configs[1]'s 256 envs, a spread of env ids against single-env oracles"""
+    ids = [0, 1, 3, 4, 255] + ([256, 511, 512, 777, 1023] if E == 1024 else [5, 64, 127, 128, 200])
+    res = _long_parity(dev, oracle, game, E=E, dim=84, steps=steps, seed=17, ids=ids)
+    if game == 'breakout':
+        assert sum(nd for nd, _ in res) >= 3
