@@ -1129,16 +1129,15 @@ PARLHIP_EXPORT int parlhip_impala_loss_f32(const float* blog, const float* tlog,
 // w.r.t. logits / values) moves 5 MB at the reference shape (T=50, B=1024, A=6): launch-bound by
 // construction.  The tensors next to it are not small: the trunk output h [T*B, 256] f32 (52 MB) is
 // read by the two head GEMMs (policy_fc, value_fc: atari_model.py:44-57) and by their weight-gradient
-// GEMMs, and d total / d h (52 MB) is written by their input-gradient GEMMs.  Here one wavefront owns
-// one sequence b: it reads its T rows of h ONCE into registers (lane l holds columns 4l..4l+3 of every
-// row), forms the A+1 head outputs of every row with a butterfly reduction that leaves row t's
-// outputs in lane t (63 shuffles per 64 rows and output instead of 6 per row and output), runs the
-// loss math lane-per-step exactly as impala_loss_wave_kernel does, and then produces d total / d h row
-// by row (one coalesced 1 KiB store each) and the heads' weight / bias gradients from the rows it
-// still holds.  Algorithmic bytes per (t, b) row: 1024 (h) + 1024 (dh) + 4A (behaviour logits) + 8 + 4
-// + 1 in, 8 out for T-1 rows  =>  107 MB per launch at the reference shape instead of 5 MB.
-// Weight-gradient partials: 4 waves through LDS, one partial per workgroup, fixed-order sum
-// (heads_partial_sum_kernel): deterministic.  Time-major, T <= 64, 256 hidden units.
+// GEMMs, and d total / d h (52 MB) is written by their input-gradient GEMMs.  Here the rows of a sequence are
+// read ONCE into registers, the A+1 head outputs of every row are formed, the loss math runs lane-per-step
+// exactly as impala_loss_wave_kernel does, and d total / d h and the heads' weight / bias gradients are
+// produced from the rows still held.  Algorithmic bytes per (t, b) row: 1024 (h) + 1024 (dh) + 4A (behaviour
+// logits) + 8 + 4 + 1 in, 8 out for T-1 rows  =>  107 MB per launch at the reference shape instead of 5 MB.
+// Weight-gradient partials: one per workgroup, fixed-order sum (heads_partial_sum_kernel): deterministic.
+// Time-major, T <= 64, 256 hidden units.  (Rounds 2-4 ran this with TWO waves per sequence, 128 columns each,
+// the rows summed by a 64-lane butterfly and the output gradients broadcast with v_readlane: ~3,800 VALU
+// instructions per wave, two waves per SIMD, 32-33 us; the layout below replaced it in round 5.)
 // ----------------------------------------------------------------------------------------
 template <int A_CT>
 __device__ __forceinline__ void log_softmax_regs(const float (&x)[A_CT], float (&lp)[A_CT]) {
@@ -1168,16 +1167,6 @@ __device__ __forceinline__ void lane_swap16(float& a, float& c) {  // odd 16-lan
   asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(c));
 }
 typedef float f2v __attribute__((ext_vector_type(2)));
-// two independent scalar chains (two outputs of the heads at once): the tree below is a chain of dependent
-// swap / add / DPP operations, a second output in flight fills its bubbles.  (Packing the two into v_pk_* ops
-// was tried: the compiler materialises every row as a splat pair — 200 more registers, scratch spills.)
-struct F2 { float a, b; };
-__device__ __forceinline__ F2 operator+(F2 x, F2 y) { return F2{x.a + y.a, x.b + y.b}; }
-__device__ __forceinline__ void lane_swap32(F2& x, F2& y) { lane_swap32(x.a, y.a); lane_swap32(x.b, y.b); }
-__device__ __forceinline__ void lane_swap16(F2& x, F2& y) { lane_swap16(x.a, y.a); lane_swap16(x.b, y.b); }
-__device__ __forceinline__ float dot2(float2 h, float wx, float wy) { return __builtin_fmaf(h.y, wy, h.x * wx); }
-__device__ __forceinline__ F2 dot2(float2 h, F2 wx, F2 wy) { return F2{dot2(h, wx.a, wy.a), dot2(h, wx.b, wy.b)}; }
-
 template <int DPP_CTRL>
 __device__ __forceinline__ float dpp_partner_add(float keep, float send) {
   return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), DPP_CTRL, 0xf,
@@ -1187,244 +1176,93 @@ template <int DPP_CTRL>
 __device__ __forceinline__ float stage_combine(float x, float y, bool hi) {
   return dpp_partner_add<DPP_CTRL>(hi ? y : x, hi ? x : y);
 }
-template <int DPP_CTRL>
-__device__ __forceinline__ F2 stage_combine(F2 x, F2 y, bool hi) {
-  return F2{stage_combine<DPP_CTRL>(x.a, y.a, hi), stage_combine<DPP_CTRL>(x.b, y.b, hi)};
-}
-
-// Row sums of (h row) . (w of one output, or of two outputs at once: F2) for the <= 64 rows a wave
-// holds: lane t ends up with row t's sum.  Butterfly: at the stage of lane bit `off` the lanes with that bit clear
-// keep the lower half of the rows they still hold, the others the upper half, each adding what its partner
-// holds of the half it keeps.  Stages 32 and 16 are ONE v_permlane32_swap / v_permlane16_swap + one add per pair
-// of values (gfx950: the swap exchanges the upper half / the odd rows of 16 lanes of one register with the lower
-// half / the even rows of a second one — exactly "keep mine, get the partner's"), stages 8..1 are DPP adds
-// (row_mirror, row_half_mirror, quad_perm: the partner differs in the stage's bit, which is all the tree needs).
-// No LDS-crossbar shuffles (the first version used 63 ds_bpermute per output), and the tree is evaluated DEPTH
-// FIRST (four rows down to one value, then one pending value per stage): a handful of live partials instead of 64.
-template <int TMAX, typename V>
-__device__ __forceinline__ V rows4(const float2 (&hr)[TMAX], V wx, V wy, int i) {  // rows i, i+16, i+32, i+48
-  V p0 = dot2(hr[i < TMAX ? i : 0], wx, wy);
-  V p1 = i + 16 < TMAX ? dot2(hr[i + 16 < TMAX ? i + 16 : 0], wx, wy) : V{};
-  V p2 = i + 32 < TMAX ? dot2(hr[i + 32 < TMAX ? i + 32 : 0], wx, wy) : V{};
-  V p3 = i + 48 < TMAX ? dot2(hr[i + 48 < TMAX ? i + 48 : 0], wx, wy) : V{};
-  lane_swap32(p0, p2);   // lanes < 32: rows i (+ the partner's), lanes >= 32: rows i + 32
-  V u0 = p0 + p2;
-  lane_swap32(p1, p3);   // rows i + 16 | i + 48
-  V u1 = p1 + p3;
-  lane_swap16(u0, u1);   // lane bit 4 clear: rows i | i + 32, set: rows i + 16 | i + 48
-  return u0 + u1;
-}
-template <int TMAX, int OFF, typename V>
-__device__ __forceinline__ V rows_tree(const float2 (&hr)[TMAX], V wx, V wy, int lane, int i) {
-  if constexpr (OFF == 16) {
-    return rows4<TMAX, V>(hr, wx, wy, i);
-  } else {
-    const V x = rows_tree<TMAX, OFF * 2, V>(hr, wx, wy, lane, i);
-    const V y = rows_tree<TMAX, OFF * 2, V>(hr, wx, wy, lane, i + OFF);
-    constexpr int ctrl = OFF == 8 ? 0x140 : (OFF == 4 ? 0x141 : (OFF == 2 ? 0x4e : 0xb1));  // row_mirror, row_half_mirror, quad_perm [2,3,0,1], [1,0,3,2]
-    return stage_combine<ctrl>(x, y, (lane & OFF) != 0);
-  }
-}
-template <int TMAX, typename V>
-__device__ __forceinline__ V heads_row_sums(const float2 (&hr)[TMAX], V wx, V wy, int lane) {
-  return rows_tree<TMAX, 1, V>(hr, wx, wy, lane, 0);
-}
-
-// TWO wavefronts per sequence, 128 columns each (lane l: columns half * 128 + 2l, +1): with one wave
-// holding whole rows the kernel needed all 512 VGPRs of a SIMD, could not share it with a resident
-// emulator wave (171 VGPRs) and waited for the env kernel to drain (332 us in the bench against 39 us
-// alone).  Registers decide how many of these waves fit NEXT TO an emulator wave (one per SIMD, always
-// there in the bench): at 255 VGPRs one (the 512 workgroups then run in two rounds: 67 us beside the env
-// kernel against 46 us alone, tools/heads_beside_env.py); at <= 168 two — __launch_bounds__(256, 3) —
-// which the depth-first butterfly below (a handful of live partials instead of 64) reaches without
-// scratch for T <= 50: 47 us beside the env kernel, 43 alone (kernel itself 32.5 us).  The two halves
-// exchange their partial head outputs through LDS and run the (cheap) loss math redundantly; each produces
-// its half of the columns of d total / d h and of the weight gradients.
-// Where the 32.5 us go (variants timed with rocprofv3): loading the 52 MB of h and storing 52 MB straight
-// back takes 18.5 us (5.7 TB/s: the access pattern is fine); + the head outputs 22.0; loss + backward
-// without the forward 25.5.  The phases of a wave do not overlap and neither staggering half of the
-// workgroups nor more ILP (two outputs in flight, packed backward) moves the total: what is left is per-wave
-// latency, two waves per SIMD.
-// (PARLHIP_HEADS_MIN_WAVES: A/B switch.  Since round 4 the emulator holds two 128-VGPR waves per SIMD, so only ONE
-// 168-VGPR wave of this kernel fits beside it; at 4 (<= 128 VGPRs) two would, at the price of 42 spilled registers
-// — compiled, not yet measured: tools/build_obj_variant.sh heads4 scan_kernels.hip -DPARLHIP_HEADS_MIN_WAVES=4)
-#ifndef PARLHIP_HEADS_MIN_WAVES
-#define PARLHIP_HEADS_MIN_WAVES 3
-#endif
-template <int A_CT, int TMAX>  // TMAX >= T: rows held in registers (2 VGPRs each)
-__global__ __launch_bounds__(256, PARLHIP_HEADS_MIN_WAVES) void impala_heads_loss_kernel(
-    const float* __restrict__ h, const float* __restrict__ wpi, const float* __restrict__ bpi,
-    const float* __restrict__ wv, const float* __restrict__ bv, const float* __restrict__ blog,
-    const int64_t* __restrict__ actions, const float* __restrict__ rew, const uint8_t* __restrict__ dones,
-    float* __restrict__ vs, float* __restrict__ pg, float* __restrict__ dh, float* __restrict__ wpart,
-    double* __restrict__ sums, int T, int B, float gamma, float clip_rho, float clip_pg, float vf_coeff,
-    float ent_coeff, int* __restrict__ err) {
-  constexpr int NO = A_CT + 1;  // head outputs per row: A logits + the value
-  constexpr int H = kHeadsHidden;
-  // the wave index as a SCALAR: row base addresses then live in SGPRs (one VGPR lane offset for all
-  // rows); as vector values the 52 row addresses cost 104 VGPRs next to the 104 of the rows themselves
-  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int half = wid & 1, sq = wid >> 1;
-  const int blk = xcd_chunk_block(blockIdx.x, gridDim.x);
-  const int64_t b_raw = (int64_t)blk * 2 + sq;
-  const bool live = b_raw < B;  // waves past the last sequence recompute sequence B-1, everything masked
-  const int64_t b = live ? b_raw : (int64_t)B - 1;
-  const int Tm = T - 1;
-  const int col = half * 128 + 2 * lane;
-
-  // ---- 1. this sequence's rows of h, this wave's 128 columns: all loads in flight at once
-  float2 hr[TMAX];
-#pragma unroll
-  for (int t = 0; t < TMAX; ++t) {
-    hr[t] = make_float2(0.f, 0.f);
-    if (t < T) hr[t] = *(const float2*)(h + ((int64_t)t * B + b) * H + col);
-  }
-  // ---- 2. head outputs: lane t ends up with row t's A logits and value
-  float2 wj[NO];
-#pragma unroll
-  for (int j = 0; j < NO; ++j) wj[j] = *(const float2*)((j < A_CT ? wpi + (size_t)j * H : wv) + col);
-  __shared__ float xch[2][2][NO][64];  // [sequence of the workgroup][half][output][lane = row]
-  float outv[NO];
-#pragma unroll
-  for (int j = 0; j + 1 < NO; j += 2) {  // two outputs at a time
-    const F2 r = heads_row_sums<TMAX, F2>(hr, F2{wj[j].x, wj[j + 1].x}, F2{wj[j].y, wj[j + 1].y}, lane);
-    outv[j] = r.a; outv[j + 1] = r.b;
-    xch[sq][half][j][lane] = r.a; xch[sq][half][j + 1][lane] = r.b;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (NO & 1) {
-    const float r = heads_row_sums<TMAX, float>(hr, wj[NO - 1].x, wj[NO - 1].y, lane);
-    outv[NO - 1] = r;
-    xch[sq][half][NO - 1][lane] = r;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < NO; ++j)  // a + b == b + a: both halves get bit-identical outputs
-    outv[j] = (outv[j] + xch[sq][half ^ 1][j][lane]) + (j < A_CT ? bpi[j] : bv[0]);
-  // ---- 3. the loss, lane per step (impala_loss_wave_kernel with K = 1 on register inputs)
-  const int t = lane;
-  const bool in_t = t < T, valid1 = t < Tm;
-  const int64_t i = (int64_t)(in_t ? t : 0) * B + b;
-  const float v_own = outv[A_CT];
-  const float bootstrap = __shfl(v_own, Tm, 64);
-  float lp[A_CT], p[A_CT], blp[A_CT];
-  {
-    float tl[A_CT];
-#pragma unroll
-    for (int j = 0; j < A_CT; ++j) tl[j] = outv[j];
-    log_softmax_regs<A_CT>(tl, lp);
-    log_softmax_row<A_CT>(blog + i * A_CT, blp);
-  }
-  float Hh = 0.f, kl = 0.f;
-#pragma unroll
-  for (int j = 0; j < A_CT; ++j) {
-    p[j] = expf(lp[j]);
-    Hh -= p[j] * lp[j];
-    kl += p[j] * (lp[j] - blp[j]);
-  }
-  const bool owner = live && half == 0;  // one of the two halves reports the sequence's scalars
-  if (!in_t || !owner) kl = 0.f;
-  float rho[1] = {1.f}, dsc[1] = {0.f}, v[1] = {0.f}, r[1] = {0.f}, vst[1], pgv[1];
-  bool valid[1] = {valid1};
-  int act = 0;
-  float tlp = 0.f;
-  if (valid1) {
-    int a = (int)actions[i];
-    if (a < 0 || a >= A_CT) { *err = 1; a = 0; }
-    act = a;
-    float ta = lp[0], ba = blp[0];
-#pragma unroll
-    for (int j = 1; j < A_CT; ++j) { ta = (j == a) ? lp[j] : ta; ba = (j == a) ? blp[j] : ba; }
-    tlp = ta;
-    dsc[0] = dones[i] ? 0.f : gamma;
-    rho[0] = expf(ta - ba);
-    v[0] = v_own;
-    r[0] = rew[i];
-  }
-  vtrace_wave_core<1>(rho, dsc, v, r, valid, lane, Tm, bootstrap, clip_rho, clip_pg, vst, pgv);
-  float g[NO];  // d total / d (logits, value) of row t; zero for the bootstrap row and beyond
-#pragma unroll
-  for (int j = 0; j < NO; ++j) g[j] = 0.f;
-  float pi = 0.f, vf = 0.f, ent = 0.f;
-  if (valid1 && live) {
-    const float dv = v[0] - vst[0];
-#pragma unroll
-    for (int j = 0; j < A_CT; ++j)
-      g[j] = -pgv[0] * ((j == act ? 1.f : 0.f) - p[j]) - ent_coeff * (p[j] * (lp[j] + Hh));
-    g[A_CT] = vf_coeff * dv;
-    if (half == 0) {
-      const int64_t o = (int64_t)t * B + b;
-      pg[o] = pgv[0];
-      vs[o] = vst[0];
-      pi = -tlp * pgv[0];
-      vf = 0.5f * dv * dv;
-      ent = Hh;
-    }
-  }
-  // ---- 4. backward of the heads: dh rows out, weight gradients from the rows still in registers
-  f2v accw[NO];  // two columns per lane: v_pk_fma_f32 with the row's output gradient as the (scalar) multiplier
-#pragma unroll
-  for (int j = 0; j < NO; ++j) accw[j] = f2v{0.f, 0.f};
-#pragma unroll
-  for (int tt = 0; tt < TMAX; ++tt) {
-    if (tt < T) {
-      f2v d = {0.f, 0.f};
-      const f2v hrow = {hr[tt].x, hr[tt].y};
-#pragma unroll
-      for (int j = 0; j < NO; ++j) {
-        const float gj = lane_bcast(g[j], tt);
-        const f2v gg = {gj, gj};
-        d = __builtin_elementwise_fma(gg, f2v{wj[j].x, wj[j].y}, d);
-        accw[j] = __builtin_elementwise_fma(gg, hrow, accw[j]);
-      }
-      if (live) *(float2*)(dh + ((int64_t)tt * B + b) * H + col) = make_float2(d.x, d.y);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // ---- 5. workgroup partials: [NO][256] weight gradients + [NO] bias gradients, then the loss sums
-  __shared__ float2 redw[2][NO][128];  // [sequence][output][column pair]
-  __shared__ float redb[2][NO + 4];
-#pragma unroll
-  for (int j = 0; j < NO; ++j) {
-    redw[sq][j][half * 64 + lane] = make_float2(accw[j].x, accw[j].y);
-    const float s = wave_sum(g[j]);
-    if (lane == 0 && half == 0) redb[sq][j] = s;
-  }
-  pi = wave_sum(pi); vf = wave_sum(vf); ent = wave_sum(ent); kl = wave_sum(kl);
-  if (lane == 0 && half == 0) { redb[sq][NO] = pi; redb[sq][NO + 1] = vf; redb[sq][NO + 2] = ent; redb[sq][NO + 3] = kl; }
-  __syncthreads();
-  float* wp = wpart + (size_t)blk * (NO * H + NO);
-  for (int k = threadIdx.x; k < NO * 128; k += 256) {
-    const int j = k >> 7, c = k & 127;
-    const float2 a0 = redw[0][j][c], a1 = redw[1][j][c];
-    ((float2*)(wp + (size_t)j * H))[c] = make_float2(a0.x + a1.x, a0.y + a1.y);
-  }
-  if (threadIdx.x < NO) wp[NO * H + threadIdx.x] = redb[0][threadIdx.x] + redb[1][threadIdx.x];
-  if (threadIdx.x < 4) atomicAdd(sums + threadIdx.x, (double)redb[0][NO + threadIdx.x] + (double)redb[1][NO + threadIdx.x]);
-}
-
 // ----------------------------------------------------------------------------------------
-// Round 5: FOUR wavefronts per sequence, rows across the lane groups.
+// FOUR wavefronts per sequence, rows across the lane groups (round 5).
 //
-// The two-wave kernel above spends ~3,800 VALU instructions per wave around an 18.5 us memory part and
-// holds only two waves per SIMD, so its load / compute / store phases do not overlap (33 us).  Here a
-// wave owns 64 columns of its sequence and lane (n = lane & 15, kk = lane >> 4) holds columns
+// A wave owns 64 columns of its sequence and lane (n = lane & 15, kk = lane >> 4) holds columns
 // 64 w + 4 n .. + 3 (one float4) of the rows t = 4 G + kk, G = 0 .. NG-1: one dwordx4 load per row group (four
 // rows x 256 contiguous bytes), NG = 13 registers-of-four for T <= 52.
 //  * head outputs: the lane's 4-column dot product per (G, j), then a butterfly over the 16 lanes of a DPP
-//    row only (the four lane groups hold DIFFERENT rows: nothing to reduce across them) — stages 8, 4, 2, 1 as
-//    row_mirror / row_half_mirror / quad_perm adds over 16 leaves (2 row groups x 8 output slots) per result
+//    row only (the four lane groups hold DIFFERENT rows: nothing to reduce across them) — stages 8 and 4 as two
+//    bank-masked v_add_f32_dpp each (row_mirror / row_half_mirror: the lanes that keep a value are whole banks),
+//    stages 2 and 1 as select + quad_perm add — over 16 leaves (2 row groups x 8 output slots) per result
 //    register, depth first, in row-group order (= load order: the waits for the loads are progressive).
-//    The four column quarters meet in LDS, ONE wave per sequence runs the loss math lane-per-step and hands
-//    d total / d (logits, value) back through LDS in the row-group layout.
-//  * backward: every lane group reads ITS row's 8 gradients (two ds_read_b128, a broadcast inside the group)
-//    — no v_readlane broadcasts — and does 2 x 14 v_pk_fma_f32 per row group: d h (one float4 store, 4 rows x
-//    256 B per instruction) and the weight gradient of its 4 columns.  The four lane groups' weight
-//    gradients are folded with v_permlane32_swap / v_permlane16_swap (two registers per swap + add).
-// Two sequences (eight waves) per workgroup: the partial layout, workspace and heads_partial_sum_kernel
-// are those of the two-wave kernel.  <= 128 VGPRs: four waves per SIMD alone, two beside the emulator.
+//    The four column quarters meet in LDS, ONE wave per sequence runs the loss math lane-per-step (its inputs
+//    fetched and the behaviour policy's log-softmax taken while h is in flight; the V-trace recurrence as a DPP
+//    scan, no LDS-crossbar shuffles) and hands d total / d (logits, value) back through LDS.
+//  * backward: d h = g W on the MATRIX pipe (v_mfma_f32_16x16x4_f32 per 16-row tile and column component: the
+//    four components' result registers are float4s of four rows, stored 4 rows x 256 B per instruction), d W =
+//    g^T h on the vector ALUs (every lane group reads ITS row's 8 gradients with two ds_read_b128 — a broadcast
+//    inside the group, no v_readlane — and does 14 v_pk_fma_f32 per row group); the waves of the workgroup's two
+//    sequences run the two passes in opposite order so that both pipes of a SIMD are busy.  The four lane groups'
+//    weight gradients are folded with v_permlane32_swap / v_permlane16_swap (two registers per swap + add); the
+//    reductions over the steps (bias gradients, loss sums) are taken by two other waves from LDS with DPP adds.
+// Two sequences (eight waves) per workgroup, one partial per workgroup.  <= 128 VGPRs: four waves per SIMD
+// alone, two beside the emulator (the two-wave kernel: 164 VGPRs, one).
+// Measured at (50, 1024, 6) (rocprofv3, kernel only): 32.1 us -> 25.7 us (0.40 -> 0.52 of the HBM peak); beside
+// the emulator 66 -> 47 us.  Where the time goes (diagnostic builds, PARLHIP_HQ_ABL): h in + d h out alone
+// 16.8 us (6.4 TB/s), + head outputs 1.8, + loss 3.3, + backward 3.8 — the phases of a workgroup are separated by
+// barriers and every workgroup of the grid is resident at once, so they add instead of overlapping.
 // ----------------------------------------------------------------------------------------
 typedef float f4v __attribute__((ext_vector_type(4)));
+
+// wave-wide sum without the LDS crossbar: four DPP adds inside each row of 16 lanes (quad_perm, row_half_mirror,
+// row_mirror: every lane ends with its row's total), then the four row totals through the scalar unit
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+  return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_or(float fallback, float x) {  // x of the DPP source lane, `fallback` where there is none
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fallback), __builtin_bit_cast(int, x),
+                                                               CTRL, 0xf, 0xf, false));
+}
+// value of lane + 1 (wave_shl:1; lane 63 gets `last`)
+__device__ __forceinline__ float next_lane(float x, float last) { return dpp_or<0x130>(last, x); }
+
+// vtrace_wave_core<1> (one step per lane) without ds_bpermute: the suffix composition of the affine maps
+// acc_t = d_t + a_t acc_{t+1} is a Hillis-Steele scan inside each row of 16 lanes with row_shl:1,2,4,8 (a lane
+// without a source keeps the identity map: `old` operand, bound_ctrl off), then the three row totals (lane 0 of
+// each row) are composed through v_readlane.  Same arithmetic, a different association of the products than the
+// 64-lane shuffle scan: equal within float rounding (tests: 1e-5 against the CPU oracle).
+__device__ __forceinline__ void vtrace_wave_core_dpp(float rho, float dsc, float v, float r, bool valid, int lane, int Tm,
+                                                     float bootstrap, float clip_rho, float clip_pg, float& vst,
+                                                     float& pgv) {
+  float v_next = next_lane(v, 0.f);
+  if (lane + 1 >= Tm) v_next = bootstrap;
+  const float crho = clip_max(rho, clip_rho);
+  const float c = fminf(rho, 1.0f);
+  const float d_ = valid ? crho * (r + dsc * v_next - v) : 0.f;
+  const float a_ = valid ? dsc * c : 1.f;
+  float SA = a_, SD = d_;
+#define HQ_SCAN_STEP(CTRL)                      \
+  do {                                          \
+    const float oa = dpp_or<CTRL>(1.f, SA);     \
+    const float od = dpp_or<CTRL>(0.f, SD);     \
+    SD = SD + SA * od;                          \
+    SA = SA * oa;                               \
+  } while (0)
+  HQ_SCAN_STEP(0x101);  // row_shl:1
+  HQ_SCAN_STEP(0x102);  // row_shl:2
+  HQ_SCAN_STEP(0x104);  // row_shl:4
+  HQ_SCAN_STEP(0x108);  // row_shl:8
+#undef HQ_SCAN_STEP
+  // carry entering row q = total(row q+1) o total(row q+2) o ... (D part only: acc beyond the wave is 0)
+  const float A1 = lane_bcast(SA, 16), D1 = lane_bcast(SD, 16), A2 = lane_bcast(SA, 32), D2 = lane_bcast(SD, 32);
+  const float D3 = lane_bcast(SD, 48);
+  const float c2 = D3, c1 = D2 + A2 * c2, c0 = D1 + A1 * c1;
+  const int row = lane >> 4;
+  const float cin = row == 0 ? c0 : (row == 1 ? c1 : (row == 2 ? c2 : 0.f));
+  const float suffix = SD + SA * cin;   // acc_t of this lane's step
+  vst = suffix + v;
+  float vs_next = next_lane(vst, 0.f);
+  if (lane + 1 >= Tm) vs_next = bootstrap;
+  pgv = clip_max(rho, clip_pg) * (r + dsc * vs_next - v);
+}
 
 template <int A_CT, int NG, int I>
 __device__ __forceinline__ float hq_leaf(const f4v (&hr)[NG], const f4v (&wj)[A_CT + 1]) {
@@ -1452,14 +1290,14 @@ __device__ __forceinline__ float stage_combine_banks(float x, float y) {
   return r;
 }
 // sum over the 16 lanes of a DPP row of 16 leaves: lane n ends with the row sum of leaf I + n
-template <int A_CT, int NG, int OFF, int I, bool BM>
+template <int A_CT, int NG, int OFF, int I>
 __device__ __forceinline__ float hq_tree(const f4v (&hr)[NG], const f4v (&wj)[A_CT + 1], int lane) {
   if constexpr (OFF == 16) {
     return hq_leaf<A_CT, NG, I>(hr, wj);
   } else {
-    const float x = hq_tree<A_CT, NG, OFF * 2, I, BM>(hr, wj, lane);
-    const float y = hq_tree<A_CT, NG, OFF * 2, I + OFF, BM>(hr, wj, lane);
-    if constexpr (BM && OFF >= 4) {
+    const float x = hq_tree<A_CT, NG, OFF * 2, I>(hr, wj, lane);
+    const float y = hq_tree<A_CT, NG, OFF * 2, I + OFF>(hr, wj, lane);
+    if constexpr (OFF >= 4) {
       return stage_combine_banks<OFF>(x, y);
     } else {
       constexpr int ctrl = OFF == 8 ? 0x140 : (OFF == 4 ? 0x141 : (OFF == 2 ? 0x4e : 0xb1));
@@ -1468,14 +1306,19 @@ __device__ __forceinline__ float hq_tree(const f4v (&hr)[NG], const f4v (&wj)[A_
   }
 }
 
-template <int A_CT, int NG, bool BM>  // 4 NG >= T rows; BM: bank-masked DPP adds in the butterfly
+// diagnostic builds (tools/build_obj_variant.sh hqN scan_kernels.hip -DPARLHIP_HQ_ABL=N): 1 copy h -> d h only,
+// 2 no loss math, 3 no forward trees, 4 no backward arithmetic (d h = h), 5 no weight-gradient pass
+#ifndef PARLHIP_HQ_ABL
+#define PARLHIP_HQ_ABL 0
+#endif
+template <int A_CT, int NG>  // 4 NG >= T rows
 __global__ __launch_bounds__(512, 4) void impala_heads_loss_q_kernel(
     const float* __restrict__ h, const float* __restrict__ wpi, const float* __restrict__ bpi,
     const float* __restrict__ wv, const float* __restrict__ bv, const float* __restrict__ blog,
     const int64_t* __restrict__ actions, const float* __restrict__ rew, const uint8_t* __restrict__ dones,
     float* __restrict__ vs, float* __restrict__ pg, float* __restrict__ dh, float* __restrict__ wpart,
     double* __restrict__ sums, int T, int B, float gamma, float clip_rho, float clip_pg, float vf_coeff,
-    float ent_coeff, int* __restrict__ err, int stagger) {
+    float ent_coeff, int* __restrict__ err) {
   constexpr int NO = A_CT + 1, H = kHeadsHidden, NR = 4 * NG, NQ = (NG + 1) / 2, NRP = 8 * NQ;  // NRP: rows incl. the padding group
   static_assert(NO <= 8, "eight output slots per row");
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1490,16 +1333,11 @@ __global__ __launch_bounds__(512, 4) void impala_heads_loss_q_kernel(
   __shared__ __attribute__((aligned(16))) float gl[2][NR * 8];      // [sequence][row][output slot]: d total / d output
   __shared__ __attribute__((aligned(16))) float redw[2][NO][H];
   __shared__ float redb[2][NO + 4];
+  __shared__ __attribute__((aligned(16))) float sl[2][64][4];      // [sequence][step]: pi, vf, entropy, kl terms
 
-  // Two cohorts: every workgroup is resident at once (1024 sequences = four waves per SIMD), so without this all
-  // of them load, then all compute, then all store, and the HBM idles while the VALUs work.  The second half of
-  // the grid (the second workgroup of every CU) starts `stagger` x 1024 clocks later: its loads stream in under
-  // the first cohort's arithmetic, its arithmetic runs under the first cohort's stores.
-  if (stagger > 0) {  // stagger = clocks / 1024 (+ 1000: alternate workgroups of an XCD instead of grid halves)
-    const bool late = stagger >= 1000 ? ((blockIdx.x >> 3) & 1) != 0 : blockIdx.x >= (gridDim.x >> 1);
-    if (late)
-      for (int i = 0; i < stagger % 1000; ++i) __builtin_amdgcn_s_sleep(16);
-  }
+  // (A start delay for half of the workgroups — so that one cohort's loads stream in under the other's arithmetic —
+  // was measured with this layout too: 26.4 us at 0, 27.2 / 28.5 / 30.2 us at 3.4 / 5.1 / 6.8 us of delay, for grid
+  // halves and for alternating workgroups alike.  Removed.)
   // ---- 1. loads: row group G = rows 4G + kk, this wave's 64 columns.  Rows past T-1 re-read row T-1: their head
   // outputs are never used, their output gradients are zero (so they add nothing to the weight gradients) and
   // their d h rows are not stored — no zero fill, no divergent branch.
@@ -1508,25 +1346,59 @@ __global__ __launch_bounds__(512, 4) void impala_heads_loss_q_kernel(
   f4v hr[NG];
 #pragma unroll
   for (int G = 0; G < NG; ++G) hr[G] = *(const f4v*)(hb + (size_t)min(4 * G + kk, Tm) * BH);
+  if constexpr (PARLHIP_HQ_ABL == 1) {
+    float* dq = dh + b * H + 64 * w + 4 * n;
+#pragma unroll
+    for (int G = 0; G < NG; ++G)
+      if (live && 4 * G + kk < T) *(f4v*)(dq + (size_t)(4 * G + kk) * BH) = hr[G];
+    return;
+  }
   f4v wj[NO];
 #pragma unroll
   for (int j = 0; j < NO; ++j) wj[j] = *(const f4v*)((j < A_CT ? wpi + (size_t)j * H : wv) + 64 * w + 4 * n);
+  // The loss wave of the sequence fetches ITS inputs now (behaviour logits, action, reward, done of step t = lane)
+  // and takes the behaviour policy's log-softmax while the rows of h are still in flight: after the forward
+  // these loads would be an exposed HBM round trip with the whole workgroup waiting at the barrier behind it.
+  const bool loss_wave = w == ((int)b_raw & 3);   // spread over the SIMDs
+  const int t = lane;
+  const bool in_t = t < T, valid1 = t < Tm;
+  const int64_t i = (int64_t)(in_t ? t : 0) * B + b;
+  float blp[A_CT], bias[NO], r_in = 0.f, dsc_in = 0.f;
+  int act = 0;
+#pragma unroll
+  for (int j = 0; j < A_CT; ++j) blp[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < NO; ++j) bias[j] = 0.f;
+  if (loss_wave) {
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {  // scalar loads: pinned here, not behind the barrier where they are used
+      bias[j] = j < A_CT ? bpi[j] : bv[0];
+      asm volatile("" : "+s"(bias[j]));
+    }
+    log_softmax_row<A_CT>(blog + i * A_CT, blp);
+    if (valid1) {
+      int a = (int)actions[i];
+      if (a < 0 || a >= A_CT) { *err = 1; a = 0; }
+      act = a;
+      dsc_in = dones[i] ? 0.f : gamma;
+      r_in = rew[i];
+    }
+  }
   // ---- 2. head outputs of this column quarter: result register q, lane (n, kk) = row 4 (2q + (n >> 3)) + kk, slot n & 7
   {
     float* xw = &xl[sq][w][32 * (n >> 3) + 8 * kk + (n & 7)];
-#define HQ_TREE(Q) if constexpr (Q < NQ) { xw[64 * Q] = hq_tree<A_CT, NG, 1, 16 * Q, BM>(hr, wj, lane); }
+#define HQ_TREE(Q) if constexpr (Q < NQ && PARLHIP_HQ_ABL != 3) { xw[64 * Q] = hq_tree<A_CT, NG, 1, 16 * Q>(hr, wj, lane); }
     HQ_TREE(0) HQ_TREE(1) HQ_TREE(2) HQ_TREE(3) HQ_TREE(4) HQ_TREE(5) HQ_TREE(6) HQ_TREE(7)
 #undef HQ_TREE
   }
   __syncthreads();
-  // ---- 3. the loss on ONE wave per sequence, lane per step (impala_loss_wave_kernel, K = 1)
+  // ---- 3. the loss on ONE wave per sequence, lane per step (impala_loss_wave_kernel, K = 1).  Only what the
+  // other waves wait for — d total / d (logits, value) — comes before the barrier; the outputs and the sums after it.
   float g[NO];
 #pragma unroll
   for (int j = 0; j < NO; ++j) g[j] = 0.f;
-  float pi = 0.f, vf = 0.f, ent = 0.f, kl = 0.f;
-  if (w == ((int)b_raw & 3)) {  // the loss wave of sequence b (spread over the SIMDs)
-    const int t = lane;
-    const bool in_t = t < T, valid1 = t < Tm;
+  float pi = 0.f, vf = 0.f, ent = 0.f, kl = 0.f, vs_t = 0.f, pg_t = 0.f;
+  if (loss_wave && PARLHIP_HQ_ABL != 2) {
     const int tr = t < NR ? t : 0;
     float o8[8];
     {
@@ -1536,23 +1408,21 @@ __global__ __launch_bounds__(512, 4) void impala_heads_loss_q_kernel(
       const f4v* x3 = (const f4v*)&xl[sq][3][tr * 8];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const f4v s = (x0[q] + x1[q]) + (x2[q] + x3[q]);
-        o8[4 * q] = s.x; o8[4 * q + 1] = s.y; o8[4 * q + 2] = s.z; o8[4 * q + 3] = s.w;
+        const f4v sm = (x0[q] + x1[q]) + (x2[q] + x3[q]);
+        o8[4 * q] = sm.x; o8[4 * q + 1] = sm.y; o8[4 * q + 2] = sm.z; o8[4 * q + 3] = sm.w;
       }
     }
     float outv[NO];
 #pragma unroll
-    for (int j = 0; j < NO; ++j) outv[j] = o8[j] + (j < A_CT ? bpi[j] : bv[0]);
-    const int64_t i = (int64_t)(in_t ? t : 0) * B + b;
+    for (int j = 0; j < NO; ++j) outv[j] = o8[j] + bias[j];
     const float v_own = outv[A_CT];
-    const float bootstrap = __shfl(v_own, Tm, 64);
-    float lp[A_CT], p[A_CT], blp[A_CT];
+    const float bootstrap = lane_bcast(v_own, Tm);
+    float lp[A_CT], p[A_CT];
     {
       float tl[A_CT];
 #pragma unroll
       for (int j = 0; j < A_CT; ++j) tl[j] = outv[j];
       log_softmax_regs<A_CT>(tl, lp);
-      log_softmax_row<A_CT>(blog + i * A_CT, blp);
     }
     float Hh = 0.f;
 #pragma unroll
@@ -1562,34 +1432,25 @@ __global__ __launch_bounds__(512, 4) void impala_heads_loss_q_kernel(
       kl += p[j] * (lp[j] - blp[j]);
     }
     if (!in_t || !live) kl = 0.f;
-    float rho[1] = {1.f}, dsc[1] = {0.f}, v[1] = {0.f}, r[1] = {0.f}, vst[1], pgv[1];
-    bool valid[1] = {valid1};
-    int act = 0;
-    float tlp = 0.f;
+    float rho = 1.f, v_t = 0.f, tlp = 0.f, vst, pgv;
     if (valid1) {
-      int a = (int)actions[i];
-      if (a < 0 || a >= A_CT) { *err = 1; a = 0; }
-      act = a;
       float ta = lp[0], ba = blp[0];
 #pragma unroll
-      for (int j = 1; j < A_CT; ++j) { ta = (j == a) ? lp[j] : ta; ba = (j == a) ? blp[j] : ba; }
+      for (int j = 1; j < A_CT; ++j) { ta = (j == act) ? lp[j] : ta; ba = (j == act) ? blp[j] : ba; }
       tlp = ta;
-      dsc[0] = dones[i] ? 0.f : gamma;
-      rho[0] = expf(ta - ba);
-      v[0] = v_own;
-      r[0] = rew[i];
+      rho = expf(ta - ba);
+      v_t = v_own;
     }
-    vtrace_wave_core<1>(rho, dsc, v, r, valid, lane, Tm, bootstrap, clip_rho, clip_pg, vst, pgv);
+    vtrace_wave_core_dpp(rho, dsc_in, v_t, r_in, valid1, lane, Tm, bootstrap, clip_rho, clip_pg, vst, pgv);
     if (valid1 && live) {
-      const float dv = v[0] - vst[0];
+      const float dv = v_t - vst;
 #pragma unroll
       for (int j = 0; j < A_CT; ++j)
-        g[j] = -pgv[0] * ((j == act ? 1.f : 0.f) - p[j]) - ent_coeff * (p[j] * (lp[j] + Hh));
+        g[j] = -pgv * ((j == act ? 1.f : 0.f) - p[j]) - ent_coeff * (p[j] * (lp[j] + Hh));
       g[A_CT] = vf_coeff * dv;
-      const int64_t o = (int64_t)t * B + b;
-      pg[o] = pgv[0];
-      vs[o] = vst[0];
-      pi = -tlp * pgv[0];
+      pg_t = pgv;
+      vs_t = vst;
+      pi = -tlp * pgv;
       vf = 0.5f * dv * dv;
       ent = Hh;
     }
@@ -1599,58 +1460,113 @@ __global__ __launch_bounds__(512, 4) void impala_heads_loss_q_kernel(
       go[1] = f4v{NO > 4 ? g[NO > 4 ? 4 : 0] : 0.f, NO > 5 ? g[NO > 5 ? 5 : 0] : 0.f, NO > 6 ? g[NO > 6 ? 6 : 0] : 0.f,
                   NO > 7 ? g[NO > 7 ? 7 : 0] : 0.f};
     }
-#pragma unroll
-    for (int j = 0; j < NO; ++j) {
-      const float s = wave_sum(g[j]);
-      if (lane == 0) redb[sq][j] = s;
-    }
-    pi = wave_sum(pi); vf = wave_sum(vf); ent = wave_sum(ent); kl = wave_sum(kl);
-    if (lane == 0) { redb[sq][NO] = pi; redb[sq][NO + 1] = vf; redb[sq][NO + 2] = ent; redb[sq][NO + 3] = kl; }
+    *(f4v*)&sl[sq][t][0] = f4v{pi, vf, ent, kl};
   }
   __syncthreads();
-  // ---- 4. backward in two passes over the row groups (each reads its row's 8 gradients from LDS: two
-  // ds_read_b128, a broadcast inside the lane group), so that the head weights (28 registers) and the weight
-  // gradient accumulators (28) are never live together:  (a) d h = sum_j g_j W_j, stored as it is formed (the
-  // stores drain under pass b);  (b) d W_j += g_j h for this lane's four columns.
-  {
-    const float* wq = wpi;  // opaque copies: the weights are RE-loaded here (L1 / L2 hits) instead of living across the loss
-    const float* vq = wv;
-    asm volatile("" : "+s"(wq), "+s"(vq));
-    f4v w2[NO];
+  // after the barrier every wave goes into its backward; the loss wave only stores its two outputs, and the
+  // reductions over the steps (bias gradients, loss sums) are taken by the sequence's next two waves from LDS
+  if (loss_wave && valid1 && live) {
+    const int64_t o = (int64_t)t * B + b;
+    pg[o] = pg_t;
+    vs[o] = vs_t;
+  }
+  if (w == (((int)b_raw + 1) & 3)) {        // d total / d bias_j = sum_t g[t][j]
+    const f4v* gp = (const f4v*)&gl[sq][(t < NR ? t : 0) * 8];
+    f4v a0 = gp[0], a1 = gp[1];
+    if (t >= NR) { a0 = f4v{0.f, 0.f, 0.f, 0.f}; a1 = a0; }
+    const float gs[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-    for (int j = 0; j < NO; ++j) w2[j] = *(const f4v*)((j < A_CT ? wq + (size_t)j * H : vq) + 64 * w + 4 * n);
-    float* dhb = dh + b * H + 64 * w + 4 * n;
+    for (int j = 0; j < NO; ++j) {
+      const float sm = wave_sum_dpp(gs[j]);
+      if (lane == 0) redb[sq][j] = sm;
+    }
+  } else if (w == (((int)b_raw + 2) & 3)) {  // pi_loss, vf_loss, entropy, kl
+    const f4v x = *(const f4v*)&sl[sq][t][0];
+    const float s0 = wave_sum_dpp(x.x), s1 = wave_sum_dpp(x.y), s2 = wave_sum_dpp(x.z), s3 = wave_sum_dpp(x.w);
+    if (lane == 0) { redb[sq][NO] = s0; redb[sq][NO + 1] = s1; redb[sq][NO + 2] = s2; redb[sq][NO + 3] = s3; }
+  }
+  // ---- 4. backward.  d h = g W on the matrix pipe, d W = g^T h on the vector ALUs; the waves of the workgroup's
+  // first sequence run d W first, those of the second d h first, so that every SIMD (two waves of each kind) has
+  // both pipes busy (as VALU code alone the two passes were 4.7 us of this kernel: 364 v_pk_fma per wave, four waves
+  // per SIMD).
+  //   d h: v_mfma_f32_16x16x4_f32 per tile of 16 rows and per column component c (column 64 w + 4 n + c):
+  //        A[i = row][k = j] = g[16 tau + i][4 s + k] (one ds_read_b32 per k-step s = 0, 1), B[k = j][n] = W_j[column],
+  //        D[row 4 (lane >> 4) + r][n]: the four components' register r are one float4 of row 16 tau + 4 (lane >> 4) + r.
+  //   d W: per row group its row's 8 gradients from LDS (two ds_read_b128, a broadcast inside the lane group) and
+  //        14 v_pk_fma_f32 on the lane's four columns.
+  f2v acc[NO][2];
+  auto pass_dw = [&]() {
 #pragma unroll
-    for (int G = 0; G < NG; ++G) {
+    for (int j = 0; j < NO; ++j) acc[j][0] = acc[j][1] = f2v{0.f, 0.f};
+#pragma unroll
+    for (int G = 0; G < ((PARLHIP_HQ_ABL == 4 || PARLHIP_HQ_ABL == 5) ? 0 : NG); ++G) {
       const f4v* gp = (const f4v*)&gl[sq][(4 * G + kk) * 8];
       const f4v g0 = gp[0], g1 = gp[1];
       const float gr[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-      f2v d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
+      const f2v h0 = {hr[G].x, hr[G].y}, h1 = {hr[G].z, hr[G].w};
 #pragma unroll
       for (int j = 0; j < NO; ++j) {
         const f2v gg = {gr[j], gr[j]};
-        d0 = __builtin_elementwise_fma(gg, f2v{w2[j].x, w2[j].y}, d0);
-        d1 = __builtin_elementwise_fma(gg, f2v{w2[j].z, w2[j].w}, d1);
+        acc[j][0] = __builtin_elementwise_fma(gg, h0, acc[j][0]);
+        acc[j][1] = __builtin_elementwise_fma(gg, h1, acc[j][1]);
       }
-      if (live && 4 * G + kk < T) *(f4v*)(dhb + (size_t)(4 * G + kk) * BH) = f4v{d0.x, d0.y, d1.x, d1.y};
     }
-  }
-  f2v acc[NO][2];
+  };
+  auto pass_dh = [&]() {
+    const float* wq = wpi;  // opaque copies: the weights are RE-loaded here (L1 / L2 hits) instead of living across the loss
+    const float* vq = wv;
+    asm volatile("" : "+s"(wq), "+s"(vq));
+    f4v wB[2];   // k-step s: W_j, j = min(4 s + kk, A) (the value head is output A; slots past it carry zero gradients)
 #pragma unroll
-  for (int j = 0; j < NO; ++j) acc[j][0] = acc[j][1] = f2v{0.f, 0.f};
-#pragma unroll
-  for (int G = 0; G < NG; ++G) {
-    const f4v* gp = (const f4v*)&gl[sq][(4 * G + kk) * 8];
-    const f4v g0 = gp[0], g1 = gp[1];
-    const float gr[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-    const f2v h0 = {hr[G].x, hr[G].y}, h1 = {hr[G].z, hr[G].w};
-#pragma unroll
-    for (int j = 0; j < NO; ++j) {
-      const f2v gg = {gr[j], gr[j]};
-      acc[j][0] = __builtin_elementwise_fma(gg, h0, acc[j][0]);
-      acc[j][1] = __builtin_elementwise_fma(gg, h1, acc[j][1]);
+    for (int sk = 0; sk < 2; ++sk) {
+      const int j = min(4 * sk + kk, A_CT);
+      wB[sk] = *(const f4v*)((j < A_CT ? wq + (size_t)j * H : vq) + 64 * w + 4 * n);
     }
+    float* dhb = dh + b * H + 64 * w + 4 * n + (size_t)(4 * kk) * BH;   // row 4 kk of a tile
+    constexpr int NT = (NG + 3) / 4;
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+      f4v D[4];
+      if constexpr (PARLHIP_HQ_ABL != 4) {
+        const int ar = min(16 * tau + n, NR - 1) * 8 + kk;
+        const float a0 = gl[sq][ar], a1 = gl[sq][ar + 4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          D[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wB[0][c], f4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          D[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wB[1][c], D[c], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) D[c] = hr[0];
+      }
+      float* dt = dhb + (size_t)(16 * tau) * BH;
+      if (live && 16 * tau + 16 <= T) {   // wave-uniform: a whole tile, four unconditional stores
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *(f4v*)(dt + (size_t)r * BH) = f4v{D[0][r], D[1][r], D[2][r], D[3][r]};
+      } else if (live) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * tau + 4 * kk + r < T) *(f4v*)(dt + (size_t)r * BH) = f4v{D[0][r], D[1][r], D[2][r], D[3][r]};
+      }
+    }
+  };
+  // (the fence keeps the second pass's LDS reads behind the first pass: hoisted above it they spilled 90 registers)
+  // (gl's address is handed to the asm: a __shared__ array nobody takes the address of is invisible to a "memory" clobber)
+#define HQ_PASS_FENCE() asm volatile("" : : "v"(&gl[0][0]) : "memory")
+  if (sq == 0) {
+    pass_dw();
+    // the accumulators are pinned here: the arithmetic of the d W pass otherwise SINKS below the d h pass to its
+    // first use (the fold), with the 91 gradient registers it reads kept alive across the MFMAs (spills)
+#pragma unroll
+    for (int j = 0; j < NO; ++j) asm volatile("" : "+v"(acc[j][0]), "+v"(acc[j][1]));
+    HQ_PASS_FENCE();
+    pass_dh();
+  } else {
+    pass_dh();
+    HQ_PASS_FENCE();
+    pass_dw();
   }
+#undef HQ_PASS_FENCE
   // ---- 5. fold the four lane groups (rows mod 4): register r = 7 c + j holds column component c of output j;
   // swap32 + add folds registers r | r + 2 NO (lanes < 32 keep r), swap16 + add r | r + NO: lane group kk ends
   // with component c = kk of every output: d W[j][64 w + 4 n + kk]
@@ -1729,7 +1645,6 @@ PARLHIP_EXPORT int parlhip_impala_heads_loss_f32(const float* hidden, const floa
                                                  parlhip_stream_t stream) {
   if (T < 2 || B < 0 || A < 1) return PARLHIP_EINVAL;
   if (T > 64 || hidden_units != kHeadsHidden) return PARLHIP_ENOSUP;
-  const bool small = T <= 50;  // the reference's sample_batch_steps is 50 (impala_config.py)
   if (B == 0) return PARLHIP_OK;
   if (!hidden || !w_policy || !b_policy || !w_value || !b_value || !behaviour_logits || !actions || !rewards ||
       !dones || !vs || !pg || !grad_hidden || !grad_heads || !sums || !workspace)
@@ -1743,28 +1658,18 @@ PARLHIP_EXPORT int parlhip_impala_heads_loss_f32(const float* hidden, const floa
   if (!err) return PARLHIP_ELAUNCH;
   const int nblk = ceil_div(B, 2);  // two sequences (four half-sequence waves) per workgroup
   float* wpart = (float*)workspace;
-#define HLT(AA, TT)                                                                                            \
-  impala_heads_loss_kernel<AA, TT><<<nblk, 256, 0, s>>>(hidden, w_policy, b_policy, w_value, b_value,         \
+#define HQT(AA, NGG)                                                                                           \
+  impala_heads_loss_q_kernel<AA, NGG><<<nblk, 512, 0, s>>>(hidden, w_policy, b_policy, w_value, b_value,      \
       behaviour_logits, actions, rewards, dones, vs, pg, grad_hidden, wpart, sums, T, B, gamma, clip_rho,     \
       clip_pg, vf_coeff, ent_coeff, err)
-#define HQT(AA, NGG, BMM)                                                                                      \
-  impala_heads_loss_q_kernel<AA, NGG, BMM><<<nblk, 512, 0, s>>>(hidden, w_policy, b_policy, w_value, b_value,      \
-      behaviour_logits, actions, rewards, dones, vs, pg, grad_hidden, wpart, sums, T, B, gamma, clip_rho,     \
-      clip_pg, vf_coeff, ent_coeff, err, stagger)
-  static const int stagger = [] { const char* e = getenv("PARLHIP_HEADS_STAGGER"); return e ? atoi(e) : 0; }();
-  // A/B switch while both layouts are measured: PARLHIP_HEADS_KERNEL=2 selects the two-waves-per-sequence kernel
-  static const int variant = [] { const char* e = getenv("PARLHIP_HEADS_KERNEL"); return e ? atoi(e) : 4; }();
   if (B > (1 << 20)) return PARLHIP_ENOSUP;  // 32-bit lane offsets of the row-group layout
-#define HL(AA) do { if (variant == 2) { if (small) HLT(AA, 50); else HLT(AA, 64); }                            \
-                    else if (variant == 5) { if (T <= 52) HQT(AA, 13, true); else HQT(AA, 16, true); }        \
-                    else { if (T <= 52) HQT(AA, 13, false); else HQT(AA, 16, false); } } while (0)
+#define HL(AA) do { if (T <= 52) HQT(AA, 13); else HQT(AA, 16); } while (0)
   switch (A) {
     case 4: HL(4); break;
     case 6: HL(6); break;
     default: return PARLHIP_ENOSUP;  // other action counts: parlhip_impala_loss_f32 behind the framework's heads
   }
 #undef HL
-#undef HLT
 #undef HQT
   const int n = (A + 1) * kHeadsHidden + (A + 1);
   heads_partial_sum_kernel<<<ceil_div(n, 8), 256, 0, s>>>(wpart, nblk, n, grad_heads);
