@@ -215,6 +215,16 @@ int parlhip_policy_head_sample_f32(const float* hidden, const float* w_policy, c
                                    float* logits_out, int64_t* actions, int B, int hidden_units, int A,
                                    uint64_t seed, uint64_t offset, uint64_t row0, parlhip_stream_t stream);
 
+/* The same launch with the Philox offset = *offset_base (a uint64 in DEVICE memory) + offset: the actors' whole
+ * rollout (examples/IMPALA/actor.py:58-76, T env steps) is replayed as a hipGraph whose kernel arguments are
+ * frozen — the number of the rollout's first step is the one thing that changes between replays, so it is read
+ * from memory; `offset` is then the step's index inside the rollout.  Draws the same actions as the entry above
+ * called with offset = *offset_base + offset.                                                             */
+int parlhip_policy_head_sample_at_f32(const float* hidden, const float* w_policy, const float* b_policy,
+                                      float* logits_out, int64_t* actions, int B, int hidden_units, int A,
+                                      uint64_t seed, const uint64_t* offset_base, uint64_t offset, uint64_t row0,
+                                      parlhip_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Frame pipeline: MaxAndSkipEnv max + WarpFrame
  * parl/env/atari_wrappers.py:239 (obs_buffer.max(axis=0)), :263-267 (cv2 RGB2GRAY +

@@ -56,6 +56,7 @@ SIGNATURES = {
     'parlhip_adv_normalize_f32': (_i, [_p, _p, _p, _i64, _f, _p, _sz, _p, _p]),
     'parlhip_categorical_sample_f32': (_i, [_p, _p, _p, _i, _i, _p]),
     'parlhip_policy_head_sample_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _u64, _u64, _u64, _p]),
+    'parlhip_policy_head_sample_at_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _u64, _p, _u64, _u64, _p]),
     'parlhip_policy_sample_f32':
     (_i, [_p, _i, _p, _p, _p, _i, _i, _u64, _u64, _u64, _p]),
     'parlhip_frame_post_tables_bytes': (_sz, [_i]),

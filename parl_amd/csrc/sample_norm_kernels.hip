@@ -80,10 +80,11 @@ template <int A_MAX>
 __global__ __launch_bounds__(256) void policy_head_sample_kernel(
     const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ logits_out, int64_t* __restrict__ actions, int B, int A, uint64_t seed, uint64_t offset,
-    uint64_t row0) {
+    uint64_t row0, const uint64_t* __restrict__ offset_base) {
   const int lane = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;  // whole wave
+  if (offset_base) offset += *offset_base;  // the rollout's first step lives in device memory (hipGraph replays)
   const float4 hv = ((const float4*)(h + b * 256))[lane];
   float row[A_MAX];
 #pragma unroll
@@ -212,10 +213,10 @@ PARLHIP_EXPORT int parlhip_categorical_sample_f32(const float* probs, const doub
   return check_launch();
 }
 
-PARLHIP_EXPORT int parlhip_policy_head_sample_f32(const float* hidden, const float* w_policy, const float* b_policy,
-                                                  float* logits_out, int64_t* actions, int B, int hidden_units, int A,
-                                                  uint64_t seed, uint64_t offset, uint64_t row0,
-                                                  parlhip_stream_t stream) {
+static int launch_policy_head_sample(const float* hidden, const float* w_policy, const float* b_policy,
+                                     float* logits_out, int64_t* actions, int B, int hidden_units, int A,
+                                     uint64_t seed, uint64_t offset, uint64_t row0, const uint64_t* offset_base,
+                                     parlhip_stream_t stream) {
   if (B < 0 || A < 1) return PARLHIP_EINVAL;
   if (hidden_units != 256 || A > 18) return PARLHIP_ENOSUP;
   if (B == 0) return PARLHIP_OK;
@@ -224,11 +225,28 @@ PARLHIP_EXPORT int parlhip_policy_head_sample_f32(const float* hidden, const flo
   hipStream_t s = (hipStream_t)stream;
   if (A <= 6)
     policy_head_sample_kernel<6><<<ceil_div(B, 4), 256, 0, s>>>(hidden, w_policy, b_policy, logits_out, actions, B, A,
-                                                                 seed, offset, row0);
+                                                                 seed, offset, row0, offset_base);
   else
     policy_head_sample_kernel<18><<<ceil_div(B, 4), 256, 0, s>>>(hidden, w_policy, b_policy, logits_out, actions, B, A,
-                                                                  seed, offset, row0);
+                                                                  seed, offset, row0, offset_base);
   return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_policy_head_sample_f32(const float* hidden, const float* w_policy, const float* b_policy,
+                                                  float* logits_out, int64_t* actions, int B, int hidden_units, int A,
+                                                  uint64_t seed, uint64_t offset, uint64_t row0,
+                                                  parlhip_stream_t stream) {
+  return launch_policy_head_sample(hidden, w_policy, b_policy, logits_out, actions, B, hidden_units, A, seed, offset,
+                                   row0, nullptr, stream);
+}
+
+PARLHIP_EXPORT int parlhip_policy_head_sample_at_f32(const float* hidden, const float* w_policy, const float* b_policy,
+                                                     float* logits_out, int64_t* actions, int B, int hidden_units,
+                                                     int A, uint64_t seed, const uint64_t* offset_base,
+                                                     uint64_t offset, uint64_t row0, parlhip_stream_t stream) {
+  if (!offset_base) return PARLHIP_EINVAL;
+  return launch_policy_head_sample(hidden, w_policy, b_policy, logits_out, actions, B, hidden_units, A, seed, offset,
+                                   row0, offset_base, stream);
 }
 
 PARLHIP_EXPORT int parlhip_policy_sample_f32(const float* x, int is_logits, int64_t* actions,

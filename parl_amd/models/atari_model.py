@@ -125,13 +125,18 @@ class AtariModel42(Model):
         """policy(obs) written straight into `out` (a [E, A] slab of a rollout buffer)"""
         return torch.addmm(self.policy_fc.bias, self._trunk(obs), self.policy_fc.weight.t(), out=out)
 
+    supports_offset_base = True   # policy_sample_into(offset_base=...): the rollout may be replayed as a hipGraph
+
     @torch.no_grad()
-    def policy_sample_into(self, obs, logits_out, actions_out, seed, offset, row0=0):
+    def policy_sample_into(self, obs, logits_out, actions_out, seed, offset, row0=0, offset_base=None):
         """the actors' step: policy(obs) into `logits_out` AND the sampled actions into `actions_out` (slabs of
-        a rollout buffer), head + draw in one launch (ops.policy_head_sample_into)"""
+        a rollout buffer), head + draw in one launch (ops.policy_head_sample_into).  offset_base: int64 [1] device
+        tensor added to `offset` on the device (DeviceRollout keeps the number of the rollout's first step there)."""
         h = self._trunk(obs)
         if not ops.policy_head_sample_into(h, self.policy_fc.weight, self.policy_fc.bias, logits_out, actions_out,
-                                           seed, offset, row0):
+                                           seed, offset, row0, offset_base):
+            if offset_base is not None:
+                raise RuntimeError('policy_sample_into: no fused head + draw for this shape, offset_base unsupported')
             torch.addmm(self.policy_fc.bias, h, self.policy_fc.weight.t(), out=logits_out)
             ops.policy_sample_into(logits_out, actions_out, seed, offset, row0)
 

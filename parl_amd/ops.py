@@ -398,19 +398,28 @@ def policy_sample_into(logits, actions_out, seed, offset, row0=0):
     return actions_out
 
 
-def policy_head_sample_into(hidden, w_policy, b_policy, logits_out, actions_out, seed, offset, row0=0):
+def policy_head_sample_into(hidden, w_policy, b_policy, logits_out, actions_out, seed, offset, row0=0, offset_base=None):
     """policy_fc + policy_sample in one launch for the actors: logits_out [B,A] f32 and actions_out [B] int64 are
-    slabs of a rollout buffer; hidden f32 [B,256].  Returns False when the library has no instantiation (the
-    caller then runs the framework's head + policy_sample_into)."""
+    slabs of a rollout buffer; hidden f32 [B,256].  offset_base: an int64 [1] device tensor added to `offset` on the
+    device (a rollout replayed as a hipGraph keeps the number of its first step there).  Returns False when the
+    library has no instantiation (the caller then runs the framework's head + policy_sample_into)."""
     hd = _f32(hidden, 'hidden')
     B, H = hd.shape
     A = w_policy.shape[0]
     if H != 256 or A > 18 or logits_out.dtype != torch.float32 or not logits_out.is_contiguous():
         return False
     wp, bp = _f32(w_policy.detach(), 'w_policy'), _f32(b_policy.detach(), 'b_policy')
-    code = N.lib().parlhip_policy_head_sample_f32(N.ptr(hd), N.ptr(wp), N.ptr(bp), N.ptr(logits_out), N.ptr(actions_out),
-                                                  B, H, A, int(seed) & (2**64 - 1), int(offset) & (2**64 - 1),
-                                                  int(row0) & (2**64 - 1), N.stream_ptr())
+    if offset_base is not None:
+        if offset_base.dtype != torch.int64 or offset_base.numel() != 1 or not offset_base.is_cuda:
+            raise N.ParlHipError('offset_base must be an int64 [1] device tensor')
+        code = N.lib().parlhip_policy_head_sample_at_f32(N.ptr(hd), N.ptr(wp), N.ptr(bp), N.ptr(logits_out),
+                                                         N.ptr(actions_out), B, H, A, int(seed) & (2**64 - 1),
+                                                         N.ptr(offset_base), int(offset) & (2**64 - 1),
+                                                         int(row0) & (2**64 - 1), N.stream_ptr())
+    else:
+        code = N.lib().parlhip_policy_head_sample_f32(N.ptr(hd), N.ptr(wp), N.ptr(bp), N.ptr(logits_out), N.ptr(actions_out),
+                                                      B, H, A, int(seed) & (2**64 - 1), int(offset) & (2**64 - 1),
+                                                      int(row0) & (2**64 - 1), N.stream_ptr())
     if code == ENOSUP:
         return False
     N.check(code, 'parlhip_policy_head_sample_f32')

@@ -16,11 +16,16 @@ import torch
 from . import ops
 
 
-def _policy_and_draw(model, obs, logits_out, actions_out, seed, offset, row0):
-    """behaviour logits of `obs` into the [E, A] slab and the sampled actions into the [E] slab"""
+def _policy_and_draw(model, obs, logits_out, actions_out, seed, offset, row0, offset_base=None):
+    """behaviour logits of `obs` into the [E, A] slab and the sampled actions into the [E] slab; the Philox offset
+    is `offset` (+ *offset_base on the device, for a model whose policy_sample_into takes one)"""
     if hasattr(model, 'policy_sample_into'):  # head + draw in one launch
-        model.policy_sample_into(obs, logits_out, actions_out, seed, offset, row0)
+        if offset_base is not None:
+            model.policy_sample_into(obs, logits_out, actions_out, seed, offset, row0, offset_base=offset_base)
+        else:
+            model.policy_sample_into(obs, logits_out, actions_out, seed, offset, row0)
         return
+    assert offset_base is None
     if hasattr(model, 'policy_into'):
         model.policy_into(obs, logits_out)  # the head's GEMM writes the slab directly
     else:
@@ -52,6 +57,11 @@ class DeviceRollout(object):
         self._slots = (torch.arange(T, dtype=torch.int32, device=dev) + 3).repeat_interleave(E)
         self._envs = torch.arange(E, dtype=torch.int32, device=dev).repeat(T)
         self.step_count = 0  # Philox offset: one uniform per (global step, env)
+        # the number of the current rollout's first step ON THE DEVICE (collect_begin): a rollout segment replayed as
+        # a hipGraph has frozen kernel arguments, its steps draw at offset *base + (step inside the rollout)
+        self._step_base = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._base_count = 0
+        self._graphs, self._graph_pool, self._segment_runs = {}, None, {}
         # MonitorEnv statistics (atari_wrappers.py:44-100), reduced on the device:
         # (episodes closed, sum of unclipped returns, sum of lengths)
         self.ep_stats = torch.zeros(3, dtype=torch.float64, device=dev)
@@ -72,6 +82,9 @@ class DeviceRollout(object):
             self.started = True
         else:
             env.roll()
+        self._base_count = self.step_count
+        if self._step_base.is_cuda:
+            self._step_base.fill_(self.step_count)
 
     @torch.no_grad()
     def collect_step(self, model, t):
@@ -79,9 +92,55 @@ class DeviceRollout(object):
         # a model whose trunk reads the ring in place gets a reference (one launch less per env step), any other the stack
         obs = env.current_obs_ref(self._obs_step) if getattr(model, 'reads_ring', False) else env.current_obs(self._obs_step)
         logits = self.behaviour_logits[t]
-        _policy_and_draw(model, obs, logits, self.actions[t], self.seed, self.step_count, env.env_id0)
+        if getattr(model, 'supports_offset_base', False) and self._step_base.is_cuda:
+            # the same uniforms as offset = step_count: step_count == *base + (steps since collect_begin)
+            _policy_and_draw(model, obs, logits, self.actions[t], self.seed, self.step_count - self._base_count,
+                             env.env_id0, self._step_base)
+        else:
+            _policy_and_draw(model, obs, logits, self.actions[t], self.seed, self.step_count, env.env_id0)
         env.step_async(self.actions[t], self.rewards[t], self.dones[t], ep_acc=self.ep_stats)
         self.step_count += 1
+
+    def can_graph(self, model):
+        return bool(getattr(model, 'supports_offset_base', False) and self._step_base.is_cuda and self.env.link is None
+                    and getattr(model, 'reads_ring', False))
+
+    @torch.no_grad()
+    def collect_segment(self, model, t0, t1, graph=False):
+        """env steps [t0, t1) of the current rollout.  graph=True (and a model / env that allow it): the segment is
+        ONE hipGraph launch — every kernel argument of these steps is a fixed address (ring slots, trajectory slab
+        rows of the selected buffer, the actor model's parameters) except the Philox offset, which is read from
+        `_step_base`.  The first run of a (buffer, segment) is eager (libraries warm), the second is captured, every
+        later one a replay.  A replay enqueues exactly the kernels the eager steps enqueue."""
+        if not (graph and self.can_graph(model)):
+            for t in range(t0, t1):
+                self.collect_step(model, t)
+            return
+        env = self.env
+        key = (self._cur, int(t0), int(t1), id(model))
+        g = self._graphs.get(key)
+        if g is None:
+            runs = self._segment_runs.get(key, 0)
+            self._segment_runs[key] = runs + 1
+            if runs == 0:
+                for t in range(t0, t1):
+                    self.collect_step(model, t)
+                return
+            assert env.t == t0, (env.t, t0)
+            sc, et = self.step_count, env.t
+            st = torch.cuda.current_stream(env.device)
+            g = torch.cuda.CUDAGraph()
+            kw = {'pool': self._graph_pool} if self._graph_pool is not None else {}
+            with torch.cuda.graph(g, stream=st, **kw):
+                for t in range(t0, t1):
+                    self.collect_step(model, t)
+            if self._graph_pool is None:
+                self._graph_pool = g.pool()
+            self._graphs[key] = g
+            self.step_count, env.t = sc, et   # the capture enqueued nothing
+        g.replay()
+        self.step_count += t1 - t0
+        env.t += t1 - t0
 
     def _batch_view(self):
         """the time-major batch over the selected trajectory buffer"""
@@ -481,6 +540,9 @@ class AsyncActorLearner(object):
         self._pub = [[t.detach().clone() for t in self._src] for _ in range(n_pub)]
         self._pub_ready = [torch.cuda.Event() for _ in range(n_pub)]
         self._pass_enqueued = False  # a learner pass (with its publications) was enqueued before this rollout
+        # the actors' rollout as hipGraph segments (between the refresh points): one host call per segment instead of
+        # five launches per env step
+        self.graph_rollout = bool(int(os.environ.get('PARL_AMD_ROLLOUT_GRAPH', '1'))) and not elastic and len(self.envs) == 1
         self.graphed = {}
         if self.sub_batches:
             from .algorithms.impala.graphed import GraphedLearn
@@ -605,14 +667,19 @@ class AsyncActorLearner(object):
         elif len(self.rollouts) == 1 and self.refresh_points and self._pass_enqueued:
             st, ro = self.actor_streams[0], self.rollouts[0]
             at = {step: i for i, (step, _) in enumerate(self.refresh_points)}
+            cuts = sorted(at) + [self.T]
             with torch.cuda.stream(st):
-                for t in range(self.T):
-                    if t in at:  # the learner pass enqueued before this rollout published these weights
-                        st.wait_event(self._pub_ready[at[t]])
-                        with torch.no_grad():
-                            torch._foreach_copy_(self._dst, self._pub[at[t]])
-                    ro.collect_step(self.actor_model, t)
+                ro.collect_segment(self.actor_model, 0, cuts[0], graph=self.graph_rollout)
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    # the learner pass enqueued before this rollout published these weights
+                    st.wait_event(self._pub_ready[at[a]])
+                    with torch.no_grad():
+                        torch._foreach_copy_(self._dst, self._pub[at[a]])
+                    ro.collect_segment(self.actor_model, a, b, graph=self.graph_rollout)
             self._pass_enqueued = False
+        elif len(self.rollouts) == 1 and not isinstance(self.rollouts[0], ElasticDeviceRollout):
+            with torch.cuda.stream(self.actor_streams[0]):
+                self.rollouts[0].collect_segment(self.actor_model, 0, self.T, graph=self.graph_rollout)
         elif len(self.rollouts) == 1:
             with torch.cuda.stream(self.actor_streams[0]):
                 self.rollouts[0].collect_steps(self.actor_model)

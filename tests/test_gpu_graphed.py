@@ -223,3 +223,50 @@ def test_default_refresh_points_are_a_function_of_the_shapes_only(dev):
     with pytest.raises(RuntimeError, match='load_optimizer_state_inplace'):
         alg.optimizer.load_state_dict(alg.optimizer.state_dict())  # would detach the graphs from the state
     env.check_faults()
+
+
+def test_rollout_segments_as_hipgraphs_equal_the_eager_steps(dev):
+    """DeviceRollout.collect_segment(graph=True): a segment of env steps replayed as ONE hipGraph (the Philox
+    offset of the rollout's first step read from device memory) produces bit for bit the batches of the eager
+    steps — across the eager first run of every (buffer, segment), the captures and several replays, with the
+    actor weights rewritten between rollouts (the graph refers to the parameters by address) and a weight
+    refresh between two segments as AsyncActorLearner does it."""
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel42
+    from parl_amd.rollout import DeviceRollout
+    E, T = 48, 12
+    torch.manual_seed(5)
+    base = AtariModel42(4).to(dev)
+    with torch.no_grad():
+        base.policy_fc.weight.mul_(0.05)
+    outs = []
+    for graph in (False, True):
+        env = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=42, horizon=T, seed=11, device=dev, max_episode_steps=60)
+        ro = DeviceRollout(env, T, seed=7, n_buffers=2)
+        m = copy.deepcopy(base)
+        for p in m.parameters():
+            p.requires_grad_(False)
+        st = torch.cuda.Stream(device=dev)
+        st.wait_stream(torch.cuda.current_stream(dev))
+        got = []
+        with torch.cuda.stream(st):
+            for it in range(7):
+                ro.collect_begin()
+                ro.collect_segment(m, 0, 5, graph=graph)
+                with torch.no_grad():   # a mid-rollout refresh: in-place, same addresses
+                    m.policy_fc.bias.add_(0.01 * (it + 1))
+                ro.collect_segment(m, 5, T, graph=graph)
+                b = ro.collect_end()
+                got.append({k: v.clone() for k, v in b.items()})
+                with torch.no_grad():
+                    m.policy_fc.weight.mul_(1.01)
+        st.synchronize()
+        env.check_faults()
+        if graph:
+            assert len(ro._graphs) == 4, ro._graphs.keys()   # 2 buffers x 2 segments were captured
+        outs.append((got, ro.step_count, ro.pop_episode_stats()))
+    (a, sa, ea), (b, sb, eb) = outs
+    assert sa == sb == 7 * T and ea == eb and ea[0] > 0
+    for it, (x, y) in enumerate(zip(a, b)):
+        for k in x:
+            assert torch.equal(x[k], y[k]), (it, k)
