@@ -79,12 +79,20 @@ class KernelTimer(object):
         return {'n': len(ts), 'mean': sum(ts) / len(ts), 'median': ts[len(ts) // 2], 'min': ts[0], 'max': ts[-1]}
 
 
+# SQ counters of atari_env_kernel<Pong> at E = 1024 (profiles/r04_env_pmc.log; the kernel did not change in round 5):
+# active instructions per wave-clock of the two waves an env occupies
+ENV_PMC = {'issue_slot_utilisation': 76765.0 / 213224.0, 'instructions_per_frame': 76765,
+           'source': 'profiles/r04_env_pmc.log (rocprofv3 --pmc, tools/pmc_env.sh): SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES per '
+                     'wave and emulated frame, both in 4-clock issue slots — a wave of this kernel issues in 36 % of its '
+                     'slots, two such waves share a SIMD'}
+
+
 def pmc_traffic(key):
     """HBM bytes per launch from the committed rocprofv3 PMC measurement of the same kernel and
     shape (profiles/r01_scan_hbm_traffic.json, produced by tools/prof_traffic.sh: separate
     FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction).  bench.py cannot run under two
     rocprofv3 passes itself; the source file is named next to the number."""
-    for name in ('r04_hbm_traffic.json', 'r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01e_scan_hbm_traffic.json', 'r01_scan_hbm_traffic.json'):
+    for name in ('r05_hbm_traffic.json', 'r04_hbm_traffic.json', 'r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01e_scan_hbm_traffic.json', 'r01_scan_hbm_traffic.json'):
         try:
             t = json.load(open(os.path.join(ROOT, 'profiles', name)))[key]
             return {'traffic': t['hbm_traffic_bytes'], 'traffic_source': 'profiles/%s:%s' % (name, key)}
@@ -500,7 +508,50 @@ def self_launch(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+class Watchdog(object):
+    """A rank that stops making progress (a collective a peer never joins, a wedged GPU) must not hang silently:
+    a daemon thread prints ONE JSON error line and ends the process when `beat()` was not called for `limit`
+    seconds.  (RCCL's own watchdog aborts the process after the process-group timeout; this one also covers hangs
+    outside collectives and leaves a line a driver can parse.)"""
+
+    def __init__(self, limit):
+        import threading
+        self.limit, self.phase, self.last, self.rank = float(limit), 'start', time.time(), int(os.environ.get('RANK', '0'))
+        if self.limit > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def beat(self, phase=None):
+        self.last = time.time()
+        if phase is not None:
+            self.phase = phase
+
+    def _run(self):
+        while True:
+            time.sleep(1.0)
+            idle = time.time() - self.last
+            if idle > self.limit:
+                print(json.dumps({'error': 'no progress for %.0f s in phase %r' % (idle, self.phase), 'rank': self.rank,
+                                  'world_size_env': int(os.environ.get('WORLD_SIZE', '1')),
+                                  'collectives': pdist.describe(), 'rccl_log_tail': pdist.collective_log_tail()}),
+                      flush=True)
+                os._exit(3)
+
+
 def main():
+    try:
+        _main()
+    except SystemExit:
+        raise
+    except BaseException as e:  # every rank leaves ONE parseable line and a non-zero exit code
+        import traceback
+        traceback.print_exc()
+        print(json.dumps({'error': '%s: %s' % (type(e).__name__, e), 'rank': int(os.environ.get('RANK', '0')),
+                          'world_size_env': int(os.environ.get('WORLD_SIZE', '1')),
+                          'collectives': pdist.describe(), 'rccl_log_tail': pdist.collective_log_tail()}), flush=True)
+        sys.exit(2)
+
+
+def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -527,6 +578,8 @@ def main():
                     help='headline workload only: skip the saturating-shape roofline and the extra config legs')
     ap.add_argument('--no-overlap', action='store_true',
                     help='run rollout and learner update back to back on one stream instead of overlapped')
+    ap.add_argument('--hang-timeout', type=float, default=float(os.environ.get('PARL_AMD_HANG_TIMEOUT', '240')),
+                    help='seconds without progress after which a rank prints a JSON error line and exits 3 (0: off)')
     ap.add_argument('--only-legs', default='',
                     help='dev: run only these extra legs (comma separated) and print their JSON, no headline run')
     args = ap.parse_args()
@@ -538,7 +591,10 @@ def main():
         return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         return self_launch(args)
+    wd = Watchdog(args.hang_timeout)
+    wd.beat('rendezvous')
     rank, local, world = pdist.init()
+    wd.beat('setup')
     if world != args.gpus:
         sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or run without torchrun and '
                  'let bench.py start the ranks itself)' % (args.gpus, world))
@@ -617,16 +673,21 @@ def main():
 
     for _ in range(args.warmup):
         step()
+        wd.beat('warm-up')
     pdist.barrier()
     torch.cuda.synchronize()
+    wd.beat('timed steps')
     vt_timer.enabled = hl_timer.enabled = env_timer.enabled = fp_timer.enabled = True
     updates0 = pipe.updates if pipe is not None else 0
     t0 = time.time()
     for _ in range(args.steps):
         loss = step()
+        wd.beat()
     pdist.barrier()
     torch.cuda.synchronize()
     dt = pdist.all_reduce_max_scalar(time.time() - t0)
+    wd.beat('after the timed steps')
+    wd.limit = max(wd.limit, 1200.0)  # the legs behind the headline (CPU baselines, profiles) have no collectives
     for e in envs:
         e.check_faults()
     total_loss = float(loss.total_loss.item())
@@ -672,6 +733,7 @@ def main():
             'actor_weight_refresh_points_are': 'fixed (parl_amd.rollout.fixed_refresh_points: a function of T, updates '
                                                'per rollout and frame size; nothing calibrated at run time)',
             'env_ids_per_rank': [[r * E, r * E + E - 1] for r in range(world)],
+            'process_group': pdist.describe(),
             'collectives': (('none (single process)' if not pdist.active() else 'RCCL, one-rank group (PARL_AMD_FORCE_DIST)')
                             if world == 1 else
                             ('gloo, ranks SHARE GPUs (fewer devices than ranks: functional run, not a scaling number)'
@@ -680,6 +742,15 @@ def main():
         'learner_updates_per_sec': ((pipe.updates - updates0) if pipe is not None else K) / dt,
         'agent_steps_per_sec': K * T * E * world / dt,
     }
+    if pipe is not None and env_timer.mean_seconds() is None and not elastic:
+        # the timed region replayed the actors' steps as hipGraph segments (no host call to bracket): the per-kernel
+        # figures below come from ONE eager rollout of the same actors after it, alone on the device
+        pipe.synchronize()
+        with torch.cuda.stream(pipe.actor_stream):
+            pipe.rollout.collect_begin()
+            pipe.rollout.collect_steps(pipe.actor_model)
+            pipe.rollout.collect_end()
+        pipe.synchronize()
     es, fps = env_timer.mean_seconds(), fp_timer.mean_seconds()
     hl_in, hl_in_stats = hl_timer.mean_seconds(), hl_timer.stats()
     if graphed_mode:
@@ -783,14 +854,18 @@ def main():
         # (per env: 512 B state read + written, two 33,600 B colour frames written, action / reward /
         # done / flags) against its duration.  It is NOT HBM-bound: one wavefront per env executes the 6507 of the
         # cartridge serially; what bounds it is single-wave instruction issue.
-        envb = Eg * (2 * 512 + 2 * 33600 + 8 + 4 + 1 + 1 + 4 + 4)
+        # the dominant kernel of the rollout is NOT bandwidth-bound (70 MB of frame stores per launch in ~0.65 ms):
+        # one wavefront pair per env executes the cartridge's 6507 serially.  What describes it is how many of the
+        # issue slots it occupies it uses — from the committed SQ counter run of this kernel (tools/pmc_env.sh).
         out['roofline_env_kernel'] = {
             'kernel': 'atari_env_kernel<GAME> (VectorEnv.step: 4 emulated frames for each of %d envs)' % Eg,
-            'bound': 'hbm', 'achieved': envb / es / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-            'frac': envb / es / 1e9 / HBM_PEAK_GBPS, 'traffic': None, 'bytes_per_launch': envb,
-            'note': 'latency-bound, not bandwidth-bound: a single wave issues ~1 instruction per 4.5 clk and pays 12-30 clk '
-                    'per branch (profiles/r01c_issue_microbench.log); two waves per env since round 4 (6507 | picture, '
-                    'DESIGN 4.1); the timed call also contains frame_post',
+            'bound': 'instruction issue latency (one wave pair per env: 6507 on the scalar unit | picture)',
+            'env_step_ms_event_timed': es * 1e3,
+            'waves_per_simd': 2.0 * Eg / 1024,
+            'issue_slot_utilisation': ENV_PMC['issue_slot_utilisation'],
+            'instructions_per_wave_pair_and_frame': ENV_PMC['instructions_per_frame'],
+            'source': ENV_PMC['source'],
+            'note': 'no HBM roofline fraction is quoted for this kernel; the event-timed call also contains frame_post',
         }
         out['kernels'] = {
             'env_step_ms (atari_env_kernel + frame_post + since_update, one agent step of one %d-env group; %d '

@@ -182,12 +182,19 @@ class PipelineLearner(object):
     def __init__(self, config):
         from parl_amd.env import DeviceVectorEnv
         from parl_amd.rollout import AsyncActorLearner
+        from parl_amd import dist as pdist
         self.config = config
-        dev = torch.device('cuda')
+        # one process per GPU (torchrun env): envs sharded by rank, one gradient all-reduce per update
+        # (parl_amd.dist; the reference has one learner GPU and no collectives, train.py:155-194)
+        self.rank, local, self.world = pdist.init()
+        if os.environ.get('PARL_AMD_SHARE_GPU'):  # fewer GPUs than ranks (a test box): ranks share devices
+            local = local % torch.cuda.device_count()
+        dev = torch.device('cuda', local)
+        torch.cuda.set_device(dev)
         E, T = config['env_num'] * config['actor_num'], config['sample_batch_steps']
         elastic = config.get('elastic_launches', 'Breakout' in config['env_name'])
         self.env = DeviceVectorEnv(config['env_name'], E, dim=config['env_dim'], horizon=4 * T + 32 if elastic else T,
-                                   seed=config.get('seed', 0), device=dev)
+                                   seed=config.get('seed', 0), env_id0=self.rank * E, device=dev)
         if config['env_dim'] == 84:  # the north-star frame size: the A2C example's network (examples/A2C/atari_model.py)
             from parl_amd.models import AtariModel84
             model = AtariModel84(self.env.act_dim).to(dev)
@@ -196,6 +203,9 @@ class PipelineLearner(object):
         self.alg = parl.algorithms.IMPALA(
             model, sample_batch_steps=T, gamma=config['gamma'], vf_loss_coeff=config['vf_loss_coeff'],
             clip_rho_threshold=config['clip_rho_threshold'], clip_pg_rho_threshold=config['clip_pg_rho_threshold'])
+        pdist.broadcast_model(model)
+        if pdist.active():
+            self.alg.grad_hook = pdist.FlatGradAllReduce(model)
         self.pipe = AsyncActorLearner(self.alg, [self.env], T, seed=config.get('seed', 0) + 1000, elastic=elastic,
                                       train_batch_size=config['train_batch_size'])
         self.lr_scheduler = PiecewiseScheduler(config['lr_scheduler'])
@@ -270,9 +280,11 @@ if __name__ == '__main__':
         torch.manual_seed(args.seed)
         np.random.seed(args.seed)
     if not args.threads:
+        from parl_amd import dist as pdist
         learner = PipelineLearner(config)
         t0 = t_log = time.time()
-        while args.minutes is None or time.time() - t0 < args.minutes * 60:
+        # every update holds a collective in a data-parallel run: all ranks stop in the same iteration (max over ranks)
+        while not pdist.all_reduce_max_scalar(float(args.minutes is not None and time.time() - t0 >= args.minutes * 60)):
             learner.step()
             if time.time() - t_log >= config['log_metrics_interval_s']:
                 learner.log_metrics()

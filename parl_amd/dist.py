@@ -8,15 +8,40 @@ union batch is the sum) of the flattened gradient, followed by global-norm clipp
 REDUCED gradient and an identical Adam step on every rank.  Small per-step tensors (actions,
 behaviour logits, rewards, dones: 41 B/step at A=6) can be all-gathered for global statistics;
 observations are never gathered (1.45 GB per rank at 84x84 would buy nothing under DP)."""
+import datetime
 import os
+import tempfile
 
 import torch
 import torch.distributed as dist
 
+_debug_log = None
 
-def init(backend=None, force=False):
+
+def collective_log_tail(n=12):
+    """the last lines RCCL wrote at NCCL_DEBUG=WARN in this process (init() points NCCL_DEBUG_FILE at a per-process
+    file unless the caller set one), for error reports"""
+    try:
+        with open(_debug_log) as f:
+            return [x.rstrip() for x in f.readlines()[-n:]]
+    except (OSError, TypeError):
+        return []
+
+
+def describe():
+    """what the process group actually is: backend and the world size IT reports (not the env's)"""
+    if not active():
+        return 'none (single process)'
+    return '%s, %d rank(s) in the group' % (dist.get_backend(), dist.get_world_size())
+
+
+def init(backend=None, force=False, timeout_s=None):
     """Initialise from the torchrun env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  A single
-    process creates no group unless force=True (one-rank RCCL group: tests, PARL_AMD_FORCE_DIST=1)."""
+    process creates no group unless force=True (one-rank RCCL group: tests, PARL_AMD_FORCE_DIST=1).
+    timeout_s (default PARL_AMD_DIST_TIMEOUT or 120): rendezvous AND collective timeout — a rank that never
+    shows up makes init raise after this long instead of hanging (torch's default is 10-30 minutes), a collective
+    one rank never joins makes RCCL's watchdog abort the process after it."""
+    global _debug_log
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -31,7 +56,22 @@ def init(backend=None, force=False):
             torch.cuda.set_device(local % torch.cuda.device_count())
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if timeout_s is None:
+            timeout_s = float(os.environ.get('PARL_AMD_DIST_TIMEOUT', '120'))
+        if backend == 'nccl':   # RCCL's own complaints, kept per process for error reports (collective_log_tail)
+            os.environ.setdefault('NCCL_DEBUG', 'WARN')
+            if 'NCCL_DEBUG_FILE' not in os.environ:
+                _debug_log = os.path.join(tempfile.gettempdir(), 'parl_amd_rccl_rank%d_pid%d.log' % (rank, os.getpid()))
+                os.environ['NCCL_DEBUG_FILE'] = _debug_log
+            else:
+                _debug_log = os.environ['NCCL_DEBUG_FILE']
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=timeout_s))
+        except Exception as e:
+            raise RuntimeError('process group rendezvous failed on rank %d of %d (%s at %s:%s, timeout %.0f s): %s: %s' %
+                               (rank, world, backend, os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'], timeout_s,
+                                type(e).__name__, e))
     return rank, local, world
 
 

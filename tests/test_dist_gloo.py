@@ -231,3 +231,22 @@ def test_ppo_data_parallel_mean_gradient(tmp_path):
         alg.learn(b['obs'], b['act'], b['val'], b['ret'], b['logp'], b['adv'])
     for k, v in alg.model.state_dict().items():
         np.testing.assert_allclose(sd0[k], v.numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_missing_rank_makes_init_raise_within_the_timeout():
+    """parl_amd.dist.init(timeout_s): a peer that never shows up is an exception naming rank / world / address after
+    the timeout, not torch's 10-30 minute default (the reference has no collectives to hang in)"""
+    import subprocess
+    import time
+    code = ('import sys; sys.path.insert(0, %r)\n'
+            'from parl_amd import dist as pdist\n'
+            'try:\n'
+            '    pdist.init(backend="gloo", timeout_s=3)\n'
+            'except RuntimeError as e:\n'
+            '    print("RAISED", e); sys.exit(7)\n') % ROOT
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    t0 = time.time()
+    p = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=120, text=True)
+    assert p.returncode == 7 and 'rendezvous failed on rank 0 of 2' in p.stdout, p.stdout[-2000:]
+    assert time.time() - t0 < 60

@@ -79,3 +79,75 @@ def test_bench_reference_train_batch_over_rccl_with_one_rank():
     out = json.loads(line[0])
     assert 'RCCL' in out['config']['collectives'] and out['config']['learner_updates_per_step'] == 4
     assert out['learner_updates_per_sec'] > 0 and out['value'] > 0
+
+
+def _bench_env(**kw):
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(_free_port()))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'PARL_AMD_SHARE_GPU', 'PARL_AMD_DIST_BACKEND', 'PARL_AMD_FORCE_DIST'):
+        env.pop(k, None)
+    env.update({k: str(v) for k, v in kw.items()})
+    return env
+
+
+def _error_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith('{"error"')]
+    assert len(lines) == 1, stdout[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_rank_whose_peer_never_shows_up_reports_and_exits():
+    """The first real N > 1 run must not be able to hang silently: rank 0 of a two-rank RCCL job whose rank 1 was
+    never started gives up after the process-group timeout, prints ONE JSON error line (rank, what it waited for)
+    and exits non-zero."""
+    import time
+    t0 = time.time()
+    env = _bench_env(WORLD_SIZE=2, RANK=0, LOCAL_RANK=0, PARL_AMD_DIST_TIMEOUT=8)
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--envs', '64',
+           '--sample-batch-steps', '10', '--no-cpu-baseline', '--quick']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, text=True)
+    assert p.returncode == 2, (p.returncode, p.stdout[-3000:])
+    err = _error_line(p.stdout)
+    assert err['rank'] == 0 and err['world_size_env'] == 2 and 'rendezvous failed' in err['error'], err
+    assert time.time() - t0 < 120
+
+
+def test_bench_watchdog_ends_a_rank_that_makes_no_progress():
+    """--hang-timeout: no beat for that long (here: a limit shorter than the set-up itself) -> one JSON error line
+    naming the phase, exit code 3 — what a collective that a dead peer never joins looks like from the outside."""
+    cmd = [sys.executable, 'bench.py', '--gpus', '1', '--steps', '2', '--warmup', '1', '--envs', '64',
+           '--sample-batch-steps', '10', '--no-cpu-baseline', '--quick', '--hang-timeout', '0.5']
+    p = subprocess.run(cmd, cwd=ROOT, env=_bench_env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                       text=True)
+    assert p.returncode == 3, (p.returncode, p.stdout[-3000:])
+    err = _error_line(p.stdout)
+    assert 'no progress' in err['error'] and err['rank'] == 0
+
+
+def test_two_rank_data_parallel_training_learns_pong(capsys):
+    """Data-parallel TRAINING, not only gradient equality: two ranks (sharing this box's GPU over gloo) of
+    examples/IMPALA/train.py, 512 envs each, every update the all-reduced gradient of 2 x 1000 rows at the
+    reference's lr schedule.  ~45 s: the mean episode reward must leave the -20.x of random play."""
+    import ast
+    import re
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = _bench_env(WORLD_SIZE=2, RANK=r, LOCAL_RANK=r, MASTER_PORT=port, PARL_AMD_SHARE_GPU=1,
+                         PARL_AMD_DIST_BACKEND='gloo')
+        procs.append(subprocess.Popen([sys.executable, 'examples/IMPALA/train.py', '--minutes', '0.75', '--env-num', '16',
+                                       '--log-interval', '10', '--seed', '1'], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[-2000:] for o in outs]
+    curves = []
+    for o in outs:
+        rows = [ast.literal_eval(m.group(1)) for m in re.finditer(r"INFO\] (\{'sample_steps'.*\})\s*$", o, re.M)]
+        assert rows, o[-2000:]
+        curves.append([(r['elapsed_time_s'], r['mean_episode_rewards'], r['learn_steps']) for r in rows])
+    with capsys.disabled():
+        print('\nIMPALA Pong, 2 ranks x 512 envs, DP over gloo (elapsed s, mean_episode_rewards, updates):', curves)
+    assert [c[-1][2] for c in curves][0] == [c[-1][2] for c in curves][1]   # the ranks took the same number of updates
+    for c in curves:
+        vals = [x[1] for x in c if x[1] is not None]
+        assert vals[0] < -18.0 and max(vals[-2:]) >= -16.0, c
