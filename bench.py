@@ -55,7 +55,7 @@ class KernelTimer(object):
 
     def wrap(self, fn):
         def timed(*a, **k):
-            if not self.enabled:
+            if not self.enabled or torch.cuda.is_current_stream_capturing():  # (an event pair inside a capture times nothing)
                 return fn(*a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()

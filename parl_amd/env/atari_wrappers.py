@@ -16,7 +16,7 @@ import collections
 from .device_vector_env import GAMES
 from .. import _native as N
 
-__all__ = ['wrap_deepmind', 'MonitorEnv', 'get_wrapper_by_cls', 'DeviceAtariEnv']
+__all__ = ['wrap_deepmind', 'MonitorEnv', 'TestEnv', 'get_wrapper_by_cls', 'DeviceAtariEnv']
 
 Box = collections.namedtuple('Box', ['shape', 'dtype', 'low', 'high'])
 Discrete = collections.namedtuple('Discrete', ['n'])
@@ -81,10 +81,48 @@ class MonitorEnv(object):
         return self._total_steps
 
 
+class TestEnv(object):
+    """parl/env/atari_wrappers.py:309-353, the evaluation wrapper `wrap_deepmind(test=True)` puts on top of the chain.
+    In the reference it passes step() through unchanged (life losses still end a "done" segment) and, in every
+    reset(), compares MonitorEnv's episode count with the end of the current evaluation window: once
+    `test_episodes` more REAL episodes have closed, get_real_done() turns True and get_eval_rewards() returns their
+    unclipped returns, until the next reset.  The chain itself lives in the env kernel; what is left of TestEnv is
+    this bookkeeping on the handle's MonitorEnv, run by VectorEnv at the places where the reference's VectorEnv
+    calls env.reset() (vector_env.py:34-39, :55-57).  Pinned on the reference class itself
+    (tests/golden/wrapper_chain_breakout_42_test.npz)."""
+    __test__ = False  # not a pytest class
+
+    def __init__(self, monitor, test_episodes=3):
+        self._monitor = monitor
+        self._test_episodes = int(test_episodes)
+        self._was_real_done = False
+        self._eval_rewards = None
+        self._end_episode = len(monitor.get_episode_rewards()) + self._test_episodes
+
+    def _on_reset(self):
+        """the part of TestEnv.reset behind the inner reset (atari_wrappers.py:336-345)"""
+        if self._get_curr_episode() >= self._end_episode:
+            self._was_real_done = True
+            self._eval_rewards = self._monitor.get_episode_rewards()[-self._test_episodes:]
+            self._end_episode = self._end_episode + self._test_episodes
+        else:
+            self._was_real_done = False
+            self._eval_rewards = None
+
+    def get_eval_rewards(self):
+        return self._eval_rewards
+
+    def get_real_done(self):
+        return self._was_real_done
+
+    def _get_curr_episode(self):
+        return len(self._monitor.get_episode_rewards())
+
+
 class WrappedDeviceAtariEnv(object):
     """result of wrap_deepmind on a device handle"""
 
-    def __init__(self, env, dim, obs_format):
+    def __init__(self, env, dim, obs_format, test_episodes=None):
         self.env = env
         self.unwrapped = env
         self.env_id = env.env_id
@@ -95,8 +133,19 @@ class WrappedDeviceAtariEnv(object):
         self.observation_space = Box(shape, 'uint8', 0, 255)
         self.action_space = env.action_space
         self.monitor = MonitorEnv()
+        self.test_env = TestEnv(self.monitor, test_episodes) if test_episodes else None
 
     reset = step = DeviceAtariEnv._no_host_stepping
+
+    def get_eval_rewards(self):   # the outermost wrapper of a test env is TestEnv: its two getters live here
+        if self.test_env is None:
+            raise AttributeError('get_eval_rewards: this env was wrapped without test=True')
+        return self.test_env.get_eval_rewards()
+
+    def get_real_done(self):
+        if self.test_env is None:
+            raise AttributeError('get_real_done: this env was wrapped without test=True')
+        return self.test_env.get_real_done()
 
     def close(self):
         pass
@@ -110,15 +159,17 @@ def wrap_deepmind(env, dim=84, framestack=True, obs_format='NHWC', test=False, t
         raise ValueError('wrap_deepmind: dim must be 42 or 84 on the device path')
     if not framestack:
         raise ValueError('wrap_deepmind: the device path always stacks 4 frames (the examples do)')
-    if test:
-        raise ValueError('wrap_deepmind(test=True): the TestEnv evaluation wrapper is not on the device path')
+    if test and int(test_episodes) < 1:
+        raise ValueError('wrap_deepmind(test=True): test_episodes must be >= 1')
     if obs_format not in ('NHWC', 'NCHW'):
         raise ValueError("obs_format should be one of ['NHWC', 'NCHW']")
-    return WrappedDeviceAtariEnv(env, dim, obs_format)
+    return WrappedDeviceAtariEnv(env, dim, obs_format, test_episodes=int(test_episodes) if test else None)
 
 
 def get_wrapper_by_cls(env, cls):
     """atari_wrappers.py:32-41: the wrapper of class `cls` in env's chain, or None"""
     if cls is MonitorEnv and isinstance(env, WrappedDeviceAtariEnv):
         return env.monitor
+    if cls is TestEnv and isinstance(env, WrappedDeviceAtariEnv):
+        return env.test_env
     return None

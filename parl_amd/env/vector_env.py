@@ -43,7 +43,11 @@ class VectorEnv(object):
 
     def reset(self):
         """vector_env.py:34-39"""
-        return self._obs_list(self.dev_env.reset())
+        obs = self._obs_list(self.dev_env.reset())
+        for e in self.envs:
+            if e.test_env is not None:  # TestEnv.reset ran for every env
+                e.test_env._on_reset()
+        return obs
 
     def step(self, actions):
         """vector_env.py:41-63 (the obs returned for a done env is its reset obs)"""
@@ -51,6 +55,7 @@ class VectorEnv(object):
         obs, rew, done, info = self.dev_env.step(a)
         ret = info['episode_returns'].cpu().numpy()
         ln = info['episode_lengths'].cpu().numpy()
+        dones = [bool(x) for x in done.cpu().numpy()]
         infos = []
         for i, e in enumerate(self.envs):
             if ln[i] > 0:  # MonitorEnv closed an episode of env i in this step
@@ -58,6 +63,7 @@ class VectorEnv(object):
                 infos.append({'episode': {'r': float(ret[i]), 'l': int(ln[i])}})
             else:
                 infos.append({})
+            if dones[i] and e.test_env is not None:  # the auto-reset of a done env went through TestEnv.reset (:55-57)
+                e.test_env._on_reset()
         self.dev_env.check_faults()
-        return (self._obs_list(obs), [float(x) for x in rew.cpu().numpy()], [bool(x) for x in done.cpu().numpy()],
-                infos)
+        return self._obs_list(obs), [float(x) for x in rew.cpu().numpy()], dones, infos

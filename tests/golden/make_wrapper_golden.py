@@ -235,12 +235,15 @@ def crc(a):
     return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff
 
 
-def run_case(mods, game, E, dim, seed, steps, max_episode_steps, action_seed, keep_full):
+def run_case(mods, game, E, dim, seed, steps, max_episode_steps, action_seed, keep_full, test_episodes=None):
     aw, ve = mods['atari_wrappers'], mods['vector_env']
     envs = []
     for e in range(E):
         base = TimeLimit(OracleAtariEnv(game, seed, e), max_episode_steps)
-        envs.append(aw.wrap_deepmind(base, dim=dim, obs_format='NCHW'))
+        if test_episodes:  # the evaluation wrapper on top of the chain (atari_wrappers.py:309-353, :383-384)
+            envs.append(aw.wrap_deepmind(base, dim=dim, obs_format='NCHW', test=True, test_episodes=test_episodes))
+        else:
+            envs.append(aw.wrap_deepmind(base, dim=dim, obs_format='NCHW'))
     vec = ve.VectorEnv(envs)
     obs = vec.reset()
     A = len(ALE_ACTIONS[game])
@@ -253,11 +256,26 @@ def run_case(mods, game, E, dim, seed, steps, max_episode_steps, action_seed, ke
     rew = np.zeros((steps, E), np.float32)
     done = np.zeros((steps, E), np.uint8)
     ocrc = np.zeros((steps, E), np.uint32)
+    k = test_episodes or 0
+    real_done = np.zeros((steps + 1, E), np.uint8)           # TestEnv.get_real_done() after reset / every step
+    eval_rew = np.full((steps + 1, E, max(k, 1)), np.nan)    # TestEnv.get_eval_rewards() (NaN: None)
+
+    def record_test(row):
+        for e, env in enumerate(envs):
+            real_done[row, e] = env.get_real_done()
+            ev = env.get_eval_rewards()
+            if ev is not None:
+                eval_rew[row, e] = ev
+
+    if k:
+        record_test(0)
     full = {}
     for t in range(steps):
         o, r, d, _ = vec.step(actions[t])
         rew[t], done[t] = r, d
         ocrc[t] = [crc(x) for x in o]
+        if k:
+            record_test(t + 1)
         if t in keep_full:
             full[t] = np.stack(o)
     out.update(rewards=rew, dones=done, obs_crc=ocrc)
@@ -270,6 +288,8 @@ def run_case(mods, game, E, dim, seed, steps, max_episode_steps, action_seed, ke
         for r_, l_ in mon.next_episode_results():
             eps.append((e, r_, l_))
     out['episodes'] = np.array(eps, np.float64).reshape(-1, 3)
+    if k:
+        out.update(test_episodes=k, real_done=real_done, eval_rewards=eval_rew)
     return out
 
 
@@ -281,8 +301,19 @@ CASES = [
     ('breakout_42_timelimit', 'breakout', 2, 42, 7, 400, 700, 3),
 ]
 
+# wrap_deepmind(test=True): TestEnv's evaluation bookkeeping on top of the same chain
+TEST_CASES = [('breakout_42_test', 'breakout', 2, 42, 9, 1100, 400000, 4, 2)]
+
 if __name__ == '__main__':
     mods = load_reference_env_modules()
+    for name, game, E, dim, seed, steps, mes, aseed, k in TEST_CASES:
+        res = run_case(mods, game, E, dim, seed, steps, mes, aseed, keep_full={0, steps - 1}, test_episodes=k)
+        path = os.path.join(HERE, 'wrapper_chain_%s.npz' % name)
+        np.savez_compressed(path, **res)
+        print(name, 'dones', int(res['dones'].sum()), 'episodes', len(res['episodes']), 'real_done rows',
+              int(res['real_done'].sum()), '->', os.path.getsize(path), 'bytes')
+    if os.environ.get('ONLY_TEST_CASES'):
+        sys.exit(0)
     for name, game, E, dim, seed, steps, mes, aseed in CASES:
         res = run_case(mods, game, E, dim, seed, steps, mes, aseed, keep_full={0, steps // 2, steps - 1})
         path = os.path.join(HERE, 'wrapper_chain_%s.npz' % name)

@@ -84,3 +84,82 @@ def test_device_env_matches_reference_wrappers(dev, case, cache):
     # the device reports at most ONE closed episode per env-step (the last); the fixtures were
     # chosen so that no step closes two
     assert sorted(eps) == sorted(map(tuple, g['episodes'].tolist()))
+
+
+# ---- wrap_deepmind(test=True): TestEnv (parl/env/atari_wrappers.py:309-353) -------------------------------------
+def _check_test_rows(g, t, envs):
+    k = int(g['test_episodes'])
+    for e, env in enumerate(envs):
+        assert bool(env.get_real_done()) == bool(g['real_done'][t, e]), 'get_real_done, row %d env %d' % (t, e)
+        want = g['eval_rewards'][t, e]
+        got = env.get_eval_rewards()
+        if np.isnan(want[0]):
+            assert got is None, (t, e, got)
+        else:
+            assert list(got) == list(want[:k]), (t, e, got, want)
+
+
+def test_testenv_bookkeeping_matches_the_reference_class(oracle):
+    """parl_amd.env.atari_wrappers.TestEnv on MonitorEnv records delivered the way VectorEnv delivers them, the env
+    stream from the C oracle: get_real_done() / get_eval_rewards() after the reset and after every step equal what
+    the reference's TestEnv reported on the same trajectory (fixture made by its own code)."""
+    from parl_amd.env.atari_wrappers import DeviceAtariEnv, TestEnv, WrappedDeviceAtariEnv, get_wrapper_by_cls
+    g = load('breakout_42_test')
+    game, E, dim, k = str(g['game']), int(g['E']), int(g['dim']), int(g['test_episodes'])
+    v = oracle.VecEnv(rom(game), game, E, dim, seed=int(g['seed']), max_episode_steps=int(g['max_episode_steps']))
+
+    class Handle(WrappedDeviceAtariEnv):   # a handle without the device library behind it
+        def __init__(self):
+            self.monitor = __import__('parl_amd.env.atari_wrappers', fromlist=['MonitorEnv']).MonitorEnv()
+            self.test_env = TestEnv(self.monitor, k)
+
+    envs = [Handle() for _ in range(E)]
+    assert isinstance(get_wrapper_by_cls(envs[0], TestEnv), TestEnv) and DeviceAtariEnv is not None
+    assert np.array_equal(v.reset(), g['reset_obs'])
+    for env in envs:
+        env.test_env._on_reset()
+    _check_test_rows(g, 0, envs)
+    n_real = 0
+    for t in range(g['actions'].shape[0]):
+        o, r, d = v.step(g['actions'][t])
+        assert np.array_equal(d, g['dones'][t]) and np.array_equal(r, g['rewards'][t])
+        for e, env in enumerate(envs):
+            for ret, ln in v.pop_episodes(e):
+                env.monitor._push(ret, ln)
+            if d[e]:
+                env.test_env._on_reset()
+        _check_test_rows(g, t + 1, envs)
+        n_real += int(g['real_done'][t + 1].sum())
+    assert n_real > 0 and g['dones'].sum() > len(g['episodes'])   # windows closed; life-loss dones stayed dones
+
+
+@pytest.mark.gpu
+def test_device_vector_env_with_test_wrapper_matches_reference(dev, monkeypatch):
+    """the drop-in form on the device: wrap_deepmind(gym.make(id), dim, obs_format, test=True, test_episodes=2) handles
+    in parl.env.vector_env.VectorEnv — observations, rewards, dones AND TestEnv's two getters against the fixture"""
+    import itertools
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'compat'))
+    try:
+        for m in ('gym', 'parl'):
+            sys.modules.pop(m, None)
+        import gym
+        from parl.env.atari_wrappers import wrap_deepmind, TestEnv, get_wrapper_by_cls
+        from parl.env import vector_env as ve
+        g = load('breakout_42_test')
+        game, E, dim, k = str(g['game']), int(g['E']), int(g['dim']), int(g['test_episodes'])
+        rom(game)
+        monkeypatch.setattr(ve, '_next_env_id', itertools.count())   # env ids 0 .. E-1 as in the fixture
+        envs = [wrap_deepmind(gym.make(GYM_ID[game]), dim=dim, obs_format='NCHW', test=True, test_episodes=k) for _ in range(E)]
+        assert isinstance(get_wrapper_by_cls(envs[0], TestEnv), TestEnv)
+        vec = ve.VectorEnv(envs, seed=int(g['seed']), device=dev)
+        obs = vec.reset()
+        assert np.array_equal(np.stack(obs), g['reset_obs'])
+        _check_test_rows(g, 0, envs)
+        for t in range(g['actions'].shape[0]):
+            o, r, d, info = vec.step(g['actions'][t])
+            assert r == [float(x) for x in g['rewards'][t]] and d == [bool(x) for x in g['dones'][t]], t
+            assert [crc(x) for x in o] == list(g['obs_crc'][t]), 'obs mismatch at step %d' % t
+            _check_test_rows(g, t + 1, envs)
+    finally:
+        sys.path.remove(os.path.join(ROOT, 'compat'))
