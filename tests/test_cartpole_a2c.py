@@ -133,7 +133,7 @@ class Learner(object):
         self.agent = CartPoleAgent(A2C(model, vf_loss_coeff=config['vf_loss_coeff']), config)
         parl.connect(config['master_address'])
         Actor = make_actor_class(calc_gae)
-        self.remote_actors = [Actor(config, seed=1 + i) for i in range(config['actor_num'])]
+        self.remote_actors = [Actor(config, seed=config.get('actor_seed0', 1) + i) for i in range(config['actor_num'])]
         self.sample_total_steps, self.updates = 0, 0
 
     def step(self):
