@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(OptTable t, const float*
   const float total = block_sum_256(s0 + s1, red);
   const float norm = sqrtf(total);
   float clip = max_norm / (norm + 1e-6f);
-  clip = clip < 1.0f ? clip : 1.0f;
+  // torch.clamp(clip_coef, max=1.0) keeps a NaN (a non-finite gradient norm): every gradient, and with it every
+  // parameter, turns NaN at once, as after torch's clip_grad_norm_ — a partly poisoned model is harder to notice
+  clip = clip < 1.0f ? clip : (clip != clip ? clip : 1.0f);
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = norm;
 
   const int k = opt_tensor_of(t, blockIdx.x);

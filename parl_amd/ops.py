@@ -317,6 +317,8 @@ class ClipAdam(object):
         self.norm = torch.zeros(1, dtype=torch.float32, device=dev)   # the global norm before clipping, last step
         self._ct = ctypes
         self._tables = None
+        for p in self.params:   # step() writes the parameters through raw pointers: their autograd version never moves,
+            p._parl_graph_written = True   # so a cached MFMA layout of them (_cached_layout) would go stale — never cache
 
     def _pointer_tables(self):
         """HOST arrays of device pointers, rebuilt when a tensor moved (p.grad is re-created by zero_grad(set_to_none))"""
@@ -582,6 +584,7 @@ def _cached_layout(w, kind, fn):
     if hit is not None and hit[0] is w and hit[1] == ver and hit[2] == w.data_ptr():
         if hit[5] != cur:
             cur.wait_event(hit[4])
+            hit[3].record_stream(cur)   # the allocator must not hand the block out again while this stream reads it
         return hit[3]
     out = fn(w)
     ev = torch.cuda.Event()

@@ -761,9 +761,16 @@ class AsyncActorLearner(object):
 
     def load_state_dict(self, d):
         pts = None
-        if 'refresh_points' in d and not d.get('refresh_auto', False) and len(d['refresh_points']) <= len(self._pub):
-            # a calibrated run resumes with its points — checked like the constructor's, before anything is touched
+        if 'refresh_points' in d and not d.get('refresh_auto', False):
+            # a run resumes with ITS points (checked like the constructor's, before anything is touched): a resume
+            # that silently fell back to this object's points would no longer be the same run
             pts = self._checked_refresh_points(d['refresh_points']) if d['refresh_points'] else []
+            if len(pts) > len(self._pub):   # publication buffers for the checkpoint's points
+                self._pub += [[t.detach().clone() for t in self._src] for _ in range(len(pts) - len(self._pub))]
+                self._pub_ready += [torch.cuda.Event() for _ in range(len(pts) - len(self._pub_ready))]
+        elif d.get('refresh_auto', False) and not self._refresh_auto:
+            raise ValueError('the checkpoint was saved while its refresh points were still being calibrated '
+                             "(refresh_points='auto'): resume it into a pipeline built with refresh_points='auto'")
         self.synchronize()
         torch.cuda.synchronize(self.env.device)
         for e, s in zip(self.envs, d['envs']):

@@ -76,19 +76,14 @@ def test_a2c_value_function_fits_at_the_reference_hyperparameters(capsys):
     minutes (profiles/r04_learn_a2c_pong_256envs_first_3min.log: +20.4 after 200 s with the earlier initialisation);
     a learner whose updates do nothing shows here first.
 
-    The seed is the one that did NOT start with torch's default initialisation: there the first Adam steps at 1e-3
-    switched off every ReLU of the 512-unit layer (critic loss flat at 425 for good, --seed 1, reproducibly).  The
-    reference's model takes PADDLE's defaults (He-normal convolutions, Xavier-uniform linear layers, zero biases:
-    models.atari_model.paddle_default_init_), 2.3-2.4x larger per layer; AtariModel84 has them since.  A second seed
-    is tried before failing; all attempts are printed."""
-    tried = []
-    for seed in (1, 2):
-        rows = _train(['--seed', str(seed), '--minutes', '0.33', '--log-interval', '5'], timeout=300, script='examples/A2C/train.py')
-        vf = [(r['sample_steps'], round(float(r['vf_loss']), 1)) for r in rows]
-        tried.append((seed, vf))
-        with capsys.disabled():
-            print('\nA2C Pong 256 envs, seed %d (sample steps, vf_loss):' % seed, vf, ' env frames/s %.0f' % rows[-1]['env_frames_per_s'])
-        assert rows[-1]['env_frames_per_s'] > 4e5
-        if min(v for _, v in vf[-2:]) < 300.0:
-            return
-    raise AssertionError('the critic never started to fit: %r' % (tried, ))
+    ONE seed (round 4 retried a second one): with torch's default initialisation the first Adam steps at 1e-3 could
+    switch off every ReLU of the 512-unit layer (critic loss flat at 425 for good); the reference's model takes
+    PADDLE's defaults (He-normal convolutions, Xavier-uniform linear layers, zero biases:
+    models.atari_model.paddle_default_init_), 2.3-2.4x larger per layer, and AtariModel84 has them since — a start
+    that collapses must fail this test, not be retried."""
+    rows = _train(['--seed', '1', '--minutes', '0.33', '--log-interval', '5'], timeout=300, script='examples/A2C/train.py')
+    vf = [(r['sample_steps'], round(float(r['vf_loss']), 1)) for r in rows]
+    with capsys.disabled():
+        print('\nA2C Pong 256 envs, seed 1 (sample steps, vf_loss):', vf, ' env frames/s %.0f' % rows[-1]['env_frames_per_s'])
+    assert rows[-1]['env_frames_per_s'] > 4e5
+    assert min(v for _, v in vf[-2:]) < 300.0, 'the critic never started to fit: %r' % (vf, )

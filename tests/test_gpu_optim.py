@@ -125,3 +125,63 @@ def test_clip_adam_covers_what_it_says():
     c = ops.ClipAdam(o, 40.0)
     with pytest.raises(Exception):
         c.step()                                                # no gradients yet
+
+
+def test_clip_adam_non_finite_gradient_norm_poisons_every_parameter_like_torch():
+    """one NaN in one gradient: torch.nn.utils.clip_grad_norm_ multiplies EVERY gradient by clamp(NaN, max=1) = NaN,
+    so the whole model turns NaN in that step — visible at once.  The fused kernel must not take a normal Adam
+    step on the clean tensors (a partly corrupted model)."""
+    from parl_amd import ops
+    from parl_amd.algorithms.impala.graphed import make_capturable
+    dev = torch.device('cuda', 0)
+    shapes = [(16, 4, 4, 4), (16, ), (300, 17)]
+    pa, pb = _models(shapes, dev, 0)
+    oa, ob = torch.optim.Adam(pa, lr=1e-3), torch.optim.Adam(pb, lr=1e-3)
+    make_capturable(oa, dev)
+    ca = ops.ClipAdam(oa, 40.0)
+    g = torch.Generator(device='cpu').manual_seed(2)
+    grads = [torch.randn(s, generator=g) for s in shapes]
+    grads[1][3] = float('nan')
+    for p, q, gr in zip(pa, pb, grads):
+        p.grad, q.grad = gr.to(dev), gr.to(dev).clone()
+    ca.step()
+    torch.nn.utils.clip_grad_norm_(pb, 40.0)
+    ob.step()
+    torch.cuda.synchronize()
+    for p, q in zip(pa, pb):
+        assert bool(torch.isnan(q).all()) and bool(torch.isnan(p).all())
+
+
+def test_eager_clip_adam_step_is_seen_by_the_cached_actor_layouts():
+    """ClipAdam.step() writes parameters through raw pointers (their autograd version never moves) while
+    ops._cached_layout keys the actors' MFMA weight layouts on that version: after an eager step a no_grad forward of
+    the 84x84 model must use the NEW conv2 / conv3 weights, not a layout cached before the step."""
+    from parl_amd import ops
+    from parl_amd.algorithms.impala.graphed import make_capturable
+    from parl_amd.models import AtariModel84
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    m = AtariModel84(6).to(dev)
+    obs = torch.randint(0, 256, (5, 4, 84, 84), dtype=torch.uint8, device=dev)
+    with torch.no_grad():
+        before = m.policy(obs).clone()   # fills the layout cache
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    make_capturable(opt, dev)
+    ca = ops.ClipAdam(opt, 40.0)
+    g = torch.Generator(device='cpu').manual_seed(3)
+    for p in m.parameters():
+        p.grad = torch.randn(p.shape, generator=g).to(dev)
+    ca.step()
+    with torch.no_grad():
+        after = m.policy(obs)
+        ref = copy_of(m).policy(obs)     # a fresh module holding the same (updated) weights: nothing cached for it
+    assert not torch.equal(before, after)
+    assert torch.equal(after, ref)
+
+
+def copy_of(m):
+    import copy
+    c = copy.deepcopy(m)
+    for p in c.parameters():
+        p.grad = None
+    return c
