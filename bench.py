@@ -101,6 +101,14 @@ def pmc_traffic(key):
     return {'traffic': None}
 
 
+def kernel_only_profile(by):
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r05_heads_loss_kernel_only.json')))
+        return {'us': d['avg_us'], 'frac': by / (d['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 'source': d['source']}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(game, dim, seconds_target=12.0):
     """The CPU oracle (a port, 'kind': 'port') stepping the same env chain on host cores."""
     from concurrent.futures import ThreadPoolExecutor
@@ -739,6 +747,8 @@ def _main():
                             ('gloo, ranks SHARE GPUs (fewer devices than ranks: functional run, not a scaling number)'
                              if shared else 'RCCL: flat-gradient all-reduce + small-tensor all-gather per update')),
         },
+        'spread_note': 'the timed region is K x ~45 ms of launch-latency-bound graph replays; on the boxes of this pool '
+                       'the same command has given 4.3-4.6 M frames/s (profiles/README.md)',
         'learner_updates_per_sec': ((pipe.updates - updates0) if pipe is not None else K) / dt,
         'agent_steps_per_sec': K * T * E * world / dt,
     }
@@ -785,9 +795,9 @@ def _main():
             if hl_in is None:  # ranks sharing a GPU / elastic / --no-overlap: no one-update pipeline was run beside it
                 hl_in, hl_in_stats = alone, None
             out['roofline'] = {
-                'kernel': 'impala_heads_loss_kernel (policy_fc + value_fc + log-softmax / entropy / KL + V-trace + loss '
-                          'sums + gradient w.r.t. the trunk output and the heads, two waves per sequence, T=%d B=%d A=%d; '
-                          'HIP events around the C-ABI call on the learner stream = this kernel + its 5 us '
+                'kernel': 'impala_heads_loss_q_kernel (policy_fc + value_fc + log-softmax / entropy / KL + V-trace + loss '
+                          'sums + gradient w.r.t. the trunk output and the heads, four waves per sequence, T=%d B=%d A=%d; '
+                          'HIP events around the C-ABI call on the learner stream = this kernel + its 4 us '
                           'heads_partial_sum_kernel)' % (T, Bl, A),
                 'bound': 'hbm', 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'bytes_per_launch': by,
                 # `frac` is the IN-PIPELINE figure: the kernel beside the actors' emulator / MFMA kernels, wherever in
@@ -798,6 +808,9 @@ def _main():
                                             'the timed region' if hl_in_stats else
                                             'not measured in this configuration: frac is the stand-alone figure'),
                 'frac_alone': by / alone / 1e9 / HBM_PEAK_GBPS, 'achieved_alone': by / alone / 1e9, 'alone_us': alone_stats,
+                # the main kernel by itself (rocprofv3 --kernel-trace --stats of the committed profile; bench.py cannot
+                # run under rocprof itself): the event-timed figures above add the partial-sum kernel and two launch gaps
+                'kernel_only': kernel_only_profile(by) if (T, Bl, A) == (50, 1024, 6) else None,
                 'note': 'the V-trace scan at the WORKLOAD shape (T=50 x 1024 sequences), fused with the two heads so that '
                         'the 52 MB trunk output and its gradient cross HBM once each.  In the headline\'s learner mode '
                         '(train_batch_size 1000 = 20 sequences per update) the same kernel moves %.1f MB per launch '

@@ -271,7 +271,10 @@ class GraphedLearn(object):
         def cut(x):
             return x.view((T, E) + tuple(x.shape[1:]))[:, b0:b0 + B]
 
-        self.obs.view((T, B) + tuple(self.obs.shape[1:])).copy_(cut(batch['obs']))
+        if hasattr(batch['obs'], 'gather_sequences'):   # rollout.RingBatch: the stacks straight from the frame ring
+            batch['obs'].gather_sequences(b0, B, self.obs)
+        else:
+            self.obs.view((T, B) + tuple(self.obs.shape[1:])).copy_(cut(batch['obs']))
         self.actions.view(T, B).copy_(cut(batch['actions']))
         self.behaviour_logits.view(T, B, -1).copy_(cut(batch['behaviour_logits']))
         self.rewards.view(T, B).copy_(cut(batch['rewards']))

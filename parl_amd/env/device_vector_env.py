@@ -90,6 +90,11 @@ class DeviceVectorEnv(object):
         self.slots = self.horizon + 4
         self.ring = torch.zeros((self.slots, E, self.fsz), **u8)
         self.since = torch.zeros((self.slots, E), **u8)
+        # more than one ring (ensure_rings): successive rollouts alternate between them, so that a learner can still
+        # read the frames of rollout i-1 IN PLACE while rollout i is written (parl_amd.rollout.RingBatch) — no
+        # [T*E, 4, d, d] batch of stacks is materialised per rollout
+        self._rings = [(self.ring, self.since)]
+        self.ring_index = 0
         self.t = 0
         self.link = None      # elastic launches: [slots, E] slot of the env's previous observation
         self.cur_slot = None  # elastic launches: [E] slot of the env's current observation
@@ -128,14 +133,23 @@ class DeviceVectorEnv(object):
                 N.ptr(self.fp_tables), N.ptr(prev) if prev is not None else None, N.ptr(self.since[slot]),
                 N.stream_ptr()), 'parlhip_frame_post_since_u8')
 
-    def gather(self, slots, envs, out=None):
-        """Stacked obs u8 [n,4,dim,dim] for (ring slot, env) pairs (int32 tensors)."""
+    def ensure_rings(self, n):
+        """allocate rings up to `n` (before or after reset(); the current ring stays current)"""
+        if self.link is not None and n > 1:
+            raise N.ParlHipError('the elastic ring layout is one circular ring')
+        while len(self._rings) < int(n):
+            self._rings.append((torch.zeros_like(self.ring), torch.zeros_like(self.since)))
+
+    def gather(self, slots, envs, out=None, ring_index=None):
+        """Stacked obs u8 [n,4,dim,dim] for (ring slot, env) pairs (int32 tensors); ring_index: of which ring
+        (default: the current one)."""
         n = slots.numel()
         if out is None:
             out = torch.empty((n, 4, self.dim, self.dim), dtype=torch.uint8, device=self.device)
+        ring, since = self._rings[self.ring_index if ring_index is None else ring_index]
         N.check(
             N.lib().parlhip_stack_gather_ring_u8(
-                N.ptr(self.ring), N.ptr(self.since), N.ptr(self.link) if self.link is not None else None, self.slots,
+                N.ptr(ring), N.ptr(since), N.ptr(self.link) if self.link is not None else None, self.slots,
                 self.envs_num, self.fsz,
                 N.ptr(slots.contiguous()),
                 N.ptr(envs.contiguous()), n, N.ptr(out), N.stream_ptr()), 'parlhip_stack_gather_ring_u8')
@@ -249,9 +263,16 @@ class DeviceVectorEnv(object):
                 N.ptr(self.fp_tables), N.stream_ptr()), 'parlhip_frame_post_u8')
 
     def roll(self):
-        """Start the next rollout: the last 4 frame slots become the history of obs time 0."""
+        """Start the next rollout: the last 4 frame slots become the history of obs time 0 — of the NEXT ring when
+        there are several (the ring just written keeps the rollout's frames for whoever still reads them)."""
         T = self.t
-        if T > 0:
+        if len(self._rings) > 1:
+            nxt = (self.ring_index + 1) % len(self._rings)
+            ring, since = self._rings[nxt]
+            ring[0:4].copy_(self.ring[T:T + 4])
+            since[0:4].copy_(self.since[T:T + 4])
+            self.ring, self.since, self.ring_index = ring, since, nxt
+        elif T > 0:
             self.ring[0:4].copy_(self.ring[T:T + 4].clone())
             self.since[0:4].copy_(self.since[T:T + 4].clone())
         self.t = 0
@@ -280,6 +301,9 @@ class DeviceVectorEnv(object):
         if self.device.type == 'cuda':
             torch.cuda.synchronize(self.device)
         d = {k: getattr(self, k).detach().cpu().clone() for k in self._STATE_TENSORS}
+        if len(self._rings) > 1:   # every ring (a collected, not yet learned rollout lives in a non-current one)
+            d['rings'] = [(r.detach().cpu().clone(), s_.detach().cpu().clone()) for r, s_ in self._rings]
+            d['ring_index'] = self.ring_index
         if self.link is not None:  # elastic ring layout
             d['link'], d['cur_slot'] = self.link.detach().cpu().clone(), self.cur_slot.detach().cpu().clone()
         d['meta'] = {'env_name': self.env_name, 'envs_num': self.envs_num, 'dim': self.dim, 'horizon': self.horizon,
@@ -295,6 +319,13 @@ class DeviceVectorEnv(object):
                                  (k, getattr(self, k), m[k]))
         if self.device.type == 'cuda':
             torch.cuda.synchronize(self.device)  # nothing in flight on any stream may still read / write the state
+        if 'rings' in d:
+            self.ensure_rings(len(d['rings']))
+            for (r, s_), (cr, cs) in zip(self._rings, d['rings']):
+                r.copy_(cr.to(self.device))
+                s_.copy_(cs.to(self.device))
+            self.ring_index = int(d['ring_index'])
+            self.ring, self.since = self._rings[self.ring_index]
         for k in self._STATE_TENSORS:
             getattr(self, k).copy_(d[k].to(self.device))
         if 'link' in d:

@@ -33,15 +33,66 @@ def _policy_and_draw(model, obs, logits_out, actions_out, seed, offset, row0, of
     ops.policy_sample_into(logits_out, actions_out, seed, offset, row0)
 
 
+class RingBatch(object):
+    """The observations of a collected rollout, NOT materialised: they are the single frames of ring `index` of the
+    env (the reference's actor ships `obs` as a [T*E, 4, d, d] array, examples/IMPALA/actor.py:78-89; four stacked
+    copies of every frame).  A learner takes the rows it needs when it needs them: `gather_sequences` (the T rows of
+    sequences [b0, b0 + nb), time-major — one 1000-row update of the reference's train_batch_size) or `materialize`
+    (the whole [T*E, 4, d, d] batch).  Valid until the env writes that ring again (the rollout after next)."""
+
+    def __init__(self, env, index, T):
+        self.env, self.index, self.T = env, int(index), int(T)
+        E = env.envs_num
+        self.shape = (self.T * E, 4, env.dim, env.dim)
+        self.dtype, self.device, self.is_cuda = torch.uint8, env.device, env.device.type == 'cuda'
+        self._idx = {}
+
+    def _indices(self, b0, nb):
+        key = (int(b0), int(nb))
+        hit = self._idx.get(key)
+        if hit is None:
+            T, dev = self.T, self.device
+            slots = (torch.arange(T, dtype=torch.int32, device=dev) + 3).repeat_interleave(nb)
+            envs = (torch.arange(nb, dtype=torch.int32, device=dev) + b0).repeat(T)
+            hit = self._idx[key] = (slots, envs)
+        return hit
+
+    def gather_sequences(self, b0, nb, out=None):
+        slots, envs = self._indices(b0, nb)
+        return self.env.gather(slots, envs, out, ring_index=self.index)
+
+    def materialize(self, out=None):
+        return self.gather_sequences(0, self.env.envs_num, out)
+
+    def record_stream(self, stream):   # the ring is a long-lived tensor of the env, not an allocation of this batch
+        pass
+
+    # tensor-like conveniences for host code that inspects a batch (tests, tools): each materialises a fresh tensor
+    def clone(self):
+        return self.materialize()
+
+    def reshape(self, *shape):
+        return self.materialize().reshape(*shape)
+
+    view = reshape
+
+    def cpu(self):
+        return self.materialize().cpu()
+
+
 class DeviceRollout(object):
-    def __init__(self, env, sample_batch_steps, seed=0, n_buffers=1):
+    def __init__(self, env, sample_batch_steps, seed=0, n_buffers=1, lazy_obs=False):
         """n_buffers > 1: successive collect() calls fill the trajectory slabs round-robin, so a
         learner on another stream can still read batch i-1 while batch i is being written
-        (AsyncActorLearner below)."""
+        (AsyncActorLearner below).  lazy_obs: the batch's 'obs' is a RingBatch (the env gets one frame ring per
+        buffer) instead of a materialised [T*E, 4, d, d] tensor per buffer."""
         assert env.horizon >= sample_batch_steps, 'env ring too short for the rollout'
         self.env, self.T, self.seed = env, int(sample_batch_steps), int(seed)
         E, A, dev = env.envs_num, env.act_dim, env.device
         T = self.T
+        self.lazy_obs = bool(lazy_obs)
+        if self.lazy_obs:
+            env.ensure_rings(max(2, int(n_buffers)))
         self._bufs = []
         for _ in range(int(n_buffers)):
             self._bufs.append({
@@ -49,8 +100,11 @@ class DeviceRollout(object):
                 'behaviour_logits': torch.zeros((T, E, A), dtype=torch.float32, device=dev),
                 'rewards': torch.zeros((T, E), dtype=torch.float32, device=dev),
                 'dones': torch.zeros((T, E), dtype=torch.uint8, device=dev),
-                'obs': torch.zeros((T * E, 4, env.dim, env.dim), dtype=torch.uint8, device=dev),
             })
+            if not self.lazy_obs:
+                self._bufs[-1]['obs'] = torch.zeros((T * E, 4, env.dim, env.dim), dtype=torch.uint8, device=dev)
+        self._ring_of_buf = [0] * int(n_buffers)   # lazy_obs: the env ring a buffer's rollout was written to
+        self._ring_batches = {}
         self._cur = -1
         self._select(0)
         self._obs_step = torch.zeros((E, 4, env.dim, env.dim), dtype=torch.uint8, device=dev)
@@ -70,7 +124,7 @@ class DeviceRollout(object):
     def _select(self, k):
         b = self._bufs[k]
         self.actions, self.behaviour_logits = b['actions'], b['behaviour_logits']
-        self.rewards, self.dones, self.obs = b['rewards'], b['dones'], b['obs']
+        self.rewards, self.dones, self.obs = b['rewards'], b['dones'], b.get('obs')
 
     @torch.no_grad()
     def collect_begin(self):
@@ -85,6 +139,7 @@ class DeviceRollout(object):
         self._base_count = self.step_count
         if self._step_base.is_cuda:
             self._step_base.fill_(self.step_count)
+        self._ring_of_buf[self._cur] = env.ring_index
 
     @torch.no_grad()
     def collect_step(self, model, t):
@@ -117,7 +172,7 @@ class DeviceRollout(object):
                 self.collect_step(model, t)
             return
         env = self.env
-        key = (self._cur, int(t0), int(t1), id(model))
+        key = (self._cur, env.ring_index, int(t0), int(t1), id(model))   # the slabs of buffer _cur, the frames of ring ring_index
         g = self._graphs.get(key)
         if g is None:
             runs = self._segment_runs.get(key, 0)
@@ -145,8 +200,14 @@ class DeviceRollout(object):
     def _batch_view(self):
         """the time-major batch over the selected trajectory buffer"""
         E = self.env.envs_num
+        obs = self.obs
+        if self.lazy_obs:
+            key = (self._cur, self._ring_of_buf[self._cur])
+            obs = self._ring_batches.get(key)
+            if obs is None:
+                obs = self._ring_batches[key] = RingBatch(self.env, self._ring_of_buf[self._cur], self.T)
         return {
-            'obs': self.obs,
+            'obs': obs,
             'actions': self.actions.reshape(self.T * E),
             'behaviour_logits': self.behaviour_logits.reshape(self.T * E, -1),
             'rewards': self.rewards.reshape(self.T * E),
@@ -155,7 +216,8 @@ class DeviceRollout(object):
 
     @torch.no_grad()
     def collect_end(self):
-        self.env.gather(self._slots, self._envs, self.obs)
+        if not self.lazy_obs:
+            self.env.gather(self._slots, self._envs, self.obs)
         return self._batch_view()
 
     def collect_steps(self, model):
@@ -175,7 +237,7 @@ class DeviceRollout(object):
         if self.ep_stats.is_cuda:
             torch.cuda.synchronize(self.ep_stats.device)
         return {'step_count': self.step_count, 'started': self.started, 'cur': self._cur, 'seed': self.seed,
-                'ep_stats': self.ep_stats.detach().cpu().clone()}
+                'ep_stats': self.ep_stats.detach().cpu().clone(), 'ring_of_buf': list(self._ring_of_buf)}
 
     def buffer_state(self, k):
         """the trajectory slabs of buffer k (a collected batch somebody still has to learn from)"""
@@ -189,6 +251,8 @@ class DeviceRollout(object):
         if d['seed'] != self.seed:
             raise ValueError('rollout seed %r differs from the checkpoint (%r)' % (self.seed, d['seed']))
         self.step_count, self.started, self._cur = int(d['step_count']), bool(d['started']), int(d['cur'])
+        if 'ring_of_buf' in d and len(d['ring_of_buf']) == len(self._ring_of_buf):
+            self._ring_of_buf = [int(x) for x in d['ring_of_buf']]
         if self._cur >= 0:
             self._select(self._cur)
         self.ep_stats.copy_(d['ep_stats'].to(self.ep_stats.device))
@@ -474,7 +538,9 @@ class AsyncActorLearner(object):
         if elastic and len(self.envs) != 1:
             raise ValueError('elastic rollouts take one env group')
         cls = ElasticDeviceRollout if elastic else DeviceRollout
-        self.rollouts = [cls(e, sample_batch_steps, seed=seed, n_buffers=2) for e in self.envs]
+        lazy = not elastic and bool(int(os.environ.get('PARL_AMD_LAZY_OBS', '1')))   # obs stay in the frame rings (RingBatch)
+        self.rollouts = [cls(e, sample_batch_steps, seed=seed, n_buffers=2, **({'lazy_obs': True} if lazy else {})) for e in self.envs]
+        self._obs_full = {}   # one materialised [T*E, 4, d, d] batch per env group for the one-update-per-rollout mode
         self.rollout = self.rollouts[0]
         self.actor_model = copy.deepcopy(alg.model)
         for p in self.actor_model.parameters():
@@ -722,13 +788,14 @@ class AsyncActorLearner(object):
             if self.sub_batches:
                 out = self._learn_sub_batches(batches[0], learning_rate, entropy_coeff)
             elif len(batches) == 1:
-                b = batches[0]
+                b = self._materialized(batches[0], 0)
                 self.updates += 1
                 out = self.alg.learn(b['obs'], b['actions'], b['behaviour_logits'], b['rewards'], b['dones'],
                                      learning_rate, entropy_coeff, time_major=True)
             else:
                 self.updates += 1
-                out = self.alg.learn_batches(batches, learning_rate, entropy_coeff, time_major=True)
+                out = self.alg.learn_batches([self._materialized(b, g) for g, b in enumerate(batches)], learning_rate,
+                                             entropy_coeff, time_major=True)
             if self.gather_small:  # per-step scalars of the batch just learned, for global statistics
                 from . import dist as pdist
                 self.gathered = [pdist.all_gather_small({'rewards': b['rewards'], 'dones': b['dones'].to(torch.uint8),
@@ -742,6 +809,18 @@ class AsyncActorLearner(object):
                 v.record_stream(ls)
         self.pending = self._collect()
         return out
+
+    def _materialized(self, batch, g):
+        """a batch whose observations are still in the env's ring (RingBatch) with the stacks gathered — on the
+        LEARNER stream, into ONE buffer per env group (the ring keeps the frames until the rollout after next)"""
+        if not isinstance(batch['obs'], RingBatch):
+            return batch
+        buf = self._obs_full.get(g)
+        if buf is None:
+            buf = self._obs_full[g] = torch.empty(batch['obs'].shape, dtype=torch.uint8, device=batch['obs'].device)
+        b = dict(batch)
+        b['obs'] = batch['obs'].materialize(buf)
+        return b
 
     def state_dict(self):
         """Everything of the PIPELINE a resumed run needs next to the model / optimizer the caller saves

@@ -270,3 +270,42 @@ def test_rollout_segments_as_hipgraphs_equal_the_eager_steps(dev):
     for it, (x, y) in enumerate(zip(a, b)):
         for k in x:
             assert torch.equal(x[k], y[k]), (it, k)
+
+
+def test_pipeline_with_observations_left_in_the_frame_rings_equals_materialised_batches(dev, monkeypatch):
+    """AsyncActorLearner keeps a rollout's observations in the env's frame rings (one ring per trajectory buffer,
+    rollout.RingBatch) and every 1000-row-style update gathers its sequences straight from there — against the
+    pipeline that materialises a [T*E, 4, d, d] batch per rollout (PARL_AMD_LAZY_OBS=0): the same parameters, bit
+    for bit, after several rollouts of graph-replayed updates with mid-rollout weight refreshes, and in the
+    one-update-per-rollout mode."""
+    import parl_amd as parl
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel42
+    from parl_amd.rollout import AsyncActorLearner, RingBatch
+    E, T = 24, 10
+    for tb in (4 * T, None):
+        outs = []
+        for lazy in ('1', '0'):
+            monkeypatch.setenv('PARL_AMD_LAZY_OBS', lazy)
+            torch.manual_seed(0)
+            env = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=42, horizon=T, seed=13, device=dev, max_episode_steps=50)
+            model = AtariModel42(env.act_dim).to(dev)
+            with torch.no_grad():
+                model.policy_fc.weight.mul_(0.05)
+                model.value_fc.weight.mul_(0.05)
+            alg = parl.algorithms.IMPALA(model, sample_batch_steps=T, gamma=0.99, vf_loss_coeff=0.5,
+                                         clip_rho_threshold=1.0, clip_pg_rho_threshold=1.0)
+            pipe = AsyncActorLearner(alg, [env], T, seed=3, train_batch_size=tb)
+            for _ in range(5):
+                pipe.step(1e-3, -0.01)
+            pipe.synchronize()
+            obs = pipe.pending[0][0]['obs']
+            assert isinstance(obs, RingBatch) == (lazy == '1')
+            if lazy == '1':
+                assert len(env._rings) == 2 and 'obs' not in pipe.rollout._bufs[0]
+            outs.append(([p.detach().clone() for p in model.parameters()], obs.clone(), pipe.updates))
+            env.check_faults()
+        (pa, oa, ua), (pb, ob, ub) = outs
+        assert ua == ub and torch.equal(oa, ob)
+        for a, b in zip(pa, pb):
+            assert torch.equal(a, b)

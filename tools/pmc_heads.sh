@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: SQ counters of impala_heads_loss_kernel at the workload shape, per wave.  Usage: tools/pmc_heads.sh <out.log>
+# GPU box: SQ counters of impala_heads_loss_q_kernel at the workload shape, per wave.  Usage: tools/pmc_heads.sh <out.log>
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 LOG=${1:-$R/gpurun_out/heads_pmc.log}
@@ -12,7 +12,7 @@ import csv, glob, collections
 agg = collections.defaultdict(float); cnt = collections.Counter()
 for f in glob.glob('$O/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'impala_heads_loss_kernel' in r['Kernel_Name']:
+        if 'impala_heads_loss_q_kernel' in r['Kernel_Name']:
             agg[r['Counter_Name']] += float(r['Counter_Value']); cnt[r['Counter_Name']] += 1
 print({c: round(v / cnt[c]) for c, v in agg.items()}, '(per launch, summed over the chip)')
 PY

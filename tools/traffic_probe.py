@@ -110,7 +110,7 @@ rw = torch.randn(T, B, device=dev)
 dn = torch.rand(T, B, device=dev) < 0.01
 flush_cache()
 ops.impala_heads_loss(hd, wp, bp, wv, bv, bl, ac, rw, dn, 0.99)
-out['impala_heads_loss_T50_B1024_A6'] = {'kernel': 'impala_heads_loss_kernel',
+out['impala_heads_loss_T50_B1024_A6'] = {'kernel': 'impala_heads_loss_q_kernel',
                                          'read': T * B * (1024 + A * 4 + 8 + 4 + 1), 'write': T * B * 1024 + (T - 1) * B * 8}
 torch.cuda.synchronize()
 print(json.dumps(out))
