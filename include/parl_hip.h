@@ -304,6 +304,23 @@ int parlhip_atari_vec_step(void* states, const uint32_t* rom_table_dev, uint32_t
                            int32_t* ep_lengths, int E, uint64_t seed, uint64_t env_id0,
                            int64_t max_episode_steps, const void* reset_cache_dev,
                            int32_t* jam_flag_dev, parlhip_stream_t stream);
+/* VectorEnv.step WITH its observation (parl/env/vector_env.py:41-63 returns the stacked obs of the step; the
+ * chain behind it: MaxAndSkipEnv max atari_wrappers.py:239, WarpFrame :263-267, FrameStack :270-306): what
+ * parlhip_atari_vec_step + parlhip_frame_post_step_u8(fmt 1, flags = obs_flags) do in two launches, in ONE —
+ * each env's two wavefronts convert its frame pair at their tail, as soon as the picture is drawn, instead of a
+ * second launch that waits for the slowest env of the grid.  Bit-identical outputs.  obs_out u8 [E, dim*dim] (the
+ * ring slot of this step), tables_dev from parlhip_frame_post_tables_init(dim), since_prev (may be NULL) /
+ * since_next u8 [E] as in parlhip_frame_post_since_u8, ep_acc3 f64 [3] as in parlhip_episode_stats_accum_f64 (may
+ * be NULL).  `frames` still receives the raw pair.  PARLHIP_ENOSUP unless dim is 42 or 84 and the cartridge is
+ * an unbanked 2K one (the tail's LDS is the half of the cartridge table a 2K cartridge leaves free): the caller
+ * then uses the two-launch form.                                                                       */
+int parlhip_atari_vec_step_obs(void* states, const uint32_t* rom_table_dev, uint32_t rom_size, int game,
+                               const int64_t* actions, uint8_t* frames, float* rewards, uint8_t* dones,
+                               uint8_t* obs_flags, float* ep_returns, int32_t* ep_lengths, int E,
+                               uint64_t seed, uint64_t env_id0, int64_t max_episode_steps,
+                               const void* reset_cache_dev, int32_t* jam_flag_dev, uint8_t* obs_out, int dim,
+                               const void* tables_dev, const uint8_t* since_prev, uint8_t* since_next,
+                               double* ep_acc3, parlhip_stream_t stream);
 /* Elastic VectorEnv.step (examples/IMPALA/actor.py:58-76 collects sample_batch_steps steps of every env;
  * the reference's actors are independent processes, so one actor's slow step never holds up another's).
  * A launch emulates at most `frame_budget` (>= 4) frames per env: an env whose step needs more — the 12

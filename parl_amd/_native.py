@@ -76,6 +76,9 @@ SIGNATURES = {
     (_i, [_p, _p, ctypes.c_uint32, _i, _p, _p, _i, _u64, _u64, _i64, _p, _p]),
     'parlhip_atari_vec_step':
     (_i, [_p, _p, ctypes.c_uint32, _i, _p, _p, _p, _p, _p, _p, _p, _i, _u64, _u64, _i64, _p, _p, _p]),
+    'parlhip_atari_vec_step_obs':
+    (_i, [_p, _p, ctypes.c_uint32, _i, _p, _p, _p, _p, _p, _p, _p, _i, _u64, _u64, _i64, _p, _p, _p, _i, _p, _p, _p, _p,
+          _p]),
     'parlhip_atari_vec_step_elastic':
     (_i, [_p, _p, ctypes.c_uint32, _i, _p, _p, _p, _p, _p, _p, _p, _i, _u64, _u64, _i64, _p, _p, _i, _i, _i, _i, _i] +
      [_p] * 7 + [_i] + [_p] * 4),

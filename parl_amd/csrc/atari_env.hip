@@ -16,6 +16,7 @@
 // that the 6507/TIA code exists once in the kernel (instruction-cache footprint).
 #include "common.hpp"
 #include "atari_core.hpp"
+#include "frame_tail.hpp"
 #include "philox.hpp"
 
 namespace parlhip {
@@ -31,6 +32,23 @@ struct EnvParams {
   long long max_episode_steps;
   int budget;  // elastic stepping: frames one launch may emulate per env (0: every step runs to its end)
 };
+
+// What a launch does besides VectorEnv.step itself (parlhip_atari_vec_step_obs).  It is the FIRST kernel argument
+// and the kernel body never names it: the two ends of the launch read it through the kernarg segment pointer where
+// they need it (fuse_args()).  A named argument is loaded in the entry block and stays live across wave A's frame
+// loop — whose register allocation does not forgive that (six pointers as plain arguments once took the kernel from
+// 420 to 24,881 SGPR spills, see elastic stepping below); the kernarg pointer is one SGPR pair.
+struct StepFuse {
+  // tail: the observation (frame_tail.hpp).  obs_out == nullptr: the colour frames stay raw and a
+  // parlhip_frame_post_*_u8 launch follows
+  uint8_t* obs_out;           // [E, dim * dim]: the ring slot of this step
+  const uint8_t* tables;      // parlhip_frame_post_tables_init blob
+  const uint8_t* since_prev;  // [E] FrameStack counters of the previous slot, or null (= 0)
+  uint8_t* since_next;        // [E]
+  double* ep_acc;             // [3] MonitorEnv sums (parlhip_episode_stats_accum_f64), or null
+  int dim, pad;
+};
+DEVI const StepFuse* fuse_args() { return (const StepFuse*)__builtin_amdgcn_kernarg_segment_ptr(); }
 
 // Elastic stepping (parlhip_atari_vec_step_elastic): a launch emulates at most `budget` frames per
 // env.  An env whose step needs more (the 12 frames of a life-loss reset: EpisodicLifeEnv's NOOP step +
@@ -126,7 +144,7 @@ __device__ unsigned long long g_env_regions[8192][16];
 // allocation with the translated cartridges (the biggest function of the library, 500-1500 SGPR spills), and the
 // sixteen scalar registers of its register file went to spill lanes.  One call per launch; the arguments arrive in
 // vector registers (the calling convention) and are made wave-uniform again.
-__device__ __attribute__((noinline)) void picture_wave_main(uint8_t* blob_v, const uint8_t* snap_v, RenderQueue* rq_v, int e_v) {
+__device__ __attribute__((noinline)) int picture_wave_main(uint8_t* blob_v, const uint8_t* snap_v, RenderQueue* rq_v, int e_v) {
   auto uni = [](const void* p) -> unsigned long long {
     const unsigned long long x = (unsigned long long)(uintptr_t)p;
     return ((unsigned long long)(uint32_t)rfl((int)(x >> 32)) << 32) | (uint32_t)rfl((int)(uint32_t)x);
@@ -139,7 +157,10 @@ __device__ __attribute__((noinline)) void picture_wave_main(uint8_t* blob_v, con
 #ifdef PARLHIP_ENV_REGIONS
   for (int i = 0; i < 5; ++i) { r.rt[i] = 0; r.rn[i] = 0; }
 #endif
-  r.render_main(blob, snap, kSnapBytes);
+  const uint32_t exit_w0 = r.render_main(blob, snap, kSnapBytes);
+  // the launch's last frame is drawn and stored: the env's CPU wave may read the frame pair (observation tail)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __atomic_store_n(&r.rq->fin, 1u, __ATOMIC_RELAXED);
 #ifdef PARLHIP_ENV_REGIONS
   const int e = rfl(e_v);
   if (r.lane == 0 && e < 8192) { g_env_regions[e][9] = r.rt[3]; g_env_regions[e][10] = r.rt[4]; g_env_regions[e][11] = r.rt[0];
@@ -147,6 +168,7 @@ __device__ __attribute__((noinline)) void picture_wave_main(uint8_t* blob_v, con
 #else
   (void)e_v;
 #endif
+  return (int)exit_w0;
 }
 
 // Two wavefronts per env (atari_core.hpp): waves 0 .. 3 of a workgroup run the 6507 / RIOT / wrapper chain of its
@@ -159,7 +181,7 @@ __device__ __attribute__((noinline)) void picture_wave_main(uint8_t* blob_v, con
 // 9 ms of every 50 ms rollout waiting for the learner's pass; tools/actor_gaps.sh).
 template <int GAME>
 __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
-    uint8_t* __restrict__ states, const uint32_t* __restrict__ romw_g, EnvParams prm,
+    StepFuse /* read through fuse_args(), see StepFuse */, uint8_t* __restrict__ states, const uint32_t* __restrict__ romw_g, EnvParams prm,
     const long long* __restrict__ actions, uint8_t* __restrict__ frames,
     float* __restrict__ rewards, uint8_t* __restrict__ dones, uint8_t* __restrict__ obs_flags,
     float* __restrict__ ep_returns, int* __restrict__ ep_lengths,
@@ -168,7 +190,9 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
   __shared__ uint32_t rom_lds[kMaxRomWords];
   __shared__ RenderQueue rqs[kEnvsPerBlock];
   for (int i = threadIdx.x; i < prm.rom_size; i += blockDim.x) rom_lds[i] = romw_g[i];
-  if (threadIdx.x < kEnvsPerBlock) { rqs[threadIdx.x].wr = 0; rqs[threadIdx.x].rd = 0; rqs[threadIdx.x].cx = 0; }
+  if (threadIdx.x < kEnvsPerBlock) { rqs[threadIdx.x].wr = 0; rqs[threadIdx.x].rd = 0; rqs[threadIdx.x].cx = 0; rqs[threadIdx.x].fin = 0; }
+  // the observation tail's two colour tables, in the half of rom_lds a 2K cartridge leaves free
+  if (fuse_args()->obs_out) obs_tail_stage_tables(rom_lds + kMaxRomWords / 2, fuse_args()->tables, threadIdx.x);
   __syncthreads();
   // One wavefront per env is a long serial dependency chain: when other kernels (the learner's
   // GEMMs on another stream) share the SIMD, this wave should win every issue arbitration.
@@ -193,7 +217,13 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
   const int mode = prm.mode, game = prm.game;
   if (picture_wave) {
     uint8_t* rblob = mode == MODE_SNAPSHOT ? snap + (size_t)e * kSnapBytes : states + (size_t)e * kStateBytes;
-    picture_wave_main(rblob, snap, &rqs[slot], e);
+    const int exit_w0 = rfl(picture_wave_main(rblob, snap, &rqs[slot], e));
+    if (exit_w0 & 0x100) {   // wave A asks for the observation: this wave takes the lower half of the picture
+      const StepFuse* fz = fuse_args();
+      const int dim = fz->dim;
+      obs_tail_dispatch(frames + (size_t)e * 2 * kFrameBytes, fz->obs_out + (size_t)e * dim * dim, fz->tables,
+                        rom_lds + kMaxRomWords / 2, dim, 1, exit_w0 & 1, wave);
+    }
     return;
   }
   const bool native_ok = NativeCart<GAME>::present && rfl((int)(rom_lds[0] >> 28)) == GAME;
@@ -472,9 +502,35 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
     sc[S_SUSP_TOTAL] = skip_total; sc[S_SUSP_ACT] = skip_act;
     sc[S_SUSP_ALE_J] = ale_j; sc[S_SUSP_NOOPS] = noops_left;
   }
-  emu.rq_ctl(Emu::LA_EXIT, 0, 0);
+  // the observation in this launch (parlhip_atari_vec_step_obs): the env's two waves convert its frame pair, half
+  // the picture each, as soon as wave B has drawn it; the FrameStack counter and the MonitorEnv sums of the step
+  // (what frame_post_kernel does on the side) are this wave's
+  const StepFuse* fz = fuse_args();
+  uint8_t* obs_out = mode == MODE_STEP ? fz->obs_out : nullptr;
+  const bool do_obs = obs_out != nullptr && phase == PH_END;
+  emu.rq_ctl(Emu::LA_EXIT, (uint32_t)((do_obs ? 0x100 : 0) | (v.obs_single ? 1 : 0)), 0);
   emu.rq_flush();
   store_env(emu, v, blob, lane);
+  if (obs_out) {
+    if (lane == 0) {
+      const uint8_t* sp = fz->since_prev;
+      const int p = sp ? sp[e] : 0;
+      fz->since_next[e] = (phase != PH_END || did_reset) ? 0 : (uint8_t)(p + 1 > 3 ? 3 : p + 1);
+      double* acc = fz->ep_acc;
+      if (acc && ep_closed && ep_length > 0) {
+        atomicAdd(acc + 0, 1.0);
+        atomicAdd(acc + 1, (double)(float)ep_return);
+        atomicAdd(acc + 2, (double)ep_length);
+      }
+    }
+    if (do_obs) {
+      while (Emu::lds_ld(&emu.rq->fin) == 0u) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const int dim = fz->dim;
+      obs_tail_dispatch(buf0, obs_out + (size_t)e * dim * dim, fz->tables, rom_lds + kMaxRomWords / 2, dim, 0,
+                        v.obs_single, wave);
+    }
+  }
 #ifdef PARLHIP_ENV_TIMING
   if (lane == 0 && e < 8192) g_env_t1[e] = wall_clock64();
 #endif
@@ -591,11 +647,12 @@ static int launch_env(int mode, void* states, const uint32_t* romw, uint32_t rom
                       const int64_t* actions, uint8_t* frames, float* rewards, uint8_t* dones,
                       uint8_t* obs_flags, float* ep_returns, int32_t* ep_lengths, int E, uint64_t seed,
                       uint64_t env_id0, int64_t max_steps, void* snap, int32_t* jam, hipStream_t s,
-                      int budget = 0, const uint8_t* ctl = nullptr) {
+                      int budget = 0, const uint8_t* ctl = nullptr, const StepFuse* fuse = nullptr) {
+  const StepFuse fz = fuse ? *fuse : StepFuse{};
   EnvParams prm{game, (int)rom_size, E, mode, seed, env_id0, (long long)max_steps, budget};
   const dim3 grid(ceil_div(E, kEnvsPerBlock)), block(128 * kEnvsPerBlock);
 #define PARLHIP_LAUNCH_ENV(G)                                                                           \
-  atari_env_kernel<G><<<grid, block, 0, s>>>((uint8_t*)states, romw, prm, (const long long*)actions,     \
+  atari_env_kernel<G><<<grid, block, 0, s>>>(fz, (uint8_t*)states, romw, prm, (const long long*)actions, \
                                              frames, rewards, dones, obs_flags, ep_returns, ep_lengths, \
                                              (uint8_t*)snap, jam, ctl)
   if (game == GAME_PONG) PARLHIP_LAUNCH_ENV(GAME_PONG);
@@ -642,6 +699,28 @@ PARLHIP_EXPORT int parlhip_atari_vec_step(void* states, const uint32_t* rom_tabl
   return launch_env(MODE_STEP, states, rom_table_dev, rom_size, game, actions, frames, rewards, dones,
                     obs_flags, ep_returns, ep_lengths, E, seed, env_id0, max_episode_steps,
                     (void*)reset_cache_dev, jam_flag_dev, (hipStream_t)stream);
+}
+
+PARLHIP_EXPORT int parlhip_atari_vec_step_obs(void* states, const uint32_t* rom_table_dev, uint32_t rom_size, int game,
+                                              const int64_t* actions, uint8_t* frames, float* rewards,
+                                              uint8_t* dones, uint8_t* obs_flags, float* ep_returns,
+                                              int32_t* ep_lengths, int E, uint64_t seed, uint64_t env_id0,
+                                              int64_t max_episode_steps, const void* reset_cache_dev,
+                                              int32_t* jam_flag_dev, uint8_t* obs_out, int dim,
+                                              const void* tables_dev, const uint8_t* since_prev,
+                                              uint8_t* since_next, double* ep_acc3, parlhip_stream_t stream) {
+  int rc = check_env_args(states, rom_table_dev, rom_size, game, E);
+  if (rc) return rc;
+  if (!obs_tail_supports(dim, (int)rom_size)) return PARLHIP_ENOSUP;  // the caller launches parlhip_frame_post_step_u8 instead
+  if (E == 0) return PARLHIP_OK;
+  if (!actions || !frames || !rewards || !dones || !obs_flags || !ep_returns || !ep_lengths || !jam_flag_dev ||
+      !obs_out || !tables_dev || !since_next)
+    return PARLHIP_EINVAL;
+  if (reinterpret_cast<uintptr_t>(frames) & 15) return PARLHIP_EINVAL;   // the tail reads the frame pair as uint4s
+  const StepFuse fz{obs_out, (const uint8_t*)tables_dev, since_prev, since_next, ep_acc3, dim, 0};
+  return launch_env(MODE_STEP, states, rom_table_dev, rom_size, game, actions, frames, rewards, dones,
+                    obs_flags, ep_returns, ep_lengths, E, seed, env_id0, max_episode_steps,
+                    (void*)reset_cache_dev, jam_flag_dev, (hipStream_t)stream, 0, nullptr, &fz);
 }
 
 PARLHIP_EXPORT int parlhip_atari_vec_step_elastic(void* states, const uint32_t* rom_table_dev, uint32_t rom_size,

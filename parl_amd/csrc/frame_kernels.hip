@@ -2,6 +2,7 @@
 // single frames.  Reference: parl/env/atari_wrappers.py:239, :263-267, :270-306.
 #include "common.hpp"
 #include "atari_defs.hpp"
+#include "frame_defs.hpp"
 #include <math.h>
 #include <string.h>
 #include <vector>
@@ -17,16 +18,6 @@ namespace atari {
 // once with 16-byte loads, reduced to max-RGB gray in LDS, then area-resampled from LDS.
 // Algorithmic bytes per env-step: 2*33,600 read + dim*dim written.
 // ========================================================================================
-struct Tap { int si; float alpha; };
-
-DEVI uint32_t gray_of_colors(uint32_t c0, uint32_t c1, const uint32_t* pal) {
-  const uint32_t a = pal[c0 >> 1], b = pal[c1 >> 1];
-  const uint32_t r0 = (a >> 16) & 255, g0 = (a >> 8) & 255, b0 = a & 255;
-  const uint32_t r1 = (b >> 16) & 255, g1 = (b >> 8) & 255, b1 = b & 255;
-  const uint32_t r = r0 > r1 ? r0 : r1, g = g0 > g1 ? g0 : g1, bb = b0 > b1 ? b0 : b1;
-  return (r * 4899u + g * 9617u + bb * 1868u + 8192u) >> 14;
-}
-
 // LDS of one workgroup: gray frame + palette + the tap tables, sized by the bound of area_tab
 // (<= src + 2 * dst taps per axis) so that dim <= 84 fits 4 workgroups per CU (<= 40 KB each)
 static inline size_t frame_post_lds_bytes(int dim) {

@@ -1,0 +1,223 @@
+// frame_tail.hpp — MaxAndSkipEnv max + WarpFrame (frame_post) at the TAIL of an env's two wavefronts
+// (atari_env.hip, parlhip_atari_vec_step_obs): the observation leaves the launch that emulated it.
+//
+// Reference: parl/env/atari_wrappers.py:239 (max over the last two raw frames), :263-267 (WarpFrame:
+// gray + cv2.resize INTER_AREA), restated in oracle/frame_oracle.c; arithmetic and float operation order are
+// those of frame_post_kernel (frame_kernels.hip), with which this path is bit-identical by test.
+//
+// Why here: as its own launch frame_post is 27 us (42 in the pipeline) + a launch gap on the actors' critical path,
+// and it cannot start before the SLOWEST env of the grid has finished; here every env converts its own pair of
+// frames as soon as its picture wave has drawn them, and only the slowest env's conversion is exposed.
+// How: the 210 source rows are 42 bands of 5; an output row's INTER_AREA taps never leave its band for dim in
+// {42, 84} (210 / 5 = 42 divides dim).  The env's CPU wave takes bands 0 .. 20, its picture wave 21 .. 41 — no
+// barrier between them, each has its own 800-byte gray band in LDS.  Per band: 50 lanes load one uint4 of each
+// colour frame (the next band's are already in flight), max + gray through the two LDS tables, band to LDS, then
+// lane = output column: the band's y taps (prefetched by lanes 0 .. 15) times the lane's x taps (registers).
+// LDS: the upper half of the cartridge table's 16 KB (an unbanked 2K cartridge — Pong, Breakout — fills the lower
+// half; a 4K cartridge takes the separate launch): no byte added to the env kernel's static LDS, which is what
+// lets it sit beside two 70 KB learner workgroups on a CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "atari_defs.hpp"
+#include "frame_defs.hpp"
+
+namespace parlhip {
+namespace atari {
+
+#ifndef DEVI
+#define DEVI __device__ __forceinline__
+#endif
+
+typedef __attribute__((address_space(3))) uint8_t tail_lds_u8;
+typedef __attribute__((address_space(3))) uint32_t tail_lds_u32;
+typedef uint32_t tail_u4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) tail_u4 tail_lds_u4;
+typedef __attribute__((address_space(1))) uint8_t tail_glb_u8;
+typedef __attribute__((address_space(1))) const tail_u4 tail_glb_cu4;
+
+constexpr int kTailBandRows = 5;                       // source rows per band
+constexpr int kTailBands = kH / kTailBandRows;         // 42
+constexpr int kTailBandBytes = kTailBandRows * kW;     // 800
+constexpr int kTailBandLanes = kTailBandBytes / 16;    // 50 lanes load a band
+constexpr int kTailLdsPal = 0, kTailLdsG1 = 512, kTailLdsBands = 1024;   // byte offsets in the free half of rom_lds
+constexpr int kTailLdsBytes = kTailLdsBands + 8 * kTailBandBytes;        // 7,424 <= 8,192
+static_assert(kH % kTailBandRows == 0 && kTailBandBytes % 16 == 0, "bands are whole uint4s");
+
+__host__ __device__ inline bool obs_tail_supports(int dim, int rom_words) {
+  return (dim == 42 || dim == 84) && rom_words == 2048;
+}
+
+// the workgroup's colour -> RGB and colour -> gray tables (threads 0 .. 127, before the kernel's first barrier)
+DEVI void obs_tail_stage_tables(uint32_t* lds_hi, const uint8_t* blob, int tid) {
+  if (tid < 128) {
+    const int* hdr = (const int*)blob;
+    const uint32_t c = ((const uint32_t*)(blob + hdr[7]) - 128)[tid];
+    tail_lds_u8* hi = (tail_lds_u8*)(tail_lds_u32*)lds_hi;
+    ((tail_lds_u32*)(hi + kTailLdsPal))[tid] = c;
+    hi[kTailLdsG1 + tid] = (uint8_t)gray_of_rgb(c);
+  }
+}
+
+// One half (half 0: bands 0 .. 20, half 1: 21 .. 41) of one env's observation.  frames: the env's colour frame
+// pair; out: its dim x dim slot of the rollout ring; `wave`: which of the workgroup's eight band buffers is this
+// wave's.  Arguments arrive in vector registers (a call) and are made wave-uniform again.
+// The tap structure of the two supported sizes is fixed (tests/test_frame_oracle_pin.py checks the host-built tables
+// for it): dim 42 — one output row per band, its 5 y taps the band's 5 rows, <= 5 x taps per column; dim 84 — two
+// output rows per band with 3 y taps each, <= 3 x taps, 84 columns = lanes 0 .. 63 + lanes 0 .. 19.  So every loop
+// below has constant bounds: all LDS reads of a band are issued together (as a dynamic tap loop this was one LDS
+// round trip per tap: 50 us per env).
+template <int DIM>
+static __device__ __attribute__((noinline)) void obs_tail_main(const uint8_t* frames_v, uint8_t* out_v, const uint8_t* blob_v,
+                                                               uint32_t* lds_hi_v, int half_v, int single_v, int wave_v) {
+  constexpr int M = DIM / kTailBands;             // output rows per band
+  constexpr int NY = DIM == 42 ? 5 : 3;           // y taps per output row
+  constexpr int NX = DIM == 42 ? 5 : 3;           // x taps per output column (fewer: padded with weight 0)
+  constexpr int NC = DIM > 64 ? 2 : 1;            // column sets per lane
+  static_assert(DIM == 42 || DIM == 84, "obs_tail_supports");
+  auto uni = [](const void* p) -> unsigned long long {
+    const unsigned long long x = (unsigned long long)(uintptr_t)p;
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+  };
+  const int lane = (int)(threadIdx.x & 63);
+  const int half = __builtin_amdgcn_readfirstlane(half_v);
+  const int single = __builtin_amdgcn_readfirstlane(single_v), wave = __builtin_amdgcn_readfirstlane(wave_v);
+  const uint8_t* blob = (const uint8_t*)(uintptr_t)uni(blob_v);
+  tail_glb_cu4* f0 = (tail_glb_cu4*)(uintptr_t)uni(frames_v);
+  tail_glb_cu4* f1 = single ? f0 : f0 + kFrameBytes / 16;
+  tail_glb_u8* out = (tail_glb_u8*)(uintptr_t)uni(out_v);
+  tail_lds_u8* hi = (tail_lds_u8*)(tail_lds_u32*)(uint32_t*)(uintptr_t)uni(lds_hi_v);
+  const tail_lds_u32* pal = (const tail_lds_u32*)(hi + kTailLdsPal);
+  const tail_lds_u8* g1 = hi + kTailLdsG1;
+  tail_lds_u8* band = hi + kTailLdsBands + wave * kTailBandBytes;
+
+  const int* hdr = (const int*)blob;
+  const int* xstart = (const int*)(blob + hdr[3]);
+  const Tap* xt = (const Tap*)(blob + hdr[5]);
+  typedef int tail_i2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) const tail_i2 glb_tap;   // (si, alpha bits)
+  glb_tap* yt = (glb_tap*)(uintptr_t)(blob + hdr[6]);
+
+  // the lane's output columns dx = lane (+ 64 at dim 84) and their x taps; a tap past the column's count carries
+  // weight 0 on the column's first source pixel (buf + S * 0 == buf exactly: buf >= 0)
+  int xsi[NC][NX];
+  float xal[NC][NX];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int dx = lane + 64 * c;
+    const bool on = dx < DIM;
+    const int x0 = on ? xstart[dx] : 0;
+    const int nx = on ? xstart[dx + 1] - x0 : 0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const Tap t = xt[x0 + (k < nx ? k : 0)];
+      xsi[c][k] = t.si;
+      xal[c][k] = k < nx ? t.alpha : 0.f;
+    }
+  }
+
+  const int b_begin = half ? kTailBands / 2 : 0, b_end = half ? kTailBands : kTailBands / 2;
+  const bool loader = lane < kTailBandLanes;
+  // the y taps of a band, row by row: the same (row inside the band, weight) in every band — 210 / dim and dim / 42
+  // are exact in binary, so the table repeats with the band (checked on the host-built tables by the tests) —
+  // fetched once, from band 0; a per-band fetch sat in the loop as a load whose wait also drained the pixel prefetch
+  int rowoff[M * NY];
+  float beta[M * NY];
+  {
+    const tail_i2 t = yt[lane < M * NY ? lane : 0];
+#pragma unroll
+    for (int j = 0; j < M * NY; ++j) {
+      rowoff[j] = __builtin_amdgcn_readlane(t.x, j) * kW;
+      beta[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(t.y, j));
+    }
+  }
+  tail_u4 na = {0u, 0u, 0u, 0u}, nb = na;
+  auto prefetch = [&](int bi) {
+    if (loader) {
+      na = f0[bi * kTailBandLanes + lane];
+      nb = f1[bi * kTailBandLanes + lane];
+    }
+  };
+  prefetch(b_begin);
+  for (int bi = b_begin; bi < b_end; ++bi) {
+    const tail_u4 a = na, b = nb;
+    if (bi + 1 < b_end) prefetch(bi + 1);
+    // ---- max over the two frames + gray: 16 pixels per lane (frame_post_kernel's fmt == 1 arm)
+    {
+      const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+      uint32_t ow[4];
+      const bool same = (((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) & 0xfefefefeu) == 0u;
+      if (__ballot(loader && !same) == 0ull) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t o = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o |= (uint32_t)g1[(aw[q] >> (8 * j + 1)) & 127] << (8 * j);
+          ow[q] = o;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t o = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t pa = pal[((aw[q] >> (8 * j)) & 255) >> 1], pb = pal[((bw[q] >> (8 * j)) & 255) >> 1];
+            const uint32_t r0 = (pa >> 16) & 255, g0 = (pa >> 8) & 255, b0 = pa & 255;
+            const uint32_t r1 = (pb >> 16) & 255, gg1 = (pb >> 8) & 255, b1 = pb & 255;
+            const uint32_t r = r0 > r1 ? r0 : r1, g = g0 > gg1 ? g0 : gg1, bb = b0 > b1 ? b0 : b1;
+            o |= ((r * 4899u + g * 9617u + bb * 1868u + 8192u) >> 14) << (8 * j);
+          }
+          ow[q] = o;
+        }
+      }
+      if (loader) ((tail_lds_u4*)band)[lane] = tail_u4{ow[0], ow[1], ow[2], ow[3]};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- INTER_AREA: lane = output column; float operation order of the oracle (frame_post_kernel):
+    // buf = sum_k S[x_k] * alpha_k in tap order, sum = beta_0 * buf_0, then += beta_j * buf_j
+    uint8_t px[M][NC][NY][NX];
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < NY; ++j)
+#pragma unroll
+          for (int k = 0; k < NX; ++k) px[r][c][j][k] = band[rowoff[r * NY + j] + xsi[c][k]];
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+      const int dy = bi * M + r;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int dx = lane + 64 * c;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NY; ++j) {
+          float buf = 0.f;
+#pragma unroll
+          for (int k = 0; k < NX; ++k) buf = __fadd_rn(buf, __fmul_rn((float)px[r][c][j][k], xal[c][k]));
+          const float tmp = __fmul_rn(beta[r * NY + j], buf);
+          sum = (j == 0) ? tmp : __fadd_rn(sum, tmp);
+        }
+        // cv::saturate_cast<uchar>(float): cvRound (round half to even) then clamp
+        int v = (int)__builtin_rintf(sum);
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        if (dx < DIM) out[dy * DIM + dx] = (uint8_t)v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the band buffer is rewritten by the next iteration
+  }
+}
+
+// (dim is wave-uniform at the call sites: one branch, two instantiations)
+DEVI void obs_tail_dispatch(const uint8_t* frames, uint8_t* out, const uint8_t* blob, uint32_t* lds_hi, int dim, int half,
+                            int single, int wave) {
+  if (dim == 42) obs_tail_main<42>(frames, out, blob, lds_hi, half, single, wave);
+  else obs_tail_main<84>(frames, out, blob, lds_hi, half, single, wave);
+}
+
+}  // namespace atari
+}  // namespace parlhip

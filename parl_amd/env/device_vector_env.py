@@ -100,6 +100,10 @@ class DeviceVectorEnv(object):
         self.cur_slot = None  # elastic launches: [E] slot of the env's current observation
         self._env_idx = torch.arange(E, dtype=torch.int32, device=dev)
         self._slot_const = {}
+        # VectorEnv.step as ONE launch (parlhip_atari_vec_step_obs) where the kernel supports it: 42 / 84 frames of a
+        # 2K cartridge.  PARL_AMD_FUSED_OBS=0: the two-launch form (emulator, then frame_post) — A/B and parity tests
+        self.fused_obs = (self.dim in (42, 84) and self.rom_size == 2048 and
+                          os.environ.get('PARL_AMD_FUSED_OBS', '1') != '0')
         # --- O(1) real resets
         self.reset_cache = None
         if use_reset_cache:
@@ -204,6 +208,24 @@ class DeviceVectorEnv(object):
         if self.t >= self.horizon:
             raise N.ParlHipError('rollout ring full: call roll() every `horizon` steps')
         L = N.lib()
+        if self.fused_obs:
+            # the observation leaves the launch that emulated it (the env's two waves convert its frame pair at
+            # their tail): no frame_post launch behind the emulator on the actors' critical path
+            if ep_acc is not None and (ep_acc.dtype != torch.float64 or ep_acc.numel() != 3 or
+                                       ep_acc.device.type != self.device.type):
+                raise N.ParlHipError('ep_acc must be float64 [3] on the env device')
+            slot = self.t + 4
+            N.check(
+                L.parlhip_atari_vec_step_obs(
+                    N.ptr(self.states), N.ptr(self.rom_table), self.rom_size, self.game, N.ptr(actions.contiguous()),
+                    N.ptr(self.raw_frames), N.ptr(self.rewards if rewards_out is None else rewards_out),
+                    N.ptr(self.dones if dones_out is None else dones_out), N.ptr(self.obs_flags),
+                    N.ptr(self.ep_returns), N.ptr(self.ep_lengths), self.envs_num, self.seed, self.env_id0,
+                    self.max_episode_steps, N.ptr(self.reset_cache), N.ptr(self.jam), N.ptr(self.ring[slot]),
+                    self.dim, N.ptr(self.fp_tables), N.ptr(self.since[slot - 1]), N.ptr(self.since[slot]),
+                    N.ptr(ep_acc) if ep_acc is not None else None, N.stream_ptr()), 'parlhip_atari_vec_step_obs')
+            self.t += 1
+            return
         N.check(
             L.parlhip_atari_vec_step(
                 N.ptr(self.states), N.ptr(self.rom_table), self.rom_size, self.game, N.ptr(actions.contiguous()),

@@ -117,3 +117,29 @@ def test_library_matches_the_tree(built_lib):
         sys.path.remove(csrc)
     assert _native.lib().parlhip_source_hash().decode() == srchash.source_hash(), \
         'libparl_hip.so is stale: run python __graft_entry__.py'
+
+
+@pytest.mark.parametrize('dim,ny,nx', [(42, 5, 5), (84, 3, 3)])
+def test_frame_post_tables_have_the_structure_the_observation_tail_assumes(built_lib, dim, ny, nx):
+    """parlhip_atari_vec_step_obs converts an env's frame pair band by band (5 source rows) with constant loop
+    bounds (csrc/frame_tail.hpp): every output row takes exactly `ny` y taps that stay inside its band, the
+    (row inside the band, weight) pairs repeat from band to band bit for bit, a column takes at most `nx` x taps.
+    Host function of the product library, no GPU."""
+    import numpy as np
+    from parl_amd import _native
+    lib = _native.lib()
+    nb = lib.parlhip_frame_post_tables_bytes(dim)
+    blob = np.zeros(nb, np.uint8)
+    assert lib.parlhip_frame_post_tables_init(blob.ctypes.data, dim) == 0
+    hdr = blob[:32].view(np.int32)
+    assert hdr[0] == dim
+    xstart = blob[hdr[3]:hdr[3] + 4 * (dim + 1)].view(np.int32)
+    ystart = blob[hdr[4]:hdr[4] + 4 * (dim + 1)].view(np.int32)
+    yt = blob[hdr[6]:hdr[6] + 8 * int(ystart[dim])].view(np.int32).reshape(-1, 2)   # (si, alpha bits)
+    assert (np.diff(ystart) == ny).all()
+    assert int(np.diff(xstart).max()) <= nx and int(np.diff(xstart).min()) >= 1
+    m = dim // 42
+    per_band = yt.reshape(42, m * ny, 2)
+    assert (per_band[:, :, 1] == per_band[0, :, 1]).all()                       # the same weights in every band
+    assert (per_band[:, :, 0] == per_band[0, :, 0] + 5 * np.arange(42)[:, None]).all()   # the same rows, shifted by the band
+    assert per_band[0, :, 0].min() == 0 and per_band[0, :, 0].max() == 4

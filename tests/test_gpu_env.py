@@ -22,11 +22,15 @@ def _rom(game):
         pytest.skip('cartridge %s.bin not present' % game)
 
 
-def _run_parity(dev, oracle, game, E, dim, steps, seed, max_episode_steps=400000, cache=True, check_ram=True):
+def _run_parity(dev, oracle, game, E, dim, steps, seed, max_episode_steps=400000, cache=True, check_ram=True,
+                fused=None):
     from parl_amd.env import DeviceVectorEnv
     rom = _rom(game)
     env = DeviceVectorEnv(GAMES[game], E, dim=dim, horizon=8, seed=seed, device=dev, rom_bytes=rom,
                           max_episode_steps=max_episode_steps, use_reset_cache=cache)
+    if fused is not None:  # the one-launch step (parlhip_atari_vec_step_obs) or the two-launch form, explicitly
+        assert env.fused_obs or not fused
+        env.fused_obs = bool(fused)
     orc = oracle.VecEnv(rom, game, E, dim, seed=seed, max_episode_steps=max_episode_steps)
     assert np.array_equal(env.reset().cpu().numpy(), orc.reset())
     sb = env.states.numel() // E
@@ -61,6 +65,49 @@ def test_env_matches_oracle(dev, oracle, game, dim):
     nd = _run_parity(dev, oracle, game, E=6, dim=dim, steps=160, seed=3)
     if game == 'breakout':
         assert nd > 0  # life losses / FIRE resets were exercised
+
+
+@pytest.mark.parametrize('game,dim', [('pong', 84), ('breakout', 42)])
+def test_env_matches_oracle_two_launch_form(dev, oracle, game, dim):
+    """the default step is ONE launch (the observation at the tail of the env kernel); the two-launch form
+    (parlhip_atari_vec_step, then parlhip_frame_post_step_u8) stays the path of other frame sizes / 4K cartridges"""
+    _run_parity(dev, oracle, game, E=6, dim=dim, steps=60, seed=4, fused=False)
+
+
+@pytest.mark.parametrize('game,dim,E', [('pong', 42, 9), ('pong', 84, 6), ('breakout', 42, 6), ('breakout', 84, 5)])
+def test_step_obs_one_launch_equals_two_launches(dev, game, dim, E):
+    """parlhip_atari_vec_step_obs against parlhip_atari_vec_step + parlhip_frame_post_step_u8 on twin envs: ring
+    slot, FrameStack counters, rewards, dones, raw frames, state blobs and the MonitorEnv sums, every step"""
+    from parl_amd.env import DeviceVectorEnv
+    rom = _rom(game)
+    mk = lambda: DeviceVectorEnv(GAMES[game], E, dim=dim, horizon=16, seed=11, device=dev, rom_bytes=rom,
+                                 max_episode_steps=700)
+    one, two = mk(), mk()
+    assert one.fused_obs
+    two.fused_obs = False
+    acc1 = torch.zeros(3, dtype=torch.float64, device=dev)
+    acc2 = torch.zeros(3, dtype=torch.float64, device=dev)
+    assert torch.equal(one.reset(), two.reset())
+    rng = np.random.default_rng(5)
+    resets = 0
+    for i in range(400):
+        if one.t >= one.horizon:
+            one.roll()
+            two.roll()
+        a = torch.from_numpy(rng.integers(0, one.act_dim, E)).to(dev)
+        one.step_async(a, ep_acc=acc1)
+        two.step_async(a, ep_acc=acc2)
+        slot = one.t + 3
+        assert torch.equal(one.ring[slot], two.ring[slot]), 'observation, step %d' % i
+        assert torch.equal(one.since[slot], two.since[slot]), 'since, step %d' % i
+        assert torch.equal(one.rewards, two.rewards) and torch.equal(one.dones, two.dones)
+        assert torch.equal(one.obs_flags, two.obs_flags)
+        assert torch.equal(one.raw_frames, two.raw_frames), 'raw frames, step %d' % i
+        assert torch.equal(one.states, two.states), 'state blobs, step %d' % i
+        resets += int((one.obs_flags & 2).ne(0).sum())
+    assert torch.equal(acc1, acc2) and float(acc1[0]) > 0
+    assert resets > 0
+    one.check_faults()
 
 
 def test_env_matches_oracle_timelimit_no_cache(dev, oracle):
