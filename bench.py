@@ -646,6 +646,7 @@ def _main():
     env_timer, fp_timer = KernelTimer(), KernelTimer()
     for e in envs:
         e.step_async = env_timer.wrap(e.step_async)
+        e.step_policy_async = env_timer.wrap(e.step_policy_async)
         e.step_elastic_async = env_timer.wrap(e.step_elastic_async)
         e._frame_post = fp_timer.wrap(e._frame_post)
         e._frame_post_elastic = fp_timer.wrap(e._frame_post_elastic)

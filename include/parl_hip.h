@@ -321,6 +321,23 @@ int parlhip_atari_vec_step_obs(void* states, const uint32_t* rom_table_dev, uint
                                const void* reset_cache_dev, int32_t* jam_flag_dev, uint8_t* obs_out, int dim,
                                const void* tables_dev, const uint8_t* since_prev, uint8_t* since_next,
                                double* ep_acc3, parlhip_stream_t stream);
+/* The actors' whole per-step tail of examples/IMPALA/actor.py:58-76 in ONE launch: agent.sample's policy head +
+ * np.random.choice draw (what parlhip_policy_head_sample_at_f32 does: same instructions, same logits, same
+ * actions), vector_env.step, and the observation (parlhip_atari_vec_step_obs).  hidden f32 [E,256] = the trunk
+ * output of the actors' model for the observation the envs hold (16-byte aligned), w_policy f32 [A,256], b_policy
+ * [A]; logits_out f32 [E,A] and actions_out int64 [E] are this step's rows of the rollout slabs; the draw of env e
+ * is the Philox uniform of (sample_seed; offset (+ *offset_base if not NULL), row0 + e).  A must be the game's
+ * action count (<= 6), hidden_units 256.  PARLHIP_ENOSUP as parlhip_atari_vec_step_obs.                  */
+int parlhip_atari_vec_step_policy_obs(void* states, const uint32_t* rom_table_dev, uint32_t rom_size, int game,
+                                      uint8_t* frames, float* rewards, uint8_t* dones, uint8_t* obs_flags,
+                                      float* ep_returns, int32_t* ep_lengths, int E, uint64_t seed,
+                                      uint64_t env_id0, int64_t max_episode_steps, const void* reset_cache_dev,
+                                      int32_t* jam_flag_dev, uint8_t* obs_out, int dim, const void* tables_dev,
+                                      const uint8_t* since_prev, uint8_t* since_next, double* ep_acc3,
+                                      const float* hidden, const float* w_policy, const float* b_policy,
+                                      float* logits_out, int64_t* actions_out, int hidden_units, int A,
+                                      uint64_t sample_seed, const uint64_t* offset_base, uint64_t offset,
+                                      uint64_t row0, parlhip_stream_t stream);
 /* Elastic VectorEnv.step (examples/IMPALA/actor.py:58-76 collects sample_batch_steps steps of every env;
  * the reference's actors are independent processes, so one actor's slow step never holds up another's).
  * A launch emulates at most `frame_budget` (>= 4) frames per env: an env whose step needs more — the 12

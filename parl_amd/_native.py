@@ -79,6 +79,9 @@ SIGNATURES = {
     'parlhip_atari_vec_step_obs':
     (_i, [_p, _p, ctypes.c_uint32, _i, _p, _p, _p, _p, _p, _p, _p, _i, _u64, _u64, _i64, _p, _p, _p, _i, _p, _p, _p, _p,
           _p]),
+    'parlhip_atari_vec_step_policy_obs':
+    (_i, [_p, _p, ctypes.c_uint32, _i, _p, _p, _p, _p, _p, _p, _i, _u64, _u64, _i64, _p, _p, _p, _i, _p, _p, _p, _p,
+          _p, _p, _p, _p, _p, _i, _i, _u64, _p, _u64, _u64, _p]),
     'parlhip_atari_vec_step_elastic':
     (_i, [_p, _p, ctypes.c_uint32, _i, _p, _p, _p, _p, _p, _p, _p, _i, _u64, _u64, _i64, _p, _p, _i, _i, _i, _i, _i] +
      [_p] * 7 + [_i] + [_p] * 4),

@@ -18,6 +18,7 @@
 #include "atari_core.hpp"
 #include "frame_tail.hpp"
 #include "philox.hpp"
+#include "policy_head.hpp"
 
 namespace parlhip {
 namespace atari {
@@ -46,9 +47,43 @@ struct StepFuse {
   const uint8_t* since_prev;  // [E] FrameStack counters of the previous slot, or null (= 0)
   uint8_t* since_next;        // [E]
   double* ep_acc;             // [3] MonitorEnv sums (parlhip_episode_stats_accum_f64), or null
-  int dim, pad;
+  int dim, A;
+  // head: the actors' policy head + draw (policy_head.hpp).  hidden == nullptr: the actions are read from `actions`
+  const float* hidden;        // [E, 256] trunk output of the actors' model for the observation the envs hold
+  const float* w_pi;          // [A, 256]
+  const float* b_pi;          // [A]
+  float* logits_out;          // [E, A]: behaviour logits row of this step's slab
+  long long* actions_out;     // [E]
+  const unsigned long long* offset_base;  // or null: added to `offset` on the device (hipGraph replays)
+  unsigned long long sample_seed, offset, row0;   // Philox key / counter of the draw: (offset, row0 + e)
 };
 DEVI const StepFuse* fuse_args() { return (const StepFuse*)__builtin_amdgcn_kernarg_segment_ptr(); }
+
+// The actors' policy head + draw at the HEAD of an env's CPU wave (parlhip_atari_vec_step_policy_obs): what
+// policy_head_sample_kernel does in a launch of its own between the actors' last GEMM and the emulator — 8-13 us
+// and a launch gap per env step for 1,800 multiply-adds per env — with the same instructions (policy_head.hpp).
+// Every lane ends with the action; lane 0 stores the logits row and the action into the rollout slabs.
+__device__ __attribute__((noinline)) int policy_head_main(const StepFuse* fz_v, int e_v) {
+  const unsigned long long x = (unsigned long long)(uintptr_t)fz_v;
+  const StepFuse* fz = (const StepFuse*)(uintptr_t)(((unsigned long long)(uint32_t)rfl((int)(x >> 32)) << 32) |
+                                                     (uint32_t)rfl((int)(uint32_t)x));
+  const int e = rfl(e_v), lane = (int)(threadIdx.x & 63);
+  const int A = fz->A;
+  unsigned long long offset = fz->offset;
+  const unsigned long long* ob = fz->offset_base;
+  if (ob) offset += *ob;
+  float row[6];
+  policy_head_row<6>(fz->hidden + (size_t)e * 256, fz->w_pi, fz->b_pi, A, lane, row);
+  const double u = philox_uniform53(fz->sample_seed, offset, fz->row0 + (unsigned long long)e);
+  const long long a = policy_draw<6>(row, A, u);
+  if (lane == 0) {
+    float* lo = fz->logits_out + (size_t)e * A;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) if (k < A) lo[k] = row[k];
+    fz->actions_out[e] = a;
+  }
+  return (int)a;
+}
 
 // Elastic stepping (parlhip_atari_vec_step_elastic): a launch emulates at most `budget` frames per
 // env.  An env whose step needs more (the 12 frames of a life-loss reset: EpisodicLifeEnv's NOOP step +
@@ -280,7 +315,8 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
       ale_j = rfl(sc[S_SUSP_ALE_J]); noops_left = rfl(sc[S_SUSP_NOOPS]);
       did_reset = 1;  // only reset sequences are ever cut
     } else {
-      int a = rfl((int)actions[e]);
+      const StepFuse* fzh = fuse_args();
+      int a = fzh->hidden ? rfl(policy_head_main(fzh, e)) : rfl((int)actions[e]);
       const int na = game == GAME_BREAKOUT ? 4 : 6;
       if (a < 0 || a >= na) a = 0;
       phase = PH_SKIP; ctx = CTX_MAIN; skip_act = action_code(a);
@@ -717,9 +753,42 @@ PARLHIP_EXPORT int parlhip_atari_vec_step_obs(void* states, const uint32_t* rom_
       !obs_out || !tables_dev || !since_next)
     return PARLHIP_EINVAL;
   if (reinterpret_cast<uintptr_t>(frames) & 15) return PARLHIP_EINVAL;   // the tail reads the frame pair as uint4s
-  const StepFuse fz{obs_out, (const uint8_t*)tables_dev, since_prev, since_next, ep_acc3, dim, 0};
+  StepFuse fz{};
+  fz.obs_out = obs_out; fz.tables = (const uint8_t*)tables_dev; fz.since_prev = since_prev; fz.since_next = since_next;
+  fz.ep_acc = ep_acc3; fz.dim = dim;
   return launch_env(MODE_STEP, states, rom_table_dev, rom_size, game, actions, frames, rewards, dones,
                     obs_flags, ep_returns, ep_lengths, E, seed, env_id0, max_episode_steps,
+                    (void*)reset_cache_dev, jam_flag_dev, (hipStream_t)stream, 0, nullptr, &fz);
+}
+
+PARLHIP_EXPORT int parlhip_atari_vec_step_policy_obs(
+    void* states, const uint32_t* rom_table_dev, uint32_t rom_size, int game, uint8_t* frames, float* rewards,
+    uint8_t* dones, uint8_t* obs_flags, float* ep_returns, int32_t* ep_lengths, int E, uint64_t seed,
+    uint64_t env_id0, int64_t max_episode_steps, const void* reset_cache_dev, int32_t* jam_flag_dev,
+    uint8_t* obs_out, int dim, const void* tables_dev, const uint8_t* since_prev, uint8_t* since_next,
+    double* ep_acc3, const float* hidden, const float* w_policy, const float* b_policy, float* logits_out,
+    int64_t* actions_out, int hidden_units, int A, uint64_t sample_seed, const uint64_t* offset_base,
+    uint64_t offset, uint64_t row0, parlhip_stream_t stream) {
+  int rc = check_env_args(states, rom_table_dev, rom_size, game, E);
+  if (rc) return rc;
+  if (!obs_tail_supports(dim, (int)rom_size)) return PARLHIP_ENOSUP;
+  if (hidden_units != 256 || A < 1 || A > 6) return PARLHIP_ENOSUP;
+  if (A != parlhip_atari_num_actions(game)) return PARLHIP_EINVAL;
+  if (E == 0) return PARLHIP_OK;
+  if (!frames || !rewards || !dones || !obs_flags || !ep_returns || !ep_lengths || !jam_flag_dev || !obs_out ||
+      !tables_dev || !since_next || !hidden || !w_policy || !b_policy || !logits_out || !actions_out)
+    return PARLHIP_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(frames) | reinterpret_cast<uintptr_t>(hidden) |
+       reinterpret_cast<uintptr_t>(w_policy)) & 15)
+    return PARLHIP_EINVAL;
+  StepFuse fz{};
+  fz.obs_out = obs_out; fz.tables = (const uint8_t*)tables_dev; fz.since_prev = since_prev; fz.since_next = since_next;
+  fz.ep_acc = ep_acc3; fz.dim = dim; fz.A = A;
+  fz.hidden = hidden; fz.w_pi = w_policy; fz.b_pi = b_policy; fz.logits_out = logits_out;
+  fz.actions_out = (long long*)actions_out; fz.offset_base = (const unsigned long long*)offset_base;
+  fz.sample_seed = sample_seed; fz.offset = offset; fz.row0 = row0;
+  return launch_env(MODE_STEP, states, rom_table_dev, rom_size, game, (const int64_t*)actions_out, frames, rewards,
+                    dones, obs_flags, ep_returns, ep_lengths, E, seed, env_id0, max_episode_steps,
                     (void*)reset_cache_dev, jam_flag_dev, (hipStream_t)stream, 0, nullptr, &fz);
 }
 

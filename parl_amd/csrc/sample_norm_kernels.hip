@@ -6,6 +6,7 @@
 //   parl/algorithms/torch/ppo.py:115-117 / paddle/ppo.py:124-127   (adv-mean)/(std+1e-8)
 #include "common.hpp"
 #include "philox.hpp"
+#include "policy_head.hpp"
 #include <math.h>
 
 namespace parlhip {
@@ -70,12 +71,6 @@ __global__ __launch_bounds__(256) void policy_sample_kernel(
 // h[row][4l..4l+3], a logit is four FMAs per lane and a wave reduction, lane 0 adds the bias, writes the
 // [A] logits row into the rollout slab and draws the action exactly as policy_sample_kernel does
 // (float32 softmax, float64 inverse CDF, Philox uniform of (offset, row0 + row)).  256 hidden units.
-__device__ __forceinline__ float wave_sum_f32(float x) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-  return x;
-}
-
 template <int A_MAX>
 __global__ __launch_bounds__(256) void policy_head_sample_kernel(
     const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
@@ -85,41 +80,13 @@ __global__ __launch_bounds__(256) void policy_head_sample_kernel(
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;  // whole wave
   if (offset_base) offset += *offset_base;  // the rollout's first step lives in device memory (hipGraph replays)
-  const float4 hv = ((const float4*)(h + b * 256))[lane];
   float row[A_MAX];
-#pragma unroll
-  for (int k = 0; k < A_MAX; ++k) {
-    row[k] = 0.f;
-    if (k < A) {
-      const float4 wv = ((const float4*)(w + (size_t)k * 256))[lane];
-      float p = hv.x * wv.x;
-      p = __builtin_fmaf(hv.y, wv.y, p);
-      p = __builtin_fmaf(hv.z, wv.z, p);
-      p = __builtin_fmaf(hv.w, wv.w, p);
-      row[k] = wave_sum_f32(p) + bias[k];
-    }
-  }
+  policy_head_row<A_MAX>(h + b * 256, w, bias, A, lane, row);
   if (lane != 0) return;
   const double u = philox_uniform53(seed, offset, row0 + (uint64_t)b);
-  float m = row[0];
 #pragma unroll
-  for (int k = 1; k < A_MAX; ++k) if (k < A) m = fmaxf(m, row[k]);
-  float s = 0.f;
-#pragma unroll
-  for (int k = 0; k < A_MAX; ++k) if (k < A) s += expf(row[k] - m);
-  double last = 0.0;
-#pragma unroll
-  for (int k = 0; k < A_MAX; ++k) if (k < A) last += (double)(expf(row[k] - m) / s);
-  double c = 0.0;
-  int64_t a = A;
-#pragma unroll
-  for (int k = 0; k < A_MAX; ++k) {
-    if (k < A) {
-      logits_out[b * A + k] = row[k];
-      c += (double)(expf(row[k] - m) / s);
-      if (a == A && c / last > u) a = k;
-    }
-  }
+  for (int k = 0; k < A_MAX; ++k) if (k < A) logits_out[b * A + k] = row[k];
+  const int64_t a = policy_draw<A_MAX>(row, A, u);
   actions[b] = a;
 }
 

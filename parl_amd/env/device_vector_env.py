@@ -237,6 +237,50 @@ class DeviceVectorEnv(object):
         self.t += 1
         self._frame_post(self.t + 3, ep_acc)
 
+    def can_step_policy(self, hidden_units, act_dim):
+        """whether step_policy_async exists for this env and a policy head of that shape"""
+        return bool(self.fused_obs and self.link is None and hidden_units == 256 and act_dim == self.act_dim and
+                    act_dim <= 6)
+
+    def step_policy_async(self, hidden, w_policy, b_policy, logits_out, actions_out, sample_seed, offset, row0,
+                          offset_base=None, rewards_out=None, dones_out=None, ep_acc=None):
+        """The actors' step from the trunk output on: policy_fc + the draw (what ops.policy_head_sample_into does —
+        same logits, same actions), VectorEnv.step and the observation, ONE launch
+        (parlhip_atari_vec_step_policy_obs).  hidden f32 [E, 256]; logits_out [E, A] / actions_out int64 [E]: this
+        step's rows of the rollout slabs; the draw of env e is the Philox uniform of (sample_seed; offset
+        (+ offset_base[0] on the device), row0 + e)."""
+        if self.t >= self.horizon:
+            raise N.ParlHipError('rollout ring full: call roll() every `horizon` steps')
+        E, A = self.envs_num, self.act_dim
+        if not self.can_step_policy(hidden.shape[-1], w_policy.shape[0]):
+            raise N.ParlHipError('step_policy_async: not available for this env / head (can_step_policy)')
+        if (hidden.dtype != torch.float32 or tuple(hidden.shape) != (E, 256) or logits_out.dtype != torch.float32 or
+                tuple(logits_out.shape) != (E, A) or actions_out.dtype != torch.int64 or actions_out.numel() != E):
+            raise N.ParlHipError('step_policy_async: hidden f32 [E,256], logits_out f32 [E,A], actions_out int64 [E]')
+        if ep_acc is not None and (ep_acc.dtype != torch.float64 or ep_acc.numel() != 3 or
+                                   ep_acc.device.type != self.device.type):
+            raise N.ParlHipError('ep_acc must be float64 [3] on the env device')
+        if offset_base is not None and (offset_base.dtype != torch.int64 or offset_base.numel() != 1 or
+                                        not offset_base.is_cuda):
+            raise N.ParlHipError('offset_base must be an int64 [1] device tensor')
+        wp, bp = w_policy.detach(), b_policy.detach()
+        if wp.dtype != torch.float32 or bp.dtype != torch.float32:
+            raise N.ParlHipError('step_policy_async: float32 head')
+        slot = self.t + 4
+        m64 = 2**64 - 1
+        N.check(
+            N.lib().parlhip_atari_vec_step_policy_obs(
+                N.ptr(self.states), N.ptr(self.rom_table), self.rom_size, self.game, N.ptr(self.raw_frames),
+                N.ptr(self.rewards if rewards_out is None else rewards_out),
+                N.ptr(self.dones if dones_out is None else dones_out), N.ptr(self.obs_flags), N.ptr(self.ep_returns),
+                N.ptr(self.ep_lengths), E, self.seed, self.env_id0, self.max_episode_steps, N.ptr(self.reset_cache),
+                N.ptr(self.jam), N.ptr(self.ring[slot]), self.dim, N.ptr(self.fp_tables), N.ptr(self.since[slot - 1]),
+                N.ptr(self.since[slot]), N.ptr(ep_acc) if ep_acc is not None else None, N.ptr(hidden.contiguous()),
+                N.ptr(wp.contiguous()), N.ptr(bp.contiguous()), N.ptr(logits_out), N.ptr(actions_out), 256, A,
+                int(sample_seed) & m64, N.ptr(offset_base) if offset_base is not None else None, int(offset) & m64,
+                int(row0) & m64, N.stream_ptr()), 'parlhip_atari_vec_step_policy_obs')
+        self.t += 1
+
     # ---------------------------------------------------------------- elastic launches (circular ring)
     def elastic_begin(self):
         """switch the ring to the elastic layout (after reset(): every env's observation is in slot 3)"""

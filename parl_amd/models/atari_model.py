@@ -140,6 +140,12 @@ class AtariModel42(Model):
             torch.addmm(self.policy_fc.bias, h, self.policy_fc.weight.t(), out=logits_out)
             ops.policy_sample_into(logits_out, actions_out, seed, offset, row0)
 
+    @torch.no_grad()
+    def policy_hidden(self, obs):
+        """the trunk output [E, 256] for a consumer that runs policy_fc + the draw itself: the device env's step
+        (DeviceVectorEnv.step_policy_async — head, draw, emulator and observation in one launch)"""
+        return self._trunk(obs)
+
     def value(self, obs):
         return self.value_fc(self._trunk(obs)).squeeze(1)
 

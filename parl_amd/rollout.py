@@ -147,6 +147,17 @@ class DeviceRollout(object):
         # a model whose trunk reads the ring in place gets a reference (one launch less per env step), any other the stack
         obs = env.current_obs_ref(self._obs_step) if getattr(model, 'reads_ring', False) else env.current_obs(self._obs_step)
         logits = self.behaviour_logits[t]
+        if self._head_in_env_step(model):
+            # policy head + draw at the head of the env launch, the observation at its tail: the step is conv12 ->
+            # trunk GEMM -> ONE env launch (DeviceVectorEnv.step_policy_async); same uniforms as below
+            h = model.policy_hidden(obs)
+            based = self._step_base.is_cuda
+            env.step_policy_async(h, model.policy_fc.weight, model.policy_fc.bias, logits, self.actions[t], self.seed,
+                                  self.step_count - self._base_count if based else self.step_count, env.env_id0,
+                                  self._step_base if based else None, self.rewards[t], self.dones[t],
+                                  ep_acc=self.ep_stats)
+            self.step_count += 1
+            return
         if getattr(model, 'supports_offset_base', False) and self._step_base.is_cuda:
             # the same uniforms as offset = step_count: step_count == *base + (steps since collect_begin)
             _policy_and_draw(model, obs, logits, self.actions[t], self.seed, self.step_count - self._base_count,
@@ -155,6 +166,14 @@ class DeviceRollout(object):
             _policy_and_draw(model, obs, logits, self.actions[t], self.seed, self.step_count, env.env_id0)
         env.step_async(self.actions[t], self.rewards[t], self.dones[t], ep_acc=self.ep_stats)
         self.step_count += 1
+
+    def _head_in_env_step(self, model):
+        """PARL_AMD_FUSED_HEAD=0: head + draw as their own launch (ops.policy_head_sample_into) — A/B and tests"""
+        fc = getattr(model, 'policy_fc', None)
+        return bool(hasattr(model, 'policy_hidden') and fc is not None and fc.bias is not None and
+                    fc.weight.dtype == torch.float32 and hasattr(self.env, 'can_step_policy') and
+                    self.env.can_step_policy(fc.in_features, fc.out_features) and
+                    os.environ.get('PARL_AMD_FUSED_HEAD', '1') != '0')
 
     def can_graph(self, model):
         return bool(getattr(model, 'supports_offset_base', False) and self._step_base.is_cuda and self.env.link is None

@@ -486,3 +486,45 @@ def test_full_size_vector_84_matches_oracle_on_a_subset_of_envs(dev, oracle, gam
     res = _long_parity(dev, oracle, game, E=E, dim=84, steps=steps, seed=17, ids=ids)
     if game == 'breakout':
         assert sum(nd for nd, _ in res) >= 3
+
+
+@pytest.mark.parametrize('game', ['pong', 'breakout'])
+def test_rollout_with_head_in_the_env_launch_equals_separate_launches(dev, game, monkeypatch):
+    """DeviceRollout's step as conv12 -> trunk GEMM -> ONE env launch (policy head + draw at its head, observation
+    at its tail: parlhip_atari_vec_step_policy_obs) against the same rollout with the head + draw and frame_post
+    as launches of their own: logits, actions, rewards, dones and observations identical, also across rollouts
+    and as hipGraph segments"""
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel42
+    from parl_amd.rollout import DeviceRollout
+    rom = _rom(game)
+    E, T = 12, 10
+    torch.manual_seed(3)
+    model = None
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setenv('PARL_AMD_FUSED_HEAD', '1' if fused else '0')
+        env = DeviceVectorEnv(GAMES[game], E, dim=42, horizon=T, seed=21, device=dev, rom_bytes=rom,
+                              max_episode_steps=900)
+        env.fused_obs = fused
+        if model is None:
+            model = AtariModel42(env.act_dim).to(dev)
+        ro = DeviceRollout(env, T, seed=77)
+        assert ro._head_in_env_step(model) == fused
+        got = []
+        side = torch.cuda.Stream(device=dev)   # (a hipGraph is captured on a non-default stream)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for it in range(4):
+                ro.collect_begin()
+                ro.collect_segment(model, 0, T // 2, graph=True)     # eager, capture, replay, replay
+                ro.collect_segment(model, T // 2, T, graph=False)
+                b = ro.collect_end()
+                got.append({k: (v.materialize() if hasattr(v, 'materialize') else v).clone() for k, v in b.items()})
+            got.append({'ep': ro.ep_stats.clone()})
+        side.synchronize()
+        env.check_faults()
+        outs.append(got)
+    for a, b in zip(*outs):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
