@@ -420,6 +420,20 @@ int parlhip_atari42_conv12_u8_f32(const uint8_t* obs, const float* w1, const flo
 int parlhip_atari42_conv12_ring_u8_f32(const uint8_t* ring, const uint8_t* since, int num_slots, int E,
                                        int slot, const float* w1, const float* b1, const float* w2,
                                        const float* b2, float* out, parlhip_stream_t stream);
+/* The two weight matrices in the kernel's operand order (what a wavefront keeps in registers: 144 values per
+ * lane), so that a workgroup fetches them with 36 coalesced 1 KB loads instead of 144 loads that touch 16 cache
+ * lines each — the start-up of a workgroup, half of the actors' 1024-observation launch.  packed_out f32
+ * [parlhip_atari42_conv12_weights_bytes() / 4], 16-byte aligned; rebuild whenever w1 / w2 change (the actors:
+ * once per weight refresh, atari_model.py:59-71's parameters).  The _packed_ entries below are the two forward
+ * entries above with `packed` in place of (w1, w2): bit-identical outputs.                                   */
+size_t parlhip_atari42_conv12_weights_bytes(void);
+int parlhip_atari42_conv12_weights_f32(const float* w1, const float* w2, float* packed_out,
+                                       parlhip_stream_t stream);
+int parlhip_atari42_conv12_packed_u8_f32(const uint8_t* obs, const float* packed, const float* b1,
+                                         const float* b2, float* out, int n_obs, parlhip_stream_t stream);
+int parlhip_atari42_conv12_ring_packed_u8_f32(const uint8_t* ring, const uint8_t* since, int num_slots, int E,
+                                              int slot, const float* packed, const float* b1, const float* b2,
+                                              float* out, parlhip_stream_t stream);
 
 /* The LEARNER's gradient of the same two layers (IMPALA.learn, parl/algorithms/paddle/impala/
  * impala.py:148-149,205-215 backpropagates through AtariModel.policy / .value; the reference leaves

@@ -90,6 +90,10 @@ SIGNATURES = {
     'parlhip_stack_gather_u8': (_i, [_p, _p, _i, _i, _p, _p, _i64, _p, _p]),
     'parlhip_atari42_conv12_u8_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _p]),
     'parlhip_atari42_conv12_ring_u8_f32': (_i, [_p, _p, _i, _i, _i] + [_p] * 6),
+    'parlhip_atari42_conv12_weights_bytes': (_sz, []),
+    'parlhip_atari42_conv12_weights_f32': (_i, [_p, _p, _p, _p]),
+    'parlhip_atari42_conv12_packed_u8_f32': (_i, [_p, _p, _p, _p, _p, _i, _p]),
+    'parlhip_atari42_conv12_ring_packed_u8_f32': (_i, [_p, _p, _i, _i, _i] + [_p] * 5),
     'parlhip_atari84_conv1_u8_f32': (_i, [_p, _p, _p, _p, _i, _p]),
     'parlhip_atari84_conv1_ring_u8_f32': (_i, [_p, _p, _i, _i, _i] + [_p] * 4),
     'parlhip_atari84_conv23_f32': (_i, [_p] * 7 + [_i, _p]),

@@ -20,6 +20,7 @@ class Model(nn.Module):
         with torch.no_grad():
             for name, var in self.named_parameters():
                 target_vars[name].data.copy_(decay * target_vars[name].data + (1 - decay) * var.data)
+        _layouts_follow(target_model)   # (.data writes do not move the autograd version counters)
 
     def get_weights(self):
         """{name: host numpy copy} (core/torch/model.py:115-123)"""
@@ -30,3 +31,12 @@ class Model(nn.Module):
     def set_weights(self, weights):
         """load host numpy weights (core/torch/model.py:125-134)"""
         self.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights.items()})
+        _layouts_follow(self)
+
+
+def _layouts_follow(model):
+    """a model that keeps derived device copies of its weights (AtariModel42's MFMA operand-order buffer) rebuilds
+    them after a bulk write"""
+    f = getattr(model, 'refresh_actor_layout', None)
+    if f is not None:
+        f()

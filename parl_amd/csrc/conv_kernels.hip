@@ -105,10 +105,37 @@ struct RingObs {
   int num_slots, E, slot;
 };
 
-template <bool RING>
-__global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
+// Operand-order copy of the two weight matrices (parlhip_atari42_conv12_weights_f32): register r of lane
+// (q = lane >> 4, col = lane & 15) is bw1[r] for r < 16 and bw2[(r - 16) >> 1][(r - 16) & 1] after it; four registers
+// per float4, [36][64] float4s — a wave reads its 144 operands with 36 fully coalesced 1 KB loads.  From the
+// nn.Conv2d layout the same operands are 144 dword loads that touch 16 cache lines each (sixteen weight rows 1 KB
+// apart): measured as THE start-up cost of a workgroup — 29 of the 67 us of the actors' 1024-observation launch
+// (tools/conv12_scaling.py with -DPARLHIP_CONV12_ABL=1: 20.0 / 34.6 us for nothing but the weight fetch at 256 /
+// 512 workgroups), the vector L1's tag rate, not bytes.
+constexpr int kPackedRegs = 16 + 128, kPackedFloats = kPackedRegs * 64;   // 9,216 floats = 36,864 B
+__global__ __launch_bounds__(256) void conv12_weights_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                                  float* __restrict__ packed) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kPackedFloats) return;
+  const int r = i >> 6, lane = i & 63, q = lane >> 4, col = lane & 15;
+  float v;
+  if (r < 16) {
+    v = w1[col * kK1 + r * 4 + q];
+  } else {
+    const int rr = r - 16, ks = rr >> 1, t = rr & 1;
+    v = w2[(16 * t + col) * kK2 + ks * 4 + q];
+  }
+  packed[(((r >> 2) * 64 + lane) << 2) + (r & 3)] = v;
+}
+
+// PACKED: `packed` holds the operand-order weights (w1 / w2 unused); otherwise w1 / w2 in the nn.Conv2d layout.  Two
+// instantiations, not a run-time branch: with both fetch sequences in one function the allocator went from 240 to 280
+// registers (24 of them AGPRs) — one wave per SIMD instead of two, 67 -> 78 us per 1024 observations.
+template <bool RING, bool PACKED>
+__global__ __launch_bounds__(256, 2) void conv12_u8_mfma_kernel(
     const uint8_t* __restrict__ obs, RingObs ro, const float* __restrict__ w1, const float* __restrict__ b1,
-    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ out, int n_obs) {
+    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ out, int n_obs,
+    const float* __restrict__ packed) {
   extern __shared__ float lds[];
   float* in_pad = lds;                  // [4][44][44]
   float* c1_pad = in_pad + kLdsIn;      // [16][25][25]
@@ -116,14 +143,34 @@ __global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
   const int q = lane >> 4, col = lane & 15;
   // B[k][n] = w[n][k]: lane (q, col) holds k = 4*ks + q, n = col (+16 for the second N-tile)
   float bw1[16], bw2[64][2];
+  if constexpr (PACKED) {
+    const float4* pk = reinterpret_cast<const float4*>(packed) + lane;
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) bw1[ks] = w1[col * kK1 + ks * 4 + q];
+    for (int g = 0; g < 4; ++g) {
+      const float4 v = pk[g * 64];
+      bw1[4 * g] = v.x; bw1[4 * g + 1] = v.y; bw1[4 * g + 2] = v.z; bw1[4 * g + 3] = v.w;
+    }
 #pragma unroll
-  for (int ks = 0; ks < 64; ++ks) {
-    bw2[ks][0] = w2[col * kK2 + ks * 4 + q];
-    bw2[ks][1] = w2[(16 + col) * kK2 + ks * 4 + q];
+    for (int g = 0; g < 32; ++g) {
+      const float4 v = pk[(4 + g) * 64];
+      bw2[2 * g][0] = v.x; bw2[2 * g][1] = v.y; bw2[2 * g + 1][0] = v.z; bw2[2 * g + 1][1] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) bw1[ks] = w1[col * kK1 + ks * 4 + q];
+#pragma unroll
+    for (int ks = 0; ks < 64; ++ks) {
+      bw2[ks][0] = w2[col * kK2 + ks * 4 + q];
+      bw2[ks][1] = w2[(16 + col) * kK2 + ks * 4 + q];
+    }
   }
   const float bias1 = b1[col], bias20 = b2[col], bias21 = b2[16 + col];
+#ifdef PARLHIP_CONV12_ABL   // diagnostic builds (tools/build_obj_variant.sh c12aN conv_kernels.hip -DPARLHIP_CONV12_ABL=N): where a workgroup's start goes
+#define C12_ABL_EXIT(N) if (PARLHIP_CONV12_ABL == N) { float z = bias1 + bias20 + bias21; for (int ks = 0; ks < 16; ++ks) z += bw1[ks]; for (int ks = 0; ks < 64; ++ks) z += bw2[ks][0] + bw2[ks][1]; if (z == 123.456f) out[tid] = z + lds[tid]; return; }
+#else
+#define C12_ABL_EXIT(N)
+#endif
+  C12_ABL_EXIT(1)
   // conv1: position m = 16 wave + col (gathers) and 16 wave + 4 q (first D row) of this wave's first tile
   const int oy1 = (16 * wave + col) / kO1, ox1 = (16 * wave + col) - oy1 * kO1;
   const int ey1 = (16 * wave + 4 * q) / kO1, ex1 = (16 * wave + 4 * q) - ey1 * kO1;
@@ -152,6 +199,7 @@ __global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
   if (words && (int)blockIdx.x < n_obs) fetch(blockIdx.x);
   for (int n = blockIdx.x; n < n_obs; n += gridDim.x) {
     __syncthreads();  // borders zeroed / the previous observation's conv2 gathers are done
+    C12_ABL_EXIT(2)
     // ---- obs u8 -> padded float input (x / 255, the division as in the reference) ----
     const uint8_t* src = obs + (size_t)n * 4 * kD * kD;
     if (words) {  // wave-uniform
@@ -171,6 +219,7 @@ __global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
       }
     }
     __syncthreads();
+    C12_ABL_EXIT(3)
     // ---- conv1: 28 M-tiles of 16 positions, 7 per wave ----
     // Positions advance incrementally (a tile is 64 positions further = 3 rows + 1 column of 21; rounds 1-3 divided
     // by 21 five times per tile), and a tile's 16 operands are all read before its MFMAs (sched_group_barrier:
@@ -206,6 +255,7 @@ __global__ __launch_bounds__(256) void conv12_u8_mfma_kernel(
       }
     }
     __syncthreads();
+    C12_ABL_EXIT(4)
     // ---- conv2: 8 M-tiles, 2 per wave, both N-tiles per A gather; D goes straight to HBM ----
     float* dst = out + (size_t)n * kC2 * kM2;
     for (int mt = wave; mt < 8; mt += 4) {
@@ -1315,23 +1365,39 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restric
 
 using namespace parlhip;
 
+static int launch_conv12(const uint8_t* obs, const RingObs& ro, const float* w1, const float* b1, const float* w2,
+                         const float* b2, float* out, int n_obs, const float* packed, hipStream_t stream) {
+  const size_t lds_bytes = kLdsFloats * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* fns[4] = {(const void*)conv12_u8_mfma_kernel<false, false>, (const void*)conv12_u8_mfma_kernel<false, true>,
+                          (const void*)conv12_u8_mfma_kernel<true, false>, (const void*)conv12_u8_mfma_kernel<true, true>};
+    for (const void* f : fns) {
+      int rc = check(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      if (rc) return rc;
+    }
+    attr_set = true;
+  }
+  const int grid = n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU;  // 71 KB of LDS: two workgroups per CU
+#define PARLHIP_C12(R, P, O, RO) conv12_u8_mfma_kernel<R, P><<<grid, 256, lds_bytes, stream>>>(O, RO, w1, b1, w2, b2, out, n_obs, packed)
+  if (ro.ring) {
+    if (packed) PARLHIP_C12(true, true, nullptr, ro);
+    else PARLHIP_C12(true, false, nullptr, ro);
+  } else {
+    if (packed) PARLHIP_C12(false, true, obs, RingObs{});
+    else PARLHIP_C12(false, false, obs, RingObs{});
+  }
+#undef PARLHIP_C12
+  return check_launch();
+}
+
 PARLHIP_EXPORT int parlhip_atari42_conv12_u8_f32(const uint8_t* obs, const float* w1, const float* b1,
                                                  const float* w2, const float* b2, float* out, int n_obs,
                                                  parlhip_stream_t stream) {
   if (n_obs < 0) return PARLHIP_EINVAL;
   if (n_obs == 0) return PARLHIP_OK;
   if (!obs || !w1 || !b1 || !w2 || !b2 || !out) return PARLHIP_EINVAL;
-  static bool attr_set = false;
-  const size_t lds_bytes = kLdsFloats * sizeof(float);
-  if (!attr_set) {
-    int rc = check(hipFuncSetAttribute((const void*)conv12_u8_mfma_kernel<false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    if (rc) return rc;
-    attr_set = true;
-  }
-  const int grid = n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU;  // 71 KB of LDS: two workgroups per CU
-  conv12_u8_mfma_kernel<false><<<grid, 256, lds_bytes, (hipStream_t)stream>>>(obs, RingObs{}, w1, b1, w2, b2, out, n_obs);
-  return check_launch();
+  return launch_conv12(obs, RingObs{}, w1, b1, w2, b2, out, n_obs, nullptr, (hipStream_t)stream);
 }
 
 PARLHIP_EXPORT int parlhip_atari42_conv12_ring_u8_f32(const uint8_t* ring, const uint8_t* since, int num_slots, int E,
@@ -1341,18 +1407,39 @@ PARLHIP_EXPORT int parlhip_atari42_conv12_ring_u8_f32(const uint8_t* ring, const
   if (E == 0) return PARLHIP_OK;
   if (!ring || !since || !w1 || !b1 || !w2 || !b2 || !out) return PARLHIP_EINVAL;
   if ((uintptr_t)ring & 3u) return PARLHIP_EINVAL;
-  static bool attr_set = false;
-  const size_t lds_bytes = kLdsFloats * sizeof(float);
-  if (!attr_set) {
-    int rc = check(hipFuncSetAttribute((const void*)conv12_u8_mfma_kernel<true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    if (rc) return rc;
-    attr_set = true;
-  }
-  const int grid = E < 2 * kNumCU ? E : 2 * kNumCU;
-  conv12_u8_mfma_kernel<true><<<grid, 256, lds_bytes, (hipStream_t)stream>>>(nullptr, RingObs{ring, since, num_slots, E, slot},
-                                                                            w1, b1, w2, b2, out, E);
+  return launch_conv12(nullptr, RingObs{ring, since, num_slots, E, slot}, w1, b1, w2, b2, out, E, nullptr,
+                       (hipStream_t)stream);
+}
+
+PARLHIP_EXPORT size_t parlhip_atari42_conv12_weights_bytes(void) { return (size_t)kPackedFloats * sizeof(float); }
+
+PARLHIP_EXPORT int parlhip_atari42_conv12_weights_f32(const float* w1, const float* w2, float* packed_out,
+                                                      parlhip_stream_t stream) {
+  if (!w1 || !w2 || !packed_out) return PARLHIP_EINVAL;
+  if (reinterpret_cast<uintptr_t>(packed_out) & 15) return PARLHIP_EINVAL;
+  conv12_weights_pack_kernel<<<kPackedFloats / 256, 256, 0, (hipStream_t)stream>>>(w1, w2, packed_out);
   return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_atari42_conv12_packed_u8_f32(const uint8_t* obs, const float* packed, const float* b1,
+                                                        const float* b2, float* out, int n_obs,
+                                                        parlhip_stream_t stream) {
+  if (n_obs < 0) return PARLHIP_EINVAL;
+  if (n_obs == 0) return PARLHIP_OK;
+  if (!obs || !packed || !b1 || !b2 || !out) return PARLHIP_EINVAL;
+  if (reinterpret_cast<uintptr_t>(packed) & 15) return PARLHIP_EINVAL;
+  return launch_conv12(obs, RingObs{}, nullptr, b1, nullptr, b2, out, n_obs, packed, (hipStream_t)stream);
+}
+
+PARLHIP_EXPORT int parlhip_atari42_conv12_ring_packed_u8_f32(const uint8_t* ring, const uint8_t* since, int num_slots,
+                                                             int E, int slot, const float* packed, const float* b1,
+                                                             const float* b2, float* out, parlhip_stream_t stream) {
+  if (E < 0 || num_slots < 4 || slot < 0 || slot >= num_slots) return PARLHIP_EINVAL;
+  if (E == 0) return PARLHIP_OK;
+  if (!ring || !since || !packed || !b1 || !b2 || !out) return PARLHIP_EINVAL;
+  if (((uintptr_t)ring & 3u) || (reinterpret_cast<uintptr_t>(packed) & 15)) return PARLHIP_EINVAL;
+  return launch_conv12(nullptr, RingObs{ring, since, num_slots, E, slot}, nullptr, b1, nullptr, b2, out, E, packed,
+                       (hipStream_t)stream);
 }
 
 PARLHIP_EXPORT int parlhip_atari84_conv1_u8_f32(const uint8_t* obs, const float* w1, const float* b1,

@@ -91,6 +91,9 @@ def broadcast_model(model, src=0):
         return
     for p in list(model.parameters()) + list(model.buffers()):
         dist.broadcast(p.data, src=src)
+    f = getattr(model, 'refresh_actor_layout', None)   # derived copies of the weights (.data writes move no version counter)
+    if f is not None:
+        f()
 
 
 class FlatGradAllReduce(object):

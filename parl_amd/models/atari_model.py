@@ -96,13 +96,38 @@ class AtariModel42(Model):
 
     reads_ring = True   # the actors' step may hand _trunk an ops.RingObservation (DeviceRollout.collect_step)
 
+    # The actors' conv1 / conv2 weights in the MFMA kernel's operand order (ops.atari42_conv12_pack): ONE buffer at a
+    # fixed address for the life of the model — a rollout segment replayed as a hipGraph reads it — rebuilt when the
+    # weights were written: by whoever copies new weights in (refresh_actor_layout(): AsyncActorLearner after every
+    # snapshot / mid-rollout refresh, on the stream of the copy, so the events that order the weights order it too),
+    # or here, in an eager call, when the parameters' version counters moved.
+    _wpk, _wpk_key = None, None
+
+    def _packed_weights(self, force=False):
+        w1, w2 = self.conv1.weight, self.conv2.weight
+        if self._wpk is None or self._wpk.device != w1.device:
+            self._wpk, self._wpk_key = torch.empty((36, 64, 4), dtype=torch.float32, device=w1.device), None
+        key = (w1._version, w2._version, w1.data_ptr(), w2.data_ptr())
+        written = getattr(w1, '_parl_graph_written', False) or getattr(w2, '_parl_graph_written', False)
+        if force or written or key != self._wpk_key:   # (parameters a graph replay / raw-pointer optimizer writes: never trusted)
+            ops.atari42_conv12_pack(w1, w2, out=self._wpk)
+            self._wpk_key = key
+        return self._wpk
+
+    def refresh_actor_layout(self):
+        """call after writing conv1 / conv2 weights in a way the version counters may not see, or to put the rebuild
+        on the stream (and in front of the events) of a weight copy"""
+        if self.conv1.weight.is_cuda:
+            self._packed_weights(force=True)
+
     def _trunk(self, obs):
         if isinstance(obs, ops.RingObservation) and (torch.is_grad_enabled() or obs.dim != 42 or obs.shape[0] == 0):
             obs = obs.materialize()
         if (not torch.is_grad_enabled()) and obs.dtype == torch.uint8 and obs.is_cuda and obs.shape[0] > 0:
             # the actors' path (no autograd): conv1+conv2 as one fused MFMA kernel on the uint8
             # observations (ops.atari42_conv12; a RingObservation is read in place), conv3 is a 3872 -> 256 linear layer
-            h = ops.atari42_conv12(obs, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
+            h = ops.atari42_conv12(obs, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                   packed=self._packed_weights())
             # conv3 + ReLU as ONE GEMM with a ReLU epilogue (hipBLASLt) instead of addmm + clamp
             return torch._addmm_activation(self.conv3.bias, h, self.conv3.weight.flatten(1).t(), use_gelu=False)
         if obs.dtype == torch.uint8 and obs.is_cuda and obs.shape[0] > 0:

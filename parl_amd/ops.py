@@ -445,18 +445,46 @@ class RingObservation(object):
         return self._gather(out)
 
 
-def atari42_conv12(obs, conv1_weight, conv1_bias, conv2_weight, conv2_bias, out=None):
+def atari42_conv12_pack(conv1_weight, conv2_weight, out=None):
+    """The two weight matrices of atari42_conv12 in the kernel's operand order (parlhip_atari42_conv12_weights_f32):
+    f32 [36, 64, 4].  A workgroup then fetches its operands with 36 coalesced loads instead of 144 scattered ones —
+    half of the actors' 1024-observation launch was that fetch.  Rebuild when the weights change."""
+    if tuple(conv1_weight.shape) != (16, 4, 4, 4) or tuple(conv2_weight.shape) != (32, 16, 4, 4):
+        raise N.ParlHipError('atari42_conv12_pack: weights must be [16,4,4,4] and [32,16,4,4]')
+    w1, w2 = _f32(conv1_weight.detach(), 'conv1_weight'), _f32(conv2_weight.detach(), 'conv2_weight')
+    if out is None:
+        out = torch.empty((36, 64, 4), dtype=torch.float32, device=w1.device)
+    elif out.dtype != torch.float32 or out.numel() != 36 * 64 * 4 or not out.is_contiguous():
+        raise N.ParlHipError('atari42_conv12_pack: out must be contiguous f32 [36,64,4]')
+    N.check(N.lib().parlhip_atari42_conv12_weights_f32(N.ptr(w1), N.ptr(w2), N.ptr(out), N.stream_ptr()),
+            'parlhip_atari42_conv12_weights_f32')
+    return out
+
+
+def atari42_conv12(obs, conv1_weight, conv1_bias, conv2_weight, conv2_bias, out=None, packed=None):
     """conv1 + ReLU + conv2 + ReLU of the IMPALA Atari network (examples/IMPALA/atari_model.py:59-71)
     for uint8 observations [n,4,42,42], as ONE fused MFMA kernel (inference only).  Returns f32
-    [n, 3872] = the NCHW-flattened [n,32,11,11] activation.  `obs` may be a RingObservation (the actors' step)."""
+    [n, 3872] = the NCHW-flattened [n,32,11,11] activation.  `obs` may be a RingObservation (the actors' step).
+    packed: atari42_conv12_pack(conv1_weight, conv2_weight) of the CURRENT weights (same result, faster start)."""
+    if tuple(conv1_weight.shape) != (16, 4, 4, 4) or tuple(conv2_weight.shape) != (32, 16, 4, 4):
+        raise N.ParlHipError('atari42_conv12: weights must be [16,4,4,4] and [32,16,4,4]')
+    if packed is not None and (packed.dtype != torch.float32 or packed.numel() != 36 * 64 * 4 or not packed.is_contiguous()):
+        raise N.ParlHipError('atari42_conv12: packed must be atari42_conv12_pack\'s f32 [36,64,4]')
+    b1, b2 = _f32(conv1_bias.detach(), 'conv1_bias'), _f32(conv2_bias.detach(), 'conv2_bias')
     if isinstance(obs, RingObservation):
-        if obs.dim != 42 or tuple(conv1_weight.shape) != (16, 4, 4, 4) or tuple(conv2_weight.shape) != (32, 16, 4, 4):
-            raise N.ParlHipError('atari42_conv12: a 42x42 ring and weights [16,4,4,4], [32,16,4,4]')
+        if obs.dim != 42:
+            raise N.ParlHipError('atari42_conv12: a 42x42 ring')
         S, E = obs.ring.shape[0], obs.ring.shape[1]
         if out is None:
             out = torch.empty((E, 32 * 11 * 11), dtype=torch.float32, device=obs.device)
-        w1, b1 = _f32(conv1_weight.detach(), 'conv1_weight'), _f32(conv1_bias.detach(), 'conv1_bias')
-        w2, b2 = _f32(conv2_weight.detach(), 'conv2_weight'), _f32(conv2_bias.detach(), 'conv2_bias')
+        if packed is not None:
+            N.check(
+                N.lib().parlhip_atari42_conv12_ring_packed_u8_f32(N.ptr(obs.ring), N.ptr(obs.since), S, E, obs.slot,
+                                                                 N.ptr(packed), N.ptr(b1), N.ptr(b2), N.ptr(out),
+                                                                 N.stream_ptr()),
+                'parlhip_atari42_conv12_ring_packed_u8_f32')
+            return out
+        w1, w2 = _f32(conv1_weight.detach(), 'conv1_weight'), _f32(conv2_weight.detach(), 'conv2_weight')
         N.check(
             N.lib().parlhip_atari42_conv12_ring_u8_f32(N.ptr(obs.ring), N.ptr(obs.since), S, E, obs.slot, N.ptr(w1),
                                                       N.ptr(b1), N.ptr(w2), N.ptr(b2), N.ptr(out), N.stream_ptr()),
@@ -464,13 +492,16 @@ def atari42_conv12(obs, conv1_weight, conv1_bias, conv2_weight, conv2_bias, out=
         return out
     if obs.dtype != torch.uint8 or obs.dim() != 4 or tuple(obs.shape[1:]) != (4, 42, 42):
         raise N.ParlHipError('atari42_conv12: obs must be uint8 [n,4,42,42]')
-    if tuple(conv1_weight.shape) != (16, 4, 4, 4) or tuple(conv2_weight.shape) != (32, 16, 4, 4):
-        raise N.ParlHipError('atari42_conv12: weights must be [16,4,4,4] and [32,16,4,4]')
     n = obs.shape[0]
     if out is None:
         out = torch.empty((n, 32 * 11 * 11), dtype=torch.float32, device=obs.device)
-    w1, b1 = _f32(conv1_weight.detach(), 'conv1_weight'), _f32(conv1_bias.detach(), 'conv1_bias')
-    w2, b2 = _f32(conv2_weight.detach(), 'conv2_weight'), _f32(conv2_bias.detach(), 'conv2_bias')
+    if packed is not None:
+        N.check(
+            N.lib().parlhip_atari42_conv12_packed_u8_f32(N.ptr(obs.contiguous()), N.ptr(packed), N.ptr(b1), N.ptr(b2),
+                                                        N.ptr(out), n, N.stream_ptr()),
+            'parlhip_atari42_conv12_packed_u8_f32')
+        return out
+    w1, w2 = _f32(conv1_weight.detach(), 'conv1_weight'), _f32(conv2_weight.detach(), 'conv2_weight')
     N.check(
         N.lib().parlhip_atari42_conv12_u8_f32(N.ptr(obs.contiguous()), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(b2),
                                              N.ptr(out), n, N.stream_ptr()), 'parlhip_atari42_conv12_u8_f32')
@@ -510,7 +541,9 @@ class Atari42Conv12Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, obs, w1, b1, w2, b2):
-        a2 = atari42_conv12(obs, w1, b1, w2, b2)
+        # the learner's weights change with every update: the operand-order copy is made per call (one 9,216-thread
+        # launch, also inside a captured update) — cheaper than fetching the operands scattered in every workgroup
+        a2 = atari42_conv12(obs, w1, b1, w2, b2, packed=atari42_conv12_pack(w1, w2) if obs.shape[0] >= 256 else None)
         ctx.save_for_backward(obs, w1, b1, w2, a2)
         return a2
 

@@ -730,7 +730,15 @@ class AsyncActorLearner(object):
                     s0.wait_event(self.batch_ready[g][k])
             with torch.no_grad():
                 torch._foreach_copy_(self._dst, self._src)
+                self._refresh_actor_layout()
             self.snapshot_done.record(s0)
+
+    def _refresh_actor_layout(self):
+        """derived copies of the actors' weights (a model's MFMA operand-order buffers) follow every weight copy, on
+        its stream"""
+        f = getattr(self.actor_model, 'refresh_actor_layout', None)
+        if f is not None:
+            f()
 
     def _collect(self):
         k = (self.rollouts[0]._cur + 1) % 2
@@ -760,6 +768,7 @@ class AsyncActorLearner(object):
                     st.wait_event(self._pub_ready[at[a]])
                     with torch.no_grad():
                         torch._foreach_copy_(self._dst, self._pub[at[a]])
+                        self._refresh_actor_layout()
                     ro.collect_segment(self.actor_model, a, b, graph=self.graph_rollout)
             self._pass_enqueued = False
         elif len(self.rollouts) == 1 and not isinstance(self.rollouts[0], ElasticDeviceRollout):

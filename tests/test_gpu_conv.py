@@ -362,3 +362,64 @@ def test_model84_learner_path_gradients_match_gemm_lowered_autograd(dev):
     ga, gb = grads(obs), grads(obs.float())
     for (name, _), a, b in zip(m.named_parameters(), ga, gb):
         assert float((a - b).abs().max()) <= 3e-4 * float(b.abs().max()) + 1e-6, name
+
+
+def test_conv12_packed_weights_give_identical_outputs(dev):
+    """parlhip_atari42_conv12_weights_f32 + the _packed_ forward entries: the operand-order copy of the weights is
+    data movement only — outputs bit-identical to the nn.Conv2d-layout entries, plain and ring-reading"""
+    from parl_amd import ops
+    from parl_amd.env import DeviceVectorEnv
+    torch.manual_seed(5)
+    w1, b1 = torch.randn(16, 4, 4, 4, device=dev) * 0.2, torch.randn(16, device=dev) * 0.1
+    w2, b2 = torch.randn(32, 16, 4, 4, device=dev) * 0.1, torch.randn(32, device=dev) * 0.1
+    pk = ops.atari42_conv12_pack(w1, w2)
+    assert tuple(pk.shape) == (36, 64, 4)
+    # every weight appears exactly once in the packed copy
+    assert torch.equal(torch.sort(pk.flatten()).values, torch.sort(torch.cat([w1.flatten(), w2.flatten()])).values)
+    for n in (1, 3, 700, 1030):
+        obs = torch.randint(0, 256, (n, 4, 42, 42), dtype=torch.uint8, device=dev)
+        assert torch.equal(ops.atari42_conv12(obs, w1, b1, w2, b2), ops.atari42_conv12(obs, w1, b1, w2, b2, packed=pk))
+    try:
+        env = DeviceVectorEnv('PongNoFrameskip-v4', 9, dim=42, horizon=8, seed=2, device=dev)
+    except FileNotFoundError:
+        pytest.skip('cartridge pong.bin not present')
+    env.reset()
+    for i in range(5):
+        env.step(torch.randint(0, 6, (9, ), device=dev))
+        ref = env.current_obs_ref()
+        assert torch.equal(ops.atari42_conv12(ref, w1, b1, w2, b2), ops.atari42_conv12(ref, w1, b1, w2, b2, packed=pk))
+
+
+def test_model42_packed_weights_follow_the_weights(dev):
+    """AtariModel42 keeps ONE operand-order buffer (fixed address: hipGraph segments read it); it is rebuilt when
+    the parameters' version counters moved, after set_weights / sync_weights_to, and on refresh_actor_layout()"""
+    from parl_amd.models import AtariModel42
+    torch.manual_seed(1)
+    m, other = AtariModel42(6).to(dev), AtariModel42(6).to(dev)
+    obs = torch.randint(0, 256, (33, 4, 42, 42), dtype=torch.uint8, device=dev)
+
+    def check():
+        with torch.no_grad():
+            got = m.policy_hidden(obs)
+            h = ops.atari42_conv12(obs, m.conv1.weight, m.conv1.bias, m.conv2.weight, m.conv2.bias)   # unpacked
+            want = torch._addmm_activation(m.conv3.bias, h, m.conv3.weight.flatten(1).t(), use_gelu=False)
+        assert torch.equal(got, want)
+
+    from parl_amd import ops
+    check()
+    addr = m._wpk.data_ptr()
+    with torch.no_grad():
+        m.conv2.weight.mul_(1.5)                      # an eager in-place write: the version counter moves
+    check()
+    with torch.no_grad():
+        torch._foreach_copy_(list(m.parameters()), list(other.parameters()))   # the actors' snapshot copy
+    check()
+    other.conv1.weight.data.add_(0.25)
+    other.sync_weights_to(m)                          # .data writes: no version bump, the model refreshes itself
+    check()
+    m.set_weights(AtariModel42(6).get_weights())
+    check()
+    m.conv1.weight.data.mul_(2.0)                     # nobody told the model ...
+    m.refresh_actor_layout()                          # ... until now
+    check()
+    assert m._wpk.data_ptr() == addr
