@@ -461,6 +461,15 @@ int parlhip_atari84_conv1_u8_f32(const uint8_t* obs, const float* w1, const floa
  * out f32 [E,32,20,20].  Bit-identical to parlhip_stack_gather_ring_u8 + parlhip_atari84_conv1_u8_f32.        */
 int parlhip_atari84_conv1_ring_u8_f32(const uint8_t* ring, const uint8_t* since, int num_slots, int E, int slot,
                                       const float* w1, const float* b1, float* out, parlhip_stream_t stream);
+/* The two entries above with the weight matrix in operand order: wt1 f32 [64][2][64], wt1[ks][nt][q*16 + col] =
+ * w1[16*nt + col][4*ks + q] over w1 viewed as [32, 256] (the layout parlhip_atari84_conv23_f32 takes its wt2 / wt3
+ * in): a workgroup fetches its operands with coalesced loads — the scattered fetch from the nn.Conv2d layout is
+ * the start-up cost of a workgroup (see parlhip_atari42_conv12_weights_f32).  Bit-identical outputs.          */
+int parlhip_atari84_conv1_packed_u8_f32(const uint8_t* obs, const float* wt1, const float* b1, float* out,
+                                        int n_obs, parlhip_stream_t stream);
+int parlhip_atari84_conv1_ring_packed_u8_f32(const uint8_t* ring, const uint8_t* since, int num_slots, int E,
+                                             int slot, const float* wt1, const float* b1, float* out,
+                                             parlhip_stream_t stream);
 
 /* examples/A2C/atari_model.py:21-104 (AtariModel trunk), second and third layer, fused:
  * conv2 32->64 k4 s2 p2 + ReLU (20x20 -> 11x11), conv3 64->64 k3 s1 + ReLU (-> 9x9).

@@ -96,6 +96,8 @@ SIGNATURES = {
     'parlhip_atari42_conv12_ring_packed_u8_f32': (_i, [_p, _p, _i, _i, _i] + [_p] * 5),
     'parlhip_atari84_conv1_u8_f32': (_i, [_p, _p, _p, _p, _i, _p]),
     'parlhip_atari84_conv1_ring_u8_f32': (_i, [_p, _p, _i, _i, _i] + [_p] * 4),
+    'parlhip_atari84_conv1_packed_u8_f32': (_i, [_p, _p, _p, _p, _i, _p]),
+    'parlhip_atari84_conv1_ring_packed_u8_f32': (_i, [_p, _p, _i, _i, _i] + [_p] * 4),
     'parlhip_atari84_conv23_f32': (_i, [_p] * 7 + [_i, _p]),
     'parlhip_atari84_conv3_bwd_workspace_bytes': (_sz, [_i]),
     'parlhip_atari84_conv3_bwd_f32': (_i, [_p] * 4 + [_i] + [_p] * 4),

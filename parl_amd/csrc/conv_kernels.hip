@@ -662,7 +662,11 @@ constexpr int kPlane84 = kD84 * kD84;    // 7056
 constexpr int kGuard84 = 88;                                     // zero bytes in front of plane 0 (>= 85, 4-byte multiple)
 constexpr int kLds84u8Bytes = kGuard84 + 4 * kPlane84 + 8;       // 28,320
 
-template <bool RING>   // RING: the four 84x84 frames of env n read from the rollout ring in place (see RingObs)
+// RING: the four 84x84 frames of env n read from the rollout ring in place (see RingObs).  PACKED: `w` is the weight
+// matrix in operand order, wt1[ks][nt][lane] (the layout conv23_84_mfma_kernel's wt2 / wt3 have): 128 coalesced
+// 256-byte loads per wave instead of 128 loads touching 16 cache lines each — the start-up cost conv12_u8_mfma_kernel
+// had (see there).
+template <bool RING, bool PACKED>
 __global__ __launch_bounds__(256, 2) void conv1_84_u8_mfma_kernel(
     const uint8_t* __restrict__ obs, RingObs ro, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, int n_obs) {
@@ -674,8 +678,13 @@ __global__ __launch_bounds__(256, 2) void conv1_84_u8_mfma_kernel(
   float breg[64][2];
 #pragma unroll
   for (int ks = 0; ks < 64; ++ks) {
-    breg[ks][0] = w[col * kK84 + ks * 4 + q];
-    breg[ks][1] = w[(16 + col) * kK84 + ks * 4 + q];
+    if constexpr (PACKED) {
+      breg[ks][0] = w[(ks * 2) * 64 + lane];
+      breg[ks][1] = w[(ks * 2 + 1) * 64 + lane];
+    } else {
+      breg[ks][0] = w[col * kK84 + ks * 4 + q];
+      breg[ks][1] = w[(16 + col) * kK84 + ks * 4 + q];
+    }
   }
   const float bias0 = bias[col], bias1 = bias[16 + col];
   if (tid < kGuard84 / 4) reinterpret_cast<uint32_t*>(tile)[tid] = 0u;
@@ -1442,46 +1451,74 @@ PARLHIP_EXPORT int parlhip_atari42_conv12_ring_packed_u8_f32(const uint8_t* ring
                        (hipStream_t)stream);
 }
 
-PARLHIP_EXPORT int parlhip_atari84_conv1_u8_f32(const uint8_t* obs, const float* w1, const float* b1,
-                                                float* out, int n_obs, parlhip_stream_t stream) {
-  if (n_obs < 0) return PARLHIP_EINVAL;
-  if (n_obs == 0) return PARLHIP_OK;
-  if (!obs || !w1 || !b1 || !out) return PARLHIP_EINVAL;
-  // 4-byte input loads / 16-byte output stores (torch allocations are 256 B aligned; a view
-  // starting at an observation boundary keeps both: 28,224 and 51,200 are multiples of 16)
-  if (((uintptr_t)obs & 3u) || ((uintptr_t)out & 15u)) return PARLHIP_EINVAL;
+static int launch_conv1_84(const uint8_t* obs, const RingObs& ro, const float* w, const float* b1, float* out, int n_obs,
+                           bool packed, hipStream_t stream) {
   static bool attr_set = false;
   const size_t lds_bytes = kLds84u8Bytes;
   if (!attr_set) {
-    int rc = check(hipFuncSetAttribute((const void*)conv1_84_u8_mfma_kernel<false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    if (rc) return rc;
+    const void* fns[4] = {(const void*)conv1_84_u8_mfma_kernel<false, false>, (const void*)conv1_84_u8_mfma_kernel<false, true>,
+                          (const void*)conv1_84_u8_mfma_kernel<true, false>, (const void*)conv1_84_u8_mfma_kernel<true, true>};
+    for (const void* f : fns) {
+      int rc = check(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      if (rc) return rc;
+    }
     attr_set = true;
   }
   const int grid = n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU;  // 28 KB of LDS, <= 256 VGPRs: two workgroups per CU
-  conv1_84_u8_mfma_kernel<false><<<grid, 256, lds_bytes, (hipStream_t)stream>>>(obs, RingObs{}, w1, b1, out, n_obs);
+#define PARLHIP_C184(R, P, O, RO) conv1_84_u8_mfma_kernel<R, P><<<grid, 256, lds_bytes, stream>>>(O, RO, w, b1, out, n_obs)
+  if (ro.ring) {
+    if (packed) PARLHIP_C184(true, true, nullptr, ro);
+    else PARLHIP_C184(true, false, nullptr, ro);
+  } else {
+    if (packed) PARLHIP_C184(false, true, obs, RingObs{});
+    else PARLHIP_C184(false, false, obs, RingObs{});
+  }
+#undef PARLHIP_C184
   return check_launch();
+}
+
+static int conv1_84_args(const void* in, const float* w1, const float* b1, const float* out, int n_obs) {
+  if (n_obs < 0) return PARLHIP_EINVAL;
+  if (n_obs == 0) return 1;
+  if (!in || !w1 || !b1 || !out) return PARLHIP_EINVAL;
+  // 4-byte input loads / 16-byte output stores (torch allocations are 256 B aligned; a view
+  // starting at an observation boundary keeps both: 28,224 and 51,200 are multiples of 16)
+  if (((uintptr_t)in & 3u) || ((uintptr_t)out & 15u)) return PARLHIP_EINVAL;
+  return PARLHIP_OK;
+}
+
+PARLHIP_EXPORT int parlhip_atari84_conv1_u8_f32(const uint8_t* obs, const float* w1, const float* b1,
+                                                float* out, int n_obs, parlhip_stream_t stream) {
+  const int rc = conv1_84_args(obs, w1, b1, out, n_obs);
+  if (rc) return rc < 0 ? rc : PARLHIP_OK;
+  return launch_conv1_84(obs, RingObs{}, w1, b1, out, n_obs, false, (hipStream_t)stream);
+}
+
+PARLHIP_EXPORT int parlhip_atari84_conv1_packed_u8_f32(const uint8_t* obs, const float* wt1, const float* b1,
+                                                       float* out, int n_obs, parlhip_stream_t stream) {
+  const int rc = conv1_84_args(obs, wt1, b1, out, n_obs);
+  if (rc) return rc < 0 ? rc : PARLHIP_OK;
+  return launch_conv1_84(obs, RingObs{}, wt1, b1, out, n_obs, true, (hipStream_t)stream);
 }
 
 PARLHIP_EXPORT int parlhip_atari84_conv1_ring_u8_f32(const uint8_t* ring, const uint8_t* since, int num_slots, int E,
                                                      int slot, const float* w1, const float* b1, float* out,
                                                      parlhip_stream_t stream) {
-  if (E < 0 || num_slots < 4 || slot < 0 || slot >= num_slots) return PARLHIP_EINVAL;
-  if (E == 0) return PARLHIP_OK;
-  if (!ring || !since || !w1 || !b1 || !out) return PARLHIP_EINVAL;
-  if (((uintptr_t)ring & 3u) || ((uintptr_t)out & 15u)) return PARLHIP_EINVAL;
-  static bool attr_set = false;
-  const size_t lds_bytes = kLds84u8Bytes;
-  if (!attr_set) {
-    int rc = check(hipFuncSetAttribute((const void*)conv1_84_u8_mfma_kernel<true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    if (rc) return rc;
-    attr_set = true;
-  }
-  const int grid = E < 2 * kNumCU ? E : 2 * kNumCU;
-  conv1_84_u8_mfma_kernel<true><<<grid, 256, lds_bytes, (hipStream_t)stream>>>(nullptr, RingObs{ring, since, num_slots, E, slot},
-                                                                              w1, b1, out, E);
-  return check_launch();
+  if (num_slots < 4 || slot < 0 || slot >= num_slots) return PARLHIP_EINVAL;
+  const int rc = conv1_84_args(ring, w1, b1, out, E);
+  if (rc) return rc < 0 ? rc : PARLHIP_OK;
+  if (!since) return PARLHIP_EINVAL;
+  return launch_conv1_84(nullptr, RingObs{ring, since, num_slots, E, slot}, w1, b1, out, E, false, (hipStream_t)stream);
+}
+
+PARLHIP_EXPORT int parlhip_atari84_conv1_ring_packed_u8_f32(const uint8_t* ring, const uint8_t* since, int num_slots,
+                                                            int E, int slot, const float* wt1, const float* b1,
+                                                            float* out, parlhip_stream_t stream) {
+  if (num_slots < 4 || slot < 0 || slot >= num_slots) return PARLHIP_EINVAL;
+  const int rc = conv1_84_args(ring, wt1, b1, out, E);
+  if (rc) return rc < 0 ? rc : PARLHIP_OK;
+  if (!since) return PARLHIP_EINVAL;
+  return launch_conv1_84(nullptr, RingObs{ring, since, num_slots, E, slot}, wt1, b1, out, E, true, (hipStream_t)stream);
 }
 
 static int conv12_bwd_grid(int n_obs) { return n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU; }  // 69 KB of LDS: two per CU

@@ -557,34 +557,41 @@ class Atari42Conv12Fn(torch.autograd.Function):
 def atari84_conv1(obs, conv1_weight, conv1_bias, out=None):
     """conv1 + ReLU of the A2C Atari network (examples/A2C/atari_model.py:21-104: 4->32 k8 s4 p1,
     84x84 -> 20x20) for uint8 observations [n,4,84,84] as one MFMA kernel with the /255 fused
-    (inference only).  Returns f32 [n,32,20,20].  `obs` may be a RingObservation (the actors' step)."""
+    (inference only).  Returns f32 [n,32,20,20].  `obs` may be a RingObservation (the actors' step).
+    The kernel gets the weights in operand order (wt1 = _mfma_b_layout of the [32, 256] matrix; cached per weight
+    tensor and version like atari84_conv23's): the scattered fetch from the nn.Conv2d layout was the start-up
+    cost of every workgroup."""
+    if tuple(conv1_weight.shape) != (32, 4, 8, 8) or tuple(conv1_bias.shape) != (32, ):
+        raise N.ParlHipError('atari84_conv1: weight must be [32,4,8,8], bias [32]')
+    b1 = _f32(conv1_bias.detach(), 'conv1_bias')
+    if not conv1_weight.is_cuda:
+        N.ptr(conv1_weight)   # raises: no CPU path
+    # (rebuilt when the tensor's version moved — every optimizer step for the learner, once per rollout for the actors —
+    # and always for parameters a graph replay writes)
+    wt1 = _cached_layout(conv1_weight, 'wt1', lambda w: _mfma_b_layout(_f32(w.detach(), 'conv1_weight').reshape(32, 256)))
     if isinstance(obs, RingObservation):
-        if obs.dim != 84 or tuple(conv1_weight.shape) != (32, 4, 8, 8) or tuple(conv1_bias.shape) != (32, ):
-            raise N.ParlHipError('atari84_conv1: an 84x84 ring, weight [32,4,8,8], bias [32]')
+        if obs.dim != 84:
+            raise N.ParlHipError('atari84_conv1: an 84x84 ring')
         S, E = obs.ring.shape[0], obs.ring.shape[1]
         if out is None:
             out = torch.empty((E, 32, 20, 20), dtype=torch.float32, device=obs.device)
         elif out.dtype != torch.float32 or out.numel() != E * 12800 or not out.is_contiguous():
             raise N.ParlHipError('atari84_conv1: out must be contiguous f32 [n,32,20,20]')
-        w1, b1 = _f32(conv1_weight.detach(), 'conv1_weight'), _f32(conv1_bias.detach(), 'conv1_bias')
         N.check(
-            N.lib().parlhip_atari84_conv1_ring_u8_f32(N.ptr(obs.ring), N.ptr(obs.since), S, E, obs.slot, N.ptr(w1),
-                                                     N.ptr(b1), N.ptr(out), N.stream_ptr()),
-            'parlhip_atari84_conv1_ring_u8_f32')
+            N.lib().parlhip_atari84_conv1_ring_packed_u8_f32(N.ptr(obs.ring), N.ptr(obs.since), S, E, obs.slot,
+                                                            N.ptr(wt1), N.ptr(b1), N.ptr(out), N.stream_ptr()),
+            'parlhip_atari84_conv1_ring_packed_u8_f32')
         return out
     if obs.dtype != torch.uint8 or obs.dim() != 4 or tuple(obs.shape[1:]) != (4, 84, 84):
         raise N.ParlHipError('atari84_conv1: obs must be uint8 [n,4,84,84]')
-    if tuple(conv1_weight.shape) != (32, 4, 8, 8) or tuple(conv1_bias.shape) != (32, ):
-        raise N.ParlHipError('atari84_conv1: weight must be [32,4,8,8], bias [32]')
     n = obs.shape[0]
     if out is None:
         out = torch.empty((n, 32, 20, 20), dtype=torch.float32, device=obs.device)
     elif out.dtype != torch.float32 or out.numel() != n * 12800 or not out.is_contiguous():
         raise N.ParlHipError('atari84_conv1: out must be contiguous f32 [n,32,20,20]')
-    w1, b1 = _f32(conv1_weight.detach(), 'conv1_weight'), _f32(conv1_bias.detach(), 'conv1_bias')
     N.check(
-        N.lib().parlhip_atari84_conv1_u8_f32(N.ptr(obs.contiguous()), N.ptr(w1), N.ptr(b1), N.ptr(out), n,
-                                            N.stream_ptr()), 'parlhip_atari84_conv1_u8_f32')
+        N.lib().parlhip_atari84_conv1_packed_u8_f32(N.ptr(obs.contiguous()), N.ptr(wt1), N.ptr(b1), N.ptr(out), n,
+                                                   N.stream_ptr()), 'parlhip_atari84_conv1_packed_u8_f32')
     return out
 
 

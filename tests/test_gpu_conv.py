@@ -423,3 +423,19 @@ def test_model42_packed_weights_follow_the_weights(dev):
     m.refresh_actor_layout()                          # ... until now
     check()
     assert m._wpk.data_ptr() == addr
+
+
+def test_conv1_84_operand_order_weights_give_identical_outputs(dev):
+    """parlhip_atari84_conv1_[ring_]packed_u8_f32 (what ops.atari84_conv1 calls) against the nn.Conv2d-layout entries"""
+    from parl_amd import _native as N
+    from parl_amd import ops
+    torch.manual_seed(9)
+    w1, b1 = torch.randn(32, 4, 8, 8, device=dev) * 0.1, torch.randn(32, device=dev) * 0.1
+    for n in (1, 5, 600):
+        obs = torch.randint(0, 256, (n, 4, 84, 84), dtype=torch.uint8, device=dev)
+        want = torch.empty((n, 32, 20, 20), dtype=torch.float32, device=dev)
+        N.check(N.lib().parlhip_atari84_conv1_u8_f32(N.ptr(obs), N.ptr(w1), N.ptr(b1), N.ptr(want), n, N.stream_ptr()), 'conv1_84')
+        assert torch.equal(ops.atari84_conv1(obs, w1, b1), want)
+    w1.mul_(0.5)   # the cached operand-order copy follows the tensor's version
+    N.check(N.lib().parlhip_atari84_conv1_u8_f32(N.ptr(obs), N.ptr(w1), N.ptr(b1), N.ptr(want), n, N.stream_ptr()), 'conv1_84')
+    assert torch.equal(ops.atari84_conv1(obs, w1, b1), want)
