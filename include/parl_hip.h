@@ -371,6 +371,22 @@ int parlhip_atari_vec_step_elastic(void* states, const uint32_t* rom_table_dev, 
                                    int32_t* finished, float* rewards_rows, uint8_t* dones_rows,
                                    int new_slot, int32_t* cur_slot, int32_t* link, uint8_t* since,
                                    parlhip_stream_t stream);
+/* The elastic launch with the observation of the envs that completed a step made in the same launch
+ * (parlhip_atari_vec_step_obs's tail; obs_out = ring slot `new_slot`, u8 [E, dim*dim]): replaces the
+ * parlhip_frame_post_u8(flags = obs_flags) call behind parlhip_atari_vec_step_elastic.  Same outputs.
+ * PARLHIP_ENOSUP unless dim is 42 or 84 and the cartridge an unbanked 2K one.                            */
+int parlhip_atari_vec_step_elastic_obs(void* states, const uint32_t* rom_table_dev, uint32_t rom_size,
+                                       int game, const int64_t* actions, uint8_t* frames, float* rewards,
+                                       uint8_t* dones, uint8_t* obs_flags, float* ep_returns,
+                                       int32_t* ep_lengths, int E, uint64_t seed, uint64_t env_id0,
+                                       int64_t max_episode_steps, const void* reset_cache_dev,
+                                       int32_t* jam_flag_dev, int frame_budget, int launch, int rows_limit,
+                                       int rows_ring, int batch_rows, int32_t* rows_done,
+                                       int32_t* row_launch, int32_t* row_slot, uint8_t* ctl,
+                                       int32_t* finished, float* rewards_rows, uint8_t* dones_rows,
+                                       int new_slot, int32_t* cur_slot, int32_t* link, uint8_t* since,
+                                       uint8_t* obs_out, int dim, const void* tables_dev,
+                                       parlhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * FrameStack (atari_wrappers.py:270-306) over a rollout ring of SINGLE frames

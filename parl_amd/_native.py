@@ -85,6 +85,9 @@ SIGNATURES = {
     'parlhip_atari_vec_step_elastic':
     (_i, [_p, _p, ctypes.c_uint32, _i, _p, _p, _p, _p, _p, _p, _p, _i, _u64, _u64, _i64, _p, _p, _i, _i, _i, _i, _i] +
      [_p] * 7 + [_i] + [_p] * 4),
+    'parlhip_atari_vec_step_elastic_obs':
+    (_i, [_p, _p, ctypes.c_uint32, _i, _p, _p, _p, _p, _p, _p, _p, _i, _u64, _u64, _i64, _p, _p, _i, _i, _i, _i, _i] +
+     [_p] * 7 + [_i] + [_p] * 4 + [_i, _p, _p]),
     'parlhip_stack_gather_ring_u8': (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i64, _p, _p]),
     'parlhip_stack_since_update_u8': (_i, [_p, _p, _p, _i, _p]),
     'parlhip_stack_gather_u8': (_i, [_p, _p, _i, _i, _p, _p, _i64, _p, _p]),

@@ -549,9 +549,12 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
   store_env(emu, v, blob, lane);
   if (obs_out) {
     if (lane == 0) {
-      const uint8_t* sp = fz->since_prev;
-      const int p = sp ? sp[e] : 0;
-      fz->since_next[e] = (phase != PH_END || did_reset) ? 0 : (uint8_t)(p + 1 > 3 ? 3 : p + 1);
+      uint8_t* sn = fz->since_next;   // (null: elastic launches keep the FrameStack counters in elastic_post_kernel)
+      if (sn) {
+        const uint8_t* sp = fz->since_prev;
+        const int p = sp ? sp[e] : 0;
+        sn[e] = (phase != PH_END || did_reset) ? 0 : (uint8_t)(p + 1 > 3 ? 3 : p + 1);
+      }
       double* acc = fz->ep_acc;
       if (acc && ep_closed && ep_length > 0) {
         atomicAdd(acc + 0, 1.0);
@@ -792,7 +795,7 @@ PARLHIP_EXPORT int parlhip_atari_vec_step_policy_obs(
                     (void*)reset_cache_dev, jam_flag_dev, (hipStream_t)stream, 0, nullptr, &fz);
 }
 
-PARLHIP_EXPORT int parlhip_atari_vec_step_elastic(void* states, const uint32_t* rom_table_dev, uint32_t rom_size,
+static int vec_step_elastic(const StepFuse* fuse, void* states, const uint32_t* rom_table_dev, uint32_t rom_size,
                                                   int game, const int64_t* actions, uint8_t* frames, float* rewards,
                                                   uint8_t* dones, uint8_t* obs_flags, float* ep_returns,
                                                   int32_t* ep_lengths, int E, uint64_t seed, uint64_t env_id0,
@@ -820,12 +823,52 @@ PARLHIP_EXPORT int parlhip_atari_vec_step_elastic(void* states, const uint32_t* 
                                                       ep_lengths);
   rc = launch_env(MODE_STEP, states, rom_table_dev, rom_size, game, actions, frames, rewards, dones, obs_flags,
                   ep_returns, ep_lengths, E, seed, env_id0, max_episode_steps, (void*)reset_cache_dev,
-                  jam_flag_dev, s, frame_budget, ctl);
+                  jam_flag_dev, s, frame_budget, ctl, fuse);
   if (rc) return rc;
   elastic_post_kernel<<<ceil_div(E, 256), 256, 0, s>>>(E, rows_ring, batch_rows, rows_done, ctl, rewards, dones,
                                                        rewards_rows, dones_rows, finished, obs_flags, new_slot,
                                                        cur_slot, link, since);
   return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_atari_vec_step_elastic(void* states, const uint32_t* rom_table_dev, uint32_t rom_size,
+                                                  int game, const int64_t* actions, uint8_t* frames, float* rewards,
+                                                  uint8_t* dones, uint8_t* obs_flags, float* ep_returns,
+                                                  int32_t* ep_lengths, int E, uint64_t seed, uint64_t env_id0,
+                                                  int64_t max_episode_steps, const void* reset_cache_dev,
+                                                  int32_t* jam_flag_dev, int frame_budget, int launch,
+                                                  int rows_limit, int rows_ring, int batch_rows,
+                                                  int32_t* rows_done, int32_t* row_launch, int32_t* row_slot,
+                                                  uint8_t* ctl, int32_t* finished, float* rewards_rows,
+                                                  uint8_t* dones_rows, int new_slot, int32_t* cur_slot,
+                                                  int32_t* link, uint8_t* since, parlhip_stream_t stream) {
+  return vec_step_elastic(nullptr, states, rom_table_dev, rom_size, game, actions, frames, rewards, dones, obs_flags,
+                          ep_returns, ep_lengths, E, seed, env_id0, max_episode_steps, reset_cache_dev, jam_flag_dev,
+                          frame_budget, launch, rows_limit, rows_ring, batch_rows, rows_done, row_launch, row_slot, ctl,
+                          finished, rewards_rows, dones_rows, new_slot, cur_slot, link, since, stream);
+}
+
+PARLHIP_EXPORT int parlhip_atari_vec_step_elastic_obs(void* states, const uint32_t* rom_table_dev, uint32_t rom_size,
+                                                      int game, const int64_t* actions, uint8_t* frames, float* rewards,
+                                                      uint8_t* dones, uint8_t* obs_flags, float* ep_returns,
+                                                      int32_t* ep_lengths, int E, uint64_t seed, uint64_t env_id0,
+                                                      int64_t max_episode_steps, const void* reset_cache_dev,
+                                                      int32_t* jam_flag_dev, int frame_budget, int launch,
+                                                      int rows_limit, int rows_ring, int batch_rows,
+                                                      int32_t* rows_done, int32_t* row_launch, int32_t* row_slot,
+                                                      uint8_t* ctl, int32_t* finished, float* rewards_rows,
+                                                      uint8_t* dones_rows, int new_slot, int32_t* cur_slot,
+                                                      int32_t* link, uint8_t* since, uint8_t* obs_out, int dim,
+                                                      const void* tables_dev, parlhip_stream_t stream) {
+  if (!obs_tail_supports(dim, (int)rom_size)) return PARLHIP_ENOSUP;
+  if (E > 0 && (!obs_out || !tables_dev)) return PARLHIP_EINVAL;
+  if (reinterpret_cast<uintptr_t>(frames) & 15) return PARLHIP_EINVAL;
+  StepFuse fz{};
+  fz.obs_out = obs_out; fz.tables = (const uint8_t*)tables_dev; fz.dim = dim;   // since / MonitorEnv sums: the elastic path's own kernels
+  return vec_step_elastic(&fz, states, rom_table_dev, rom_size, game, actions, frames, rewards, dones, obs_flags,
+                          ep_returns, ep_lengths, E, seed, env_id0, max_episode_steps, reset_cache_dev, jam_flag_dev,
+                          frame_budget, launch, rows_limit, rows_ring, batch_rows, rows_done, row_launch, row_slot, ctl,
+                          finished, rewards_rows, dones_rows, new_slot, cur_slot, link, since, stream);
 }
 
 #ifdef PARLHIP_ENV_REGIONS

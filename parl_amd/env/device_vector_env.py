@@ -307,16 +307,18 @@ class DeviceVectorEnv(object):
             raise N.ParlHipError('call elastic_begin() after reset()')
         slot = (launch + 4) % self.slots
         L = N.lib()
-        N.check(
-            L.parlhip_atari_vec_step_elastic(
-                N.ptr(self.states), N.ptr(self.rom_table), self.rom_size, self.game, N.ptr(actions.contiguous()),
+        args = (N.ptr(self.states), N.ptr(self.rom_table), self.rom_size, self.game, N.ptr(actions.contiguous()),
                 N.ptr(self.raw_frames), N.ptr(self.rewards), N.ptr(self.dones), N.ptr(self.obs_flags),
                 N.ptr(self.ep_returns), N.ptr(self.ep_lengths), self.envs_num, self.seed, self.env_id0,
                 self.max_episode_steps, N.ptr(self.reset_cache), N.ptr(self.jam), int(frame_budget), int(launch),
                 int(rows_limit), int(rows_ring), int(batch_rows), N.ptr(rows_done), N.ptr(row_launch),
                 N.ptr(row_slot), N.ptr(self._ctl), N.ptr(finished), N.ptr(rewards_rows), N.ptr(dones_rows), slot,
-                N.ptr(self.cur_slot), N.ptr(self.link), N.ptr(self.since), N.stream_ptr()),
-            'parlhip_atari_vec_step_elastic')
+                N.ptr(self.cur_slot), N.ptr(self.link), N.ptr(self.since))
+        if self.fused_obs:   # the observation of the envs that completed a step, made at the tail of the same launch
+            N.check(L.parlhip_atari_vec_step_elastic_obs(*args, N.ptr(self.ring[slot]), self.dim, N.ptr(self.fp_tables),
+                                                         N.stream_ptr()), 'parlhip_atari_vec_step_elastic_obs')
+            return
+        N.check(L.parlhip_atari_vec_step_elastic(*args, N.stream_ptr()), 'parlhip_atari_vec_step_elastic')
         self._frame_post_elastic(slot)
 
     def _frame_post_elastic(self, slot):

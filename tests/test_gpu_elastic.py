@@ -30,17 +30,21 @@ def _model(dev, act_dim, seed=0):
     return m
 
 
-def _elastic(dev, game, E, T, dim, seed, rom, env_id0=0):
+def _elastic(dev, game, E, T, dim, seed, rom, env_id0=0, fused_obs=None):
     from parl_amd.env import DeviceVectorEnv
     from parl_amd.rollout import ElasticDeviceRollout
     env = DeviceVectorEnv(game, E, dim=dim, horizon=4 * T + 32, seed=seed, env_id0=env_id0, device=dev, rom_bytes=rom)
+    if fused_obs is not None:   # the observation at the tail of the env launch (default) or as a frame_post launch behind it
+        assert env.fused_obs or not fused_obs
+        env.fused_obs = bool(fused_obs)
     return env, ElasticDeviceRollout(env, T, seed=seed + 1)
 
 
-def test_elastic_rows_replay_through_the_oracle(dev, oracle):
+@pytest.mark.parametrize('fused_obs', [True, False])
+def test_elastic_rows_replay_through_the_oracle(dev, oracle, fused_obs):
     E, T, dim, seed, batches = 16, 10, 42, 3, 14
     rom = _rom('breakout')
-    env, ro = _elastic(dev, BREAKOUT, E, T, dim, seed, rom)
+    env, ro = _elastic(dev, BREAKOUT, E, T, dim, seed, rom, fused_obs=fused_obs)
     model = _model(dev, env.act_dim)
     orc = oracle.VecEnv(rom, 'breakout', E, dim, seed=seed)
     o_prev = orc.reset()
