@@ -79,11 +79,11 @@ class KernelTimer(object):
         return {'n': len(ts), 'mean': sum(ts) / len(ts), 'median': ts[len(ts) // 2], 'min': ts[0], 'max': ts[-1]}
 
 
-# SQ counters of atari_env_kernel<Pong> at E = 1024 (profiles/r04_env_pmc.log; the kernel did not change in round 5):
-# active instructions per wave-clock of the two waves an env occupies
-ENV_PMC = {'issue_slot_utilisation': 76765.0 / 213224.0, 'instructions_per_frame': 76765,
-           'source': 'profiles/r04_env_pmc.log (rocprofv3 --pmc, tools/pmc_env.sh): SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES per '
-                     'wave and emulated frame, both in 4-clock issue slots — a wave of this kernel issues in 36 % of its '
+# SQ counters of atari_env_kernel<Pong> at E = 1024 (profiles/r05_env_pmc.log: the kernel with the policy head at its head
+# and the observation at its tail): active instructions per wave-clock of the two waves an env occupies
+ENV_PMC = {'issue_slot_utilisation': 80224.0 / 209577.0, 'instructions_per_frame': 80224,
+           'source': 'profiles/r05_env_pmc.log (rocprofv3 --pmc, tools/pmc_env.sh): SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES per '
+                     'wave and emulated frame, both in 4-clock issue slots — a wave of this kernel issues in 38 % of its '
                      'slots, two such waves share a SIMD'}
 
 
@@ -748,8 +748,8 @@ def _main():
                             ('gloo, ranks SHARE GPUs (fewer devices than ranks: functional run, not a scaling number)'
                              if shared else 'RCCL: flat-gradient all-reduce + small-tensor all-gather per update')),
         },
-        'spread_note': 'the timed region is K x ~45 ms of launch-latency-bound graph replays; on the boxes of this pool '
-                       'the same command has given 4.3-4.6 M frames/s (profiles/README.md)',
+        'spread_note': 'the timed region is K x ~42 ms of graph replays; on the boxes of this pool the same command of the '
+                       'round\'s final code has given 4.8-4.9 M frames/s (round 4\'s code: 4.3-4.6 M; profiles/README.md)',
         'learner_updates_per_sec': ((pipe.updates - updates0) if pipe is not None else K) / dt,
         'agent_steps_per_sec': K * T * E * world / dt,
     }

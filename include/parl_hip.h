@@ -441,7 +441,8 @@ int parlhip_atari42_conv12_ring_u8_f32(const uint8_t* ring, const uint8_t* since
  * lines each — the start-up of a workgroup, half of the actors' 1024-observation launch.  packed_out f32
  * [parlhip_atari42_conv12_weights_bytes() / 4], 16-byte aligned; rebuild whenever w1 / w2 change (the actors:
  * once per weight refresh, atari_model.py:59-71's parameters).  The _packed_ entries below are the two forward
- * entries above with `packed` in place of (w1, w2): bit-identical outputs.                                   */
+ * entries above with `packed` in place of (w1, w2): bit-identical outputs.  The buffer also carries the backward
+ * kernel's operands (parlhip_atari42_conv12_bwd_packed_f32).                                                  */
 size_t parlhip_atari42_conv12_weights_bytes(void);
 int parlhip_atari42_conv12_weights_f32(const float* w1, const float* w2, float* packed_out,
                                        parlhip_stream_t stream);
@@ -464,6 +465,12 @@ int parlhip_atari42_conv12_bwd_f32(const uint8_t* obs, const float* w1, const fl
                                    const float* w2, const float* a2, const float* dy, int n_obs,
                                    float* workspace, float* dw1, float* db1, float* dw2, float* db2,
                                    parlhip_stream_t stream);
+/* The same with the weights from parlhip_atari42_conv12_weights_f32's buffer (of the CURRENT weights) in place of
+ * (w1, w2): bit-identical gradients, 12 coalesced operand loads per lane instead of 48 scattered ones.        */
+int parlhip_atari42_conv12_bwd_packed_f32(const uint8_t* obs, const float* packed, const float* b1,
+                                          const float* a2, const float* dy, int n_obs, float* workspace,
+                                          float* dw1, float* db1, float* dw2, float* db2,
+                                          parlhip_stream_t stream);
 
 /* examples/A2C/atari_model.py:21-104 (AtariModel trunk), first layer — the 84x84 -> 20x20
  * contraction: x = obs / 255; conv1 4->32 k8 s4 p1 + ReLU.  obs u8 [n,4,84,84], w1 f32

@@ -110,6 +110,7 @@ SIGNATURES = {
     'parlhip_atari84_conv1_bwd_f32': (_i, [_p, _p, _i, _p, _p, _p]),
     'parlhip_atari42_conv12_bwd_workspace_bytes': (_sz, [_i]),
     'parlhip_atari42_conv12_bwd_f32': (_i, [_p] * 6 + [_i] + [_p] * 6),
+    'parlhip_atari42_conv12_bwd_packed_f32': (_i, [_p] * 5 + [_i] + [_p] * 6),
     'parlhip_vecnorm_obs_f64': (_i, [_p] * 7 + [_i, _i, _d, _d, _i, _p]),
     'parlhip_vecnorm_reward_f64': (_i, [_p] * 8 + [_i, _d, _d, _d, _p]),
     'parlhip_ppo_sample_batch_f32': (_i, [_p] * 13 + [_i64, _i64, _i, _i, _p]),

@@ -107,16 +107,30 @@ struct RingObs {
 
 // Operand-order copy of the two weight matrices (parlhip_atari42_conv12_weights_f32): register r of lane
 // (q = lane >> 4, col = lane & 15) is bw1[r] for r < 16 and bw2[(r - 16) >> 1][(r - 16) & 1] after it; four registers
-// per float4, [36][64] float4s — a wave reads its 144 operands with 36 fully coalesced 1 KB loads.  From the
+// per float4, [36][64] float4s (the FORWARD region) — a wave reads its 144 operands with 36 fully coalesced 1 KB loads.  From the
 // nn.Conv2d layout the same operands are 144 dword loads that touch 16 cache lines each (sixteen weight rows 1 KB
 // apart): measured as THE start-up cost of a workgroup — 29 of the 67 us of the actors' 1024-observation launch
 // (tools/conv12_scaling.py with -DPARLHIP_CONV12_ABL=1: 20.0 / 34.6 us for nothing but the weight fetch at 256 /
 // 512 workgroups), the vector L1's tag rate, not bytes.
-constexpr int kPackedRegs = 16 + 128, kPackedFloats = kPackedRegs * 64;   // 9,216 floats = 36,864 B
+// A second region behind it serves the backward kernel (conv12_bwd_u8_mfma_kernel, step (3)): for wave w (parity class
+// py = w >> 1, px = w & 1) and lane (q, col) (ta = q >> 1, tb = q & 1) register o of bt[32] is
+// w2[o][col][py + 2 ta][px + 2 tb]: [4 waves][8][64] float4s, every element of w2 exactly once.  (Its bw1 is the
+// forward region's first 16 registers.)
+constexpr int kPackedRegs = 16 + 128, kPackedFwdFloats = kPackedRegs * 64;   // 9,216 floats
+constexpr int kPackedBwdFloats = 4 * 32 * 64;                                // 8,192 floats
+constexpr int kPackedFloats = kPackedFwdFloats + kPackedBwdFloats;           // 17,408 floats = 69,632 B
 __global__ __launch_bounds__(256) void conv12_weights_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
                                                                   float* __restrict__ packed) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= kPackedFloats) return;
+  if (i >= kPackedFwdFloats) {
+    const int j = i - kPackedFwdFloats;
+    const int w = j >> 11, o = (j >> 6) & 31, lane = j & 63, q = lane >> 4, col = lane & 15;
+    const int py = w >> 1, px = w & 1, ta = q >> 1, tb = q & 1;
+    packed[kPackedFwdFloats + ((((w * 8 + (o >> 2)) * 64 + lane) << 2) + (o & 3))] =
+        w2[o * kK2 + col * 16 + (py + 2 * ta) * 4 + (px + 2 * tb)];
+    return;
+  }
   const int r = i >> 6, lane = i & 63, q = lane >> 4, col = lane & 15;
   float v;
   if (r < 16) {
@@ -327,6 +341,7 @@ constexpr int kBwdPartial = 1040 + 8192 + 32;            // 9264 floats per work
 constexpr int kLdsBwdU8 = 4 * kP1 * kP1;                                   // 7,744 bytes = 1,936 floats
 constexpr int kLdsBwdFloats = kLdsBwdU8 / 4 + 256 + kLdsC1 + 32 * kZ2 + 384;  // 17,568 floats = 70,272 B
 
+template <bool PACKED>   // PACKED: `w1` is parlhip_atari42_conv12_weights_f32's buffer (operand order), w2 unused
 __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
     const uint8_t* __restrict__ obs, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ a2, const float* __restrict__ dy,
@@ -340,14 +355,29 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, col = lane & 15;
   float bw1[16];
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) bw1[ks] = w1[col * kK1 + ks * 4 + q];
   const float bias1 = b1[col];
   // (3): this wave's parity class and its B operand  B[k = (o, a, b)][n = c] = w2[o][c][py+2a][px+2b]
   const int py = wave >> 1, px = wave & 1, ta = q >> 1, tb = q & 1;
   float bt[32];
+  if constexpr (PACKED) {   // 4 + 8 coalesced float4 loads instead of 48 dword loads over 16 cache lines each
+    const float4* pk = reinterpret_cast<const float4*>(w1) + lane;
 #pragma unroll
-  for (int o = 0; o < 32; ++o) bt[o] = w2[o * kK2 + col * 16 + (py + 2 * ta) * 4 + (px + 2 * tb)];
+    for (int g = 0; g < 4; ++g) {
+      const float4 v = pk[g * 64];
+      bw1[4 * g] = v.x; bw1[4 * g + 1] = v.y; bw1[4 * g + 2] = v.z; bw1[4 * g + 3] = v.w;
+    }
+    const float4* pb = reinterpret_cast<const float4*>(w1 + kPackedFwdFloats) + wave * 8 * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const float4 v = pb[g * 64];
+      bt[4 * g] = v.x; bt[4 * g + 1] = v.y; bt[4 * g + 2] = v.z; bt[4 * g + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) bw1[ks] = w1[col * kK1 + ks * 4 + q];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) bt[o] = w2[o * kK2 + col * 16 + (py + 2 * ta) * 4 + (px + 2 * tb)];
+  }
   f32x4 acc2[2][4], acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -1426,7 +1456,7 @@ PARLHIP_EXPORT int parlhip_atari42_conv12_weights_f32(const float* w1, const flo
                                                       parlhip_stream_t stream) {
   if (!w1 || !w2 || !packed_out) return PARLHIP_EINVAL;
   if (reinterpret_cast<uintptr_t>(packed_out) & 15) return PARLHIP_EINVAL;
-  conv12_weights_pack_kernel<<<kPackedFloats / 256, 256, 0, (hipStream_t)stream>>>(w1, w2, packed_out);
+  conv12_weights_pack_kernel<<<(kPackedFloats + 255) / 256, 256, 0, (hipStream_t)stream>>>(w1, w2, packed_out);
   return check_launch();
 }
 
@@ -1527,13 +1557,11 @@ PARLHIP_EXPORT size_t parlhip_atari42_conv12_bwd_workspace_bytes(int n_obs) {
   return n_obs <= 0 ? 0 : (size_t)conv12_bwd_grid(n_obs) * kBwdPartial * sizeof(float);
 }
 
-PARLHIP_EXPORT int parlhip_atari42_conv12_bwd_f32(const uint8_t* obs, const float* w1, const float* b1,
-                                                  const float* w2, const float* a2, const float* dy, int n_obs,
-                                                  float* workspace, float* dw1, float* db1, float* dw2, float* db2,
-                                                  parlhip_stream_t stream) {
+static int launch_conv12_bwd(const uint8_t* obs, const float* w1_or_packed, const float* b1, const float* w2,
+                             const float* a2, const float* dy, int n_obs, float* workspace, float* dw1, float* db1,
+                             float* dw2, float* db2, bool packed, hipStream_t s) {
   if (n_obs < 0) return PARLHIP_EINVAL;
   if (!dw1 || !db1 || !dw2 || !db2) return PARLHIP_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
   if (n_obs == 0) {
     int rc = check(hipMemsetAsync(dw1, 0, 1024 * 4, s));
     if (!rc) rc = check(hipMemsetAsync(db1, 0, 16 * 4, s));
@@ -1541,21 +1569,41 @@ PARLHIP_EXPORT int parlhip_atari42_conv12_bwd_f32(const uint8_t* obs, const floa
     if (!rc) rc = check(hipMemsetAsync(db2, 0, 32 * 4, s));
     return rc;
   }
-  if (!obs || !w1 || !b1 || !w2 || !a2 || !dy || !workspace) return PARLHIP_EINVAL;
+  if (!obs || !w1_or_packed || !b1 || (!packed && !w2) || !a2 || !dy || !workspace) return PARLHIP_EINVAL;
+  if (packed && (reinterpret_cast<uintptr_t>(w1_or_packed) & 15)) return PARLHIP_EINVAL;
   static bool attr_set = false;
   const size_t lds_bytes = kLdsBwdFloats * sizeof(float);
   if (!attr_set) {
-    int rc = check(hipFuncSetAttribute((const void*)conv12_bwd_u8_mfma_kernel,
+    int rc = check(hipFuncSetAttribute((const void*)conv12_bwd_u8_mfma_kernel<false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (rc) return rc;
+    rc = check(hipFuncSetAttribute((const void*)conv12_bwd_u8_mfma_kernel<true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     if (rc) return rc;
     attr_set = true;
   }
   const int grid = conv12_bwd_grid(n_obs);
-  conv12_bwd_u8_mfma_kernel<<<grid, 256, lds_bytes, s>>>(obs, w1, b1, w2, a2, dy, workspace, n_obs);
+  if (packed) conv12_bwd_u8_mfma_kernel<true><<<grid, 256, lds_bytes, s>>>(obs, w1_or_packed, b1, nullptr, a2, dy, workspace, n_obs);
+  else conv12_bwd_u8_mfma_kernel<false><<<grid, 256, lds_bytes, s>>>(obs, w1_or_packed, b1, w2, a2, dy, workspace, n_obs);
   int rc = check_launch();
   if (rc) return rc;
   conv12_bwd_reduce_kernel<<<(kBwdPartial + 15) / 16, 256, 0, s>>>(workspace, grid, dw1, db1, dw2, db2);
   return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_atari42_conv12_bwd_f32(const uint8_t* obs, const float* w1, const float* b1,
+                                                  const float* w2, const float* a2, const float* dy, int n_obs,
+                                                  float* workspace, float* dw1, float* db1, float* dw2, float* db2,
+                                                  parlhip_stream_t stream) {
+  return launch_conv12_bwd(obs, w1, b1, w2, a2, dy, n_obs, workspace, dw1, db1, dw2, db2, false, (hipStream_t)stream);
+}
+
+PARLHIP_EXPORT int parlhip_atari42_conv12_bwd_packed_f32(const uint8_t* obs, const float* packed, const float* b1,
+                                                         const float* a2, const float* dy, int n_obs,
+                                                         float* workspace, float* dw1, float* db1, float* dw2,
+                                                         float* db2, parlhip_stream_t stream) {
+  return launch_conv12_bwd(obs, packed, b1, nullptr, a2, dy, n_obs, workspace, dw1, db1, dw2, db2, true,
+                           (hipStream_t)stream);
 }
 
 PARLHIP_EXPORT int parlhip_atari84_conv23_f32(const float* a1, const float* wt2, const float* b2, const float* wt3,

@@ -106,7 +106,7 @@ class AtariModel42(Model):
     def _packed_weights(self, force=False):
         w1, w2 = self.conv1.weight, self.conv2.weight
         if self._wpk is None or self._wpk.device != w1.device:
-            self._wpk, self._wpk_key = torch.empty((36, 64, 4), dtype=torch.float32, device=w1.device), None
+            self._wpk, self._wpk_key = ops.atari42_conv12_pack(w1, w2), None
         key = (w1._version, w2._version, w1.data_ptr(), w2.data_ptr())
         written = getattr(w1, '_parl_graph_written', False) or getattr(w2, '_parl_graph_written', False)
         if force or written or key != self._wpk_key:   # (parameters a graph replay / raw-pointer optimizer writes: never trusted)

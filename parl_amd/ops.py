@@ -447,15 +447,17 @@ class RingObservation(object):
 
 def atari42_conv12_pack(conv1_weight, conv2_weight, out=None):
     """The two weight matrices of atari42_conv12 in the kernel's operand order (parlhip_atari42_conv12_weights_f32):
-    f32 [36, 64, 4].  A workgroup then fetches its operands with 36 coalesced loads instead of 144 scattered ones —
-    half of the actors' 1024-observation launch was that fetch.  Rebuild when the weights change."""
+    flat f32 [17,408] — the forward kernel's [36][64] float4s, then the backward kernel's [4][8][64].  A workgroup then
+    fetches its operands with 36 (backward: 12) coalesced loads instead of 144 (48) scattered ones — half of the
+    actors' 1024-observation launch was that fetch.  Rebuild when the weights change."""
     if tuple(conv1_weight.shape) != (16, 4, 4, 4) or tuple(conv2_weight.shape) != (32, 16, 4, 4):
         raise N.ParlHipError('atari42_conv12_pack: weights must be [16,4,4,4] and [32,16,4,4]')
     w1, w2 = _f32(conv1_weight.detach(), 'conv1_weight'), _f32(conv2_weight.detach(), 'conv2_weight')
+    n = N.lib().parlhip_atari42_conv12_weights_bytes() // 4
     if out is None:
-        out = torch.empty((36, 64, 4), dtype=torch.float32, device=w1.device)
-    elif out.dtype != torch.float32 or out.numel() != 36 * 64 * 4 or not out.is_contiguous():
-        raise N.ParlHipError('atari42_conv12_pack: out must be contiguous f32 [36,64,4]')
+        out = torch.empty(n, dtype=torch.float32, device=w1.device)
+    elif out.dtype != torch.float32 or out.numel() != n or not out.is_contiguous():
+        raise N.ParlHipError('atari42_conv12_pack: out must be contiguous f32 [%d]' % n)
     N.check(N.lib().parlhip_atari42_conv12_weights_f32(N.ptr(w1), N.ptr(w2), N.ptr(out), N.stream_ptr()),
             'parlhip_atari42_conv12_weights_f32')
     return out
@@ -468,8 +470,9 @@ def atari42_conv12(obs, conv1_weight, conv1_bias, conv2_weight, conv2_bias, out=
     packed: atari42_conv12_pack(conv1_weight, conv2_weight) of the CURRENT weights (same result, faster start)."""
     if tuple(conv1_weight.shape) != (16, 4, 4, 4) or tuple(conv2_weight.shape) != (32, 16, 4, 4):
         raise N.ParlHipError('atari42_conv12: weights must be [16,4,4,4] and [32,16,4,4]')
-    if packed is not None and (packed.dtype != torch.float32 or packed.numel() != 36 * 64 * 4 or not packed.is_contiguous()):
-        raise N.ParlHipError('atari42_conv12: packed must be atari42_conv12_pack\'s f32 [36,64,4]')
+    if packed is not None and (packed.dtype != torch.float32 or not packed.is_contiguous() or
+                               packed.numel() * 4 != N.lib().parlhip_atari42_conv12_weights_bytes()):
+        raise N.ParlHipError('atari42_conv12: packed must be atari42_conv12_pack\'s buffer')
     b1, b2 = _f32(conv1_bias.detach(), 'conv1_bias'), _f32(conv2_bias.detach(), 'conv2_bias')
     if isinstance(obs, RingObservation):
         if obs.dim != 42:
@@ -508,7 +511,7 @@ def atari42_conv12(obs, conv1_weight, conv1_bias, conv2_weight, conv2_bias, out=
     return out
 
 
-def atari42_conv12_backward(obs, conv1_weight, conv1_bias, conv2_weight, a2, grad_a2):
+def atari42_conv12_backward(obs, conv1_weight, conv1_bias, conv2_weight, a2, grad_a2, packed=None):
     """Gradient of atari42_conv12 w.r.t. its four parameters given its output a2 [n,3872] and
     d loss / d a2 (the learner side of examples/IMPALA/atari_model.py:59-71; the observations get
     no gradient).  conv1 is recomputed inside the kernel; deterministic.  Returns
@@ -528,6 +531,13 @@ def atari42_conv12_backward(obs, conv1_weight, conv1_bias, conv2_weight, a2, gra
     ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=dev)
     w1, b1 = _f32(conv1_weight.detach(), 'conv1_weight'), _f32(conv1_bias.detach(), 'conv1_bias')
     w2 = _f32(conv2_weight.detach(), 'conv2_weight')
+    if packed is not None:   # atari42_conv12_pack of the weights the forward ran with (they have not changed since)
+        N.check(
+            N.lib().parlhip_atari42_conv12_bwd_packed_f32(N.ptr(obs.contiguous()), N.ptr(packed), N.ptr(b1), N.ptr(a2),
+                                                         N.ptr(grad_a2), n, N.ptr(ws), N.ptr(dw1), N.ptr(db1),
+                                                         N.ptr(dw2), N.ptr(db2), N.stream_ptr()),
+            'parlhip_atari42_conv12_bwd_packed_f32')
+        return dw1, db1, dw2, db2
     N.check(
         N.lib().parlhip_atari42_conv12_bwd_f32(N.ptr(obs.contiguous()), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(a2),
                                               N.ptr(grad_a2), n, N.ptr(ws), N.ptr(dw1), N.ptr(db1), N.ptr(dw2),
@@ -543,14 +553,16 @@ class Atari42Conv12Fn(torch.autograd.Function):
     def forward(ctx, obs, w1, b1, w2, b2):
         # the learner's weights change with every update: the operand-order copy is made per call (one 9,216-thread
         # launch, also inside a captured update) — cheaper than fetching the operands scattered in every workgroup
-        a2 = atari42_conv12(obs, w1, b1, w2, b2, packed=atari42_conv12_pack(w1, w2) if obs.shape[0] >= 256 else None)
+        pk = atari42_conv12_pack(w1, w2) if obs.shape[0] >= 256 else None
+        a2 = atari42_conv12(obs, w1, b1, w2, b2, packed=pk)
         ctx.save_for_backward(obs, w1, b1, w2, a2)
+        ctx.packed = pk   # (not a saved tensor: an internal buffer nobody else writes)
         return a2
 
     @staticmethod
     def backward(ctx, grad_a2):
         obs, w1, b1, w2, a2 = ctx.saved_tensors
-        dw1, db1, dw2, db2 = atari42_conv12_backward(obs, w1, b1, w2, a2, grad_a2)
+        dw1, db1, dw2, db2 = atari42_conv12_backward(obs, w1, b1, w2, a2, grad_a2, packed=ctx.packed)
         return None, dw1, db1, dw2, db2
 
 

@@ -373,9 +373,17 @@ def test_conv12_packed_weights_give_identical_outputs(dev):
     w1, b1 = torch.randn(16, 4, 4, 4, device=dev) * 0.2, torch.randn(16, device=dev) * 0.1
     w2, b2 = torch.randn(32, 16, 4, 4, device=dev) * 0.1, torch.randn(32, device=dev) * 0.1
     pk = ops.atari42_conv12_pack(w1, w2)
-    assert tuple(pk.shape) == (36, 64, 4)
-    # every weight appears exactly once in the packed copy
-    assert torch.equal(torch.sort(pk.flatten()).values, torch.sort(torch.cat([w1.flatten(), w2.flatten()])).values)
+    assert pk.numel() == 36 * 64 * 4 + 4 * 8 * 64 * 4
+    # every weight appears exactly once in the forward region, every conv2 weight once more in the backward region
+    assert torch.equal(torch.sort(pk[:9216]).values, torch.sort(torch.cat([w1.flatten(), w2.flatten()])).values)
+    assert torch.equal(torch.sort(pk[9216:]).values, torch.sort(w2.flatten()).values)
+    for n in (3, 300, 1100):   # the backward with the operand-order weights: bit-identical gradients
+        obs = torch.randint(0, 256, (n, 4, 42, 42), dtype=torch.uint8, device=dev)
+        a2 = ops.atari42_conv12(obs, w1, b1, w2, b2)
+        dy = torch.randn_like(a2)
+        for x, y in zip(ops.atari42_conv12_backward(obs, w1, b1, w2, a2, dy),
+                        ops.atari42_conv12_backward(obs, w1, b1, w2, a2, dy, packed=pk)):
+            assert torch.equal(x, y)
     for n in (1, 3, 700, 1030):
         obs = torch.randint(0, 256, (n, 4, 42, 42), dtype=torch.uint8, device=dev)
         assert torch.equal(ops.atari42_conv12(obs, w1, b1, w2, b2), ops.atari42_conv12(obs, w1, b1, w2, b2, packed=pk))

@@ -37,6 +37,25 @@ if __name__ == '__main__':
         torch.cuda.synchronize()
         print('rollout %d: host enqueue %.1f ms (%.0f us/step), to completion %.1f ms (%.0f us/step)' %
               (rep, (t1 - t0) * 1e3, (t1 - t0) / T * 1e6, (t2 - t0) * 1e3, (t2 - t0) / T * 1e6))
+    # the rollout as ONE hipGraph (what AsyncActorLearner replays between weight refreshes), nothing beside it
+    if ro.can_graph(model):
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            ts = []
+            for rep in range(2 + 5):   # eager, capture, then replays
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ro.collect_begin()
+                a.record(side)
+                ro.collect_segment(model, 0, T, graph=True)
+                b.record(side)
+                ro.collect_end()
+                ts.append((a, b))
+            side.synchronize()
+            ms = sorted(a.elapsed_time(b) for a, b in ts[2:])
+            print('rollout as one hipGraph, alone: %.2f ms per %d steps (%.0f us/step, %.2f M frames/s)' %
+                  (ms[len(ms) // 2], T, ms[len(ms) // 2] / T * 1e3, 4 * T * E / ms[len(ms) // 2] / 1e3))
+        torch.cuda.current_stream(dev).wait_stream(side)
     # the chain without the emulator: forward + sample only
     obs = env.current_obs()
     logits = torch.zeros((E, env.act_dim), device=dev)

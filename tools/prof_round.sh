@@ -23,5 +23,6 @@ python tools/learner_bench.py --json $O/learner_bench.json > $O/learner_bench.lo
 (bash tools/learn84_prof.sh $O/learn84_kernels.txt 84 5120; bash tools/learn84_prof.sh $O/learn42_kernels.txt 42) > /dev/null 2>&1
 if [ -f build_exp/convreg.so ]; then PARL_HIP_LIB=$R/build_exp/convreg.so python tools/conv_regions.py 51200 2>&1 | grep -v amdgpu > $O/conv12_bwd_regions.log; fi
 python tools/ref_batch_probe.py 2>&1 | grep -v amdgpu | tail -5 > $O/ref_batch_probe.log
-timeout 230 python examples/A2C/train.py --log-interval 10 --minutes 3.2 2>&1 | grep -v amdgpu > $O/learn_a2c_pong_256envs_first_3min.log
+(python tools/conv12_scaling.py; python tools/conv84_scaling.py) 2>&1 | grep n_obs > $O/conv_scaling.log
+if [ "${PROF_A2C:-0}" == "1" ]; then timeout 230 python examples/A2C/train.py --log-interval 10 --minutes 3.2 2>&1 | grep -v amdgpu > $O/learn_a2c_pong_256envs_first_3min.log; fi
 ls $O
