@@ -270,7 +270,11 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
   const unsigned long long k0 = __builtin_readcyclecounter();
   for (int i = 0; i < 5; ++i) { emu.rt[i] = 0; emu.rn[i] = 0; }
 #endif
+#ifdef PARLHIP_ROM_SCALAR
+  emu.romw = (Emu::RomWords)romw_g;
+#else
   emu.romw = rom_lds;
+#endif
   emu.rom_mask = prm.rom_size - 1;
   emu.lane = lane;
   emu.rq = &rqs[slot];
