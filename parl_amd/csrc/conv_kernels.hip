@@ -280,9 +280,18 @@ __global__ __launch_bounds__(256, 2) void conv12_u8_mfma_kernel(
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 64; ++ks) {
+#if defined(PARLHIP_CONV12_ABL) && PARLHIP_CONV12_ABL == 6    // (diagnostic: conv2's MFMAs without its LDS gathers)
+        const float a = bias20 + (float)ks;
+#else
         const float a = a_base[(ks >> 2) * kP2 * kP2 + (ks & 3) * kP2];
+#endif
+#if defined(PARLHIP_CONV12_ABL) && PARLHIP_CONV12_ABL == 7    // (diagnostic: conv2's LDS gathers without its MFMAs)
+        acc0[0] += a * bw2[ks][0];
+        acc1[0] += a * bw2[ks][1];
+#else
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw2[ks][0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw2[ks][1], acc1, 0, 0, 0);
+#endif
       }
       // the order of the block for the scheduler (ds_read2: two operands per instruction): 8 operands, then seven times
       // [the next 8 | the 16 MFMAs of the 8 before them], then the last 16 MFMAs — 16 operand registers in flight
@@ -297,6 +306,9 @@ __global__ __launch_bounds__(256, 2) void conv12_u8_mfma_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int mo = mt * 16 + q * 4 + r;
+#ifdef PARLHIP_CONV12_ABL
+        if (PARLHIP_CONV12_ABL == 5 && acc0[r] != 123.456f) continue;   // (diagnostic: everything but the output stores)
+#endif
         if (mo < kM2) {
           const float v0 = acc0[r] + bias20, v1 = acc1[r] + bias21;
           dst[col * kM2 + mo] = v0 > 0.f ? v0 : 0.f;

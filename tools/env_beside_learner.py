@@ -76,6 +76,9 @@ def run(name, fn, steps=40):
            '' if (fn is None or busy) else '   [the other stream ran dry before the env steps ended]'))
 
 
+only = os.environ.get('ENV_BESIDE_ONLY')
+if only:
+    KERNELS = {k: v for k, v in KERNELS.items() if k == 'nothing' or only in k}
 with torch.no_grad():
     for k, f in KERNELS.items():
         if f is not None:
