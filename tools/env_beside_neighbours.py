@@ -24,13 +24,13 @@ env.roll()
 sink = torch.zeros(1024, device=dev)
 sa, sb = torch.cuda.Stream(priority=-1), torch.cuda.Stream()
 NAMES = {0: 'LDS reads (ds_read2 gathers, no MFMA)', 1: 'MFMA chains (no LDS reads)', 2: 'VALU FMAs', 3: 'resident and asleep (LDS + registers held)',
-         4: 'VALU FMAs over 200 live VGPRs', 5: '200 VGPRs held, asleep'}
+         4: 'VALU FMAs over 200 live VGPRs', 5: '200 VGPRs held, asleep', 6: '16 KB of straight-line VALU code', 7: '48 KB of straight-line VALU code'}
 
 
 def run(mode, grid=512, steps=40):
     torch.cuda.synchronize()
     if mode is not None:
-        iters = {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30}[mode]
+        iters = {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2}[mode]
         for _ in range(300):   # ~30-100 us each: like the learner's kernels
             nb.neighbour_launch(mode, sink.data_ptr(), iters, grid, sb.cuda_stream)
     with torch.cuda.stream(sa):
@@ -53,19 +53,19 @@ def run(mode, grid=512, steps=40):
 
 
 # one neighbour launch alone, for scale
-for m in range(6):
+for m in range(8):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    nb.neighbour_launch(m, sink.data_ptr(), {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30}[m], 512, sb.cuda_stream)
+    nb.neighbour_launch(m, sink.data_ptr(), {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2}[m], 512, sb.cuda_stream)
     torch.cuda.synchronize()
     with torch.cuda.stream(sb):
         a.record()
-    nb.neighbour_launch(m, sink.data_ptr(), {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30}[m], 512, sb.cuda_stream)
+    nb.neighbour_launch(m, sink.data_ptr(), {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2}[m], 512, sb.cuda_stream)
     with torch.cuda.stream(sb):
         b.record()
     torch.cuda.synchronize()
     print('neighbour %d (%s): one launch %.0f us' % (m, NAMES[m], a.elapsed_time(b) * 1e3))
 run(None)
-for m in range(6):
+for m in range(8):
     run(m)
 run(0, grid=256)
 run(1, grid=256)

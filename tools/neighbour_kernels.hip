@@ -41,6 +41,18 @@ __global__ __launch_bounds__(256, 2) void neighbour_kernel(float* sink, int iter
 #pragma unroll
       for (int k = 0; k < 32; ++k) { x = __builtin_fmaf(x, y, 0.5f); acc = __builtin_fmaf(acc, y, x); }
     }
+  } else if (MODE == 6) {   // 16 KB of straight-line code per pass (2,000 8-byte VALU instructions), four waves at different offsets
+    float x = (float)lane;
+    for (int i = 0; i < iters; ++i) {
+      asm volatile(".rept 2000\n v_fma_f32 %0, %0, 1.0, 0.5\n .endr" : "+v"(x));
+    }
+    acc = x;
+  } else if (MODE == 7) {   // 48 KB of straight-line code per pass
+    float x = (float)lane;
+    for (int i = 0; i < iters; ++i) {
+      asm volatile(".rept 6000\n v_fma_f32 %0, %0, 1.0, 0.5\n .endr" : "+v"(x));
+    }
+    acc = x;
   } else if (MODE == 4) {   // VALU FMAs over ~200 live registers (the conv kernels' register footprint, nothing else of them)
     float r[200];
 #pragma unroll
@@ -80,6 +92,8 @@ extern "C" int neighbour_launch(int mode, float* sink, int iters, int grid, void
     hipFuncSetAttribute((const void*)neighbour_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)neighbour_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)neighbour_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     set = true;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -88,6 +102,8 @@ extern "C" int neighbour_launch(int mode, float* sink, int iters, int grid, void
   else if (mode == 2) neighbour_kernel<2><<<grid, 256, lds, s>>>(sink, iters);
   else if (mode == 4) neighbour_kernel<4><<<grid, 256, lds, s>>>(sink, iters);
   else if (mode == 5) neighbour_kernel<5><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 6) neighbour_kernel<6><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 7) neighbour_kernel<7><<<grid, 256, lds, s>>>(sink, iters);
   else neighbour_kernel<3><<<grid, 256, lds, s>>>(sink, iters);
   return (int)hipGetLastError();
 }
