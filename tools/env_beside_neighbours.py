@@ -23,14 +23,24 @@ for _ in range(30):
 env.roll()
 sink = torch.zeros(1024, device=dev)
 sa, sb = torch.cuda.Stream(priority=-1), torch.cuda.Stream()
+def sc_busy():
+    return 'sc' in globals() and not sc.query()
+
+
 NAMES = {0: 'LDS reads (ds_read2 gathers, no MFMA)', 1: 'MFMA chains (no LDS reads)', 2: 'VALU FMAs', 3: 'resident and asleep (LDS + registers held)',
-         4: 'VALU FMAs over 200 live VGPRs', 5: '200 VGPRs held, asleep', 6: '16 KB of straight-line VALU code', 7: '48 KB of straight-line VALU code'}
+         4: 'VALU FMAs over 200 live VGPRs', 5: '200 VGPRs held, asleep', 6: '16 KB of straight-line VALU code', 7: '48 KB of straight-line VALU code', 8: 'LDS gather + 2 MFMAs per step, 64 operand registers, noisy data',
+         9: 'as 8 without the LDS gather in the loop', 10: 'as 8 with quiet data (all ones)', 11: 'as 8 with one operand register pair',
+         12: 'LDS gather + 2 VALU FMAs per step (no MFMA)', 13: 'LDS gathers and MFMAs interleaved, independent',
+         14: 'as 8, the gather two steps ahead of its MFMAs', 15: 'as 8, gathered value through v_mov_b32 first',
+         16: 'as 8, gathered value through v_add_f32 0 first', 17: 'sparse MFMAs, no LDS: s_sleep between pairs',
+         18: 'sparse MFMAs, no LDS: a VALU chain between pairs', 19: 'MFMAs in bursts of 16 with long sleeps, no LDS'}
 
 
 def run(mode, grid=512, steps=40):
-    torch.cuda.synchronize()
+    if not sc_busy():
+        torch.cuda.synchronize()
     if mode is not None:
-        iters = {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2}[mode]
+        iters = {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2, 8: 60, 9: 60, 10: 60, 11: 60, 12: 60, 13: 60, 14: 60, 15: 60, 16: 60, 17: 60, 18: 60, 19: 60}[mode]
         for _ in range(300):   # ~30-100 us each: like the learner's kernels
             nb.neighbour_launch(mode, sink.data_ptr(), iters, grid, sb.cuda_stream)
     with torch.cuda.stream(sa):
@@ -53,19 +63,36 @@ def run(mode, grid=512, steps=40):
 
 
 # one neighbour launch alone, for scale
-for m in range(8):
+for m in range(20):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    nb.neighbour_launch(m, sink.data_ptr(), {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2}[m], 512, sb.cuda_stream)
+    nb.neighbour_launch(m, sink.data_ptr(), {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2, 8: 60, 9: 60, 10: 60, 11: 60, 12: 60, 13: 60, 14: 60, 15: 60, 16: 60, 17: 60, 18: 60, 19: 60}[m], 512, sb.cuda_stream)
     torch.cuda.synchronize()
     with torch.cuda.stream(sb):
         a.record()
-    nb.neighbour_launch(m, sink.data_ptr(), {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2}[m], 512, sb.cuda_stream)
+    nb.neighbour_launch(m, sink.data_ptr(), {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2, 8: 60, 9: 60, 10: 60, 11: 60, 12: 60, 13: 60, 14: 60, 15: 60, 16: 60, 17: 60, 18: 60, 19: 60}[m], 512, sb.cuda_stream)
     with torch.cuda.stream(sb):
         b.record()
     torch.cuda.synchronize()
     print('neighbour %d (%s): one launch %.0f us' % (m, NAMES[m], a.elapsed_time(b) * 1e3))
 run(None)
-for m in range(8):
+for m in range(20):
     run(m)
 run(0, grid=256)
 run(1, grid=256)
+
+# a "heater": dense MFMAs on a THIRD stream (one workgroup per CU) beside the sparse-MFMA neighbour — does a matrix pipe that
+# never goes idle take the stretch away?
+sc = torch.cuda.Stream()
+
+
+def run_heated(mode, heater_iters=120000):
+    torch.cuda.synchronize()
+    nb.neighbour_launch(1, sink.data_ptr(), heater_iters, 256, sc.cuda_stream)
+    run(mode)
+
+
+if os.environ.get('HEATER'):
+    print('--- with a dense-MFMA heater kernel (grid 256) on a third stream')
+    run_heated(None)
+    run_heated(17)
+    run_heated(8)
