@@ -207,6 +207,12 @@ int parlhip_policy_sample_f32(const float* logits_or_probs, int is_logits,
                               int64_t* actions, float* probs_out,
                               double* uniforms_out, int B, int A, uint64_t seed,
                               uint64_t offset, uint64_t row0, parlhip_stream_t stream);
+/* The same with the Philox offset = offset + *offset_base, offset_base a uint64 in device memory: a rollout replayed
+ * as a hipGraph (frozen kernel arguments) keeps the number of its first step there.                        */
+int parlhip_policy_sample_at_f32(const float* x, int is_logits, int64_t* actions, float* probs_out,
+                                 double* uniforms_out, int B, int A, uint64_t seed,
+                                 const uint64_t* offset_base, uint64_t offset, uint64_t row0,
+                                 parlhip_stream_t stream);
 
 /* The actors' policy head and the draw in ONE launch: logits = hidden [B,256] @ w_policy^T [A,256] + b_policy
  * (examples/IMPALA/atari_model.py:44-57,73-79) written to logits_out [B,A] (a rollout slab), then the action

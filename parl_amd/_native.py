@@ -59,6 +59,8 @@ SIGNATURES = {
     'parlhip_policy_head_sample_at_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _u64, _p, _u64, _u64, _p]),
     'parlhip_policy_sample_f32':
     (_i, [_p, _i, _p, _p, _p, _i, _i, _u64, _u64, _u64, _p]),
+    'parlhip_policy_sample_at_f32':
+    (_i, [_p, _i, _p, _p, _p, _i, _i, _u64, _p, _u64, _u64, _p]),
     'parlhip_frame_post_tables_bytes': (_sz, [_i]),
     'parlhip_frame_post_tables_init': (_i, [_p, _i]),
     'parlhip_frame_post_u8': (_i, [_p, _p, _i64, _i, _p, _p, _i64, _i, _i, _p, _p]),

@@ -35,9 +35,10 @@ __global__ __launch_bounds__(256) void categorical_sample_kernel(
 __global__ __launch_bounds__(256) void policy_sample_kernel(
     const float* __restrict__ x, int is_logits, int64_t* __restrict__ actions,
     float* __restrict__ probs_out, double* __restrict__ uniforms_out, int B, int A,
-    uint64_t seed, uint64_t offset, uint64_t row0) {
+    uint64_t seed, uint64_t offset, uint64_t row0, const uint64_t* __restrict__ offset_base) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  if (offset_base) offset += *offset_base;   // the rollout's first step lives in device memory (hipGraph replays)
   const float* row = x + b * A;
   const double u = philox_uniform53(seed, offset, row0 + (uint64_t)b);
   if (uniforms_out) uniforms_out[b] = u;
@@ -216,17 +217,32 @@ PARLHIP_EXPORT int parlhip_policy_head_sample_at_f32(const float* hidden, const 
                                    row0, offset_base, stream);
 }
 
-PARLHIP_EXPORT int parlhip_policy_sample_f32(const float* x, int is_logits, int64_t* actions,
-                                         float* probs_out, double* uniforms_out, int B, int A,
-                                         uint64_t seed, uint64_t offset, uint64_t row0,
-                                         parlhip_stream_t stream) {
+static int launch_policy_sample(const float* x, int is_logits, int64_t* actions, float* probs_out, double* uniforms_out,
+                                int B, int A, uint64_t seed, uint64_t offset, uint64_t row0, const uint64_t* offset_base,
+                                parlhip_stream_t stream) {
   if (B < 0 || A < 1) return PARLHIP_EINVAL;
   if (B == 0) return PARLHIP_OK;
   if (!x || !actions) return PARLHIP_EINVAL;
   const int block = B >= 256 * 64 ? 256 : 64;
   policy_sample_kernel<<<ceil_div(B, block), block, 0, (hipStream_t)stream>>>(
-      x, is_logits, actions, probs_out, uniforms_out, B, A, seed, offset, row0);
+      x, is_logits, actions, probs_out, uniforms_out, B, A, seed, offset, row0, offset_base);
   return check_launch();
+}
+
+PARLHIP_EXPORT int parlhip_policy_sample_f32(const float* x, int is_logits, int64_t* actions,
+                                         float* probs_out, double* uniforms_out, int B, int A,
+                                         uint64_t seed, uint64_t offset, uint64_t row0,
+                                         parlhip_stream_t stream) {
+  return launch_policy_sample(x, is_logits, actions, probs_out, uniforms_out, B, A, seed, offset, row0, nullptr, stream);
+}
+
+PARLHIP_EXPORT int parlhip_policy_sample_at_f32(const float* x, int is_logits, int64_t* actions, float* probs_out,
+                                                double* uniforms_out, int B, int A, uint64_t seed,
+                                                const uint64_t* offset_base, uint64_t offset, uint64_t row0,
+                                                parlhip_stream_t stream) {
+  if (!offset_base) return PARLHIP_EINVAL;
+  return launch_policy_sample(x, is_logits, actions, probs_out, uniforms_out, B, A, seed, offset, row0, offset_base,
+                              stream);
 }
 
 PARLHIP_EXPORT size_t parlhip_adv_normalize_workspace_bytes(int64_t n) {

@@ -215,15 +215,47 @@ class AtariModel84(Model):
 
     reads_ring = True   # the actors' step may hand _trunk an ops.RingObservation (DeviceRollout / DeviceA2CRollout)
 
+    # The three convolutions' weights in MFMA operand order for the no-grad (actors' / bootstrap-value) path: ONE set of
+    # buffers at fixed addresses for the life of the model, so that a rollout captured as a hipGraph
+    # (DeviceA2CRollout) reads them; rebuilt when the parameters' version counters moved (an eager call), or by
+    # refresh_actor_layout() — which a graphed rollout calls INSIDE its graph, so every replay starts from the current
+    # weights — and while `_lay_pinned` is set nothing is checked.
+    _lay, _lay_key, _lay_pinned = None, None, False
+
+    def _actor_layouts(self, force=False):
+        ws = (self.conv1.weight, self.conv2.weight, self.conv3.weight)
+        if self._lay is None or self._lay[0].device != ws[0].device:
+            with torch.no_grad():
+                self._lay = (ops.atari84_conv1_layout(ws[0]), ) + tuple(ops.atari84_conv23_layouts(ws[1], ws[2]))
+            self._lay_key = None
+        if self._lay_pinned and not force:
+            return self._lay
+        key = tuple((w._version, w.data_ptr()) for w in ws)
+        written = any(getattr(w, '_parl_graph_written', False) for w in ws)
+        if force or written or key != self._lay_key:
+            with torch.no_grad():
+                self._lay[0].copy_(ops.atari84_conv1_layout(ws[0]))
+                wt2, wt3 = ops.atari84_conv23_layouts(ws[1], ws[2])
+                self._lay[1].copy_(wt2)
+                self._lay[2].copy_(wt3)
+            self._lay_key = key
+        return self._lay
+
+    def refresh_actor_layout(self):
+        if self.conv1.weight.is_cuda:
+            self._actor_layouts(force=True)
+
     def _trunk(self, obs):
         if isinstance(obs, ops.RingObservation) and (torch.is_grad_enabled() or obs.dim != 84 or obs.shape[0] == 0):
             obs = obs.materialize()
         if (not torch.is_grad_enabled()) and obs.dtype == torch.uint8 and obs.is_cuda and obs.shape[0] > 0:
             # the actors' / bootstrap-value path (no autograd): the 84x84 -> 20x20 contraction as one
             # MFMA kernel on the uint8 observations with /255, bias and ReLU fused (ops.atari84_conv1)
-            x = ops.atari84_conv1(obs, self.conv1.weight, self.conv1.bias)
+            wt1, wt2, wt3 = self._actor_layouts()
+            x = ops.atari84_conv1(obs, self.conv1.weight, self.conv1.bias, wt1=wt1)
             # conv2 + conv3 fused (a2 stays in LDS, weights streamed from L2 in MFMA operand order)
-            x = ops.atari84_conv23(x, self.conv2.weight, self.conv2.bias, self.conv3.weight, self.conv3.bias)
+            x = ops.atari84_conv23(x, self.conv2.weight, self.conv2.bias, self.conv3.weight, self.conv3.bias,
+                                   wt23=(wt2, wt3))
             return F.relu(self.fc(x))
         if obs.dtype == torch.uint8 and obs.is_cuda and obs.shape[0] > 0:
             # the learner's path: the same forward kernels under ONE autograd node whose backward is three

@@ -389,10 +389,19 @@ def policy_sample(logits_or_probs, seed, offset, row0=0, is_logits=True, want_pr
     return out if len(out) > 1 else actions
 
 
-def policy_sample_into(logits, actions_out, seed, offset, row0=0):
-    """policy_sample writing into a preallocated int64 [B] slab (rollout buffers)."""
+def policy_sample_into(logits, actions_out, seed, offset, row0=0, offset_base=None):
+    """policy_sample writing into a preallocated int64 [B] slab (rollout buffers).  offset_base: an int64 [1] device
+    tensor added to `offset` on the device (a rollout replayed as a hipGraph keeps the number of its first step there)."""
     x = _f32(logits, 'logits')
     B, A = x.shape
+    if offset_base is not None:
+        if offset_base.dtype != torch.int64 or offset_base.numel() != 1 or not offset_base.is_cuda:
+            raise N.ParlHipError('offset_base must be an int64 [1] device tensor')
+        N.check(
+            N.lib().parlhip_policy_sample_at_f32(
+                N.ptr(x), 1, N.ptr(actions_out), None, None, B, A, int(seed) & (2**64 - 1), N.ptr(offset_base),
+                int(offset) & (2**64 - 1), int(row0) & (2**64 - 1), N.stream_ptr()), 'parlhip_policy_sample_at_f32')
+        return actions_out
     N.check(
         N.lib().parlhip_policy_sample_f32(
             N.ptr(x), 1, N.ptr(actions_out), None, None, B, A, int(seed) & (2**64 - 1),
@@ -566,7 +575,7 @@ class Atari42Conv12Fn(torch.autograd.Function):
         return None, dw1, db1, dw2, db2
 
 
-def atari84_conv1(obs, conv1_weight, conv1_bias, out=None):
+def atari84_conv1(obs, conv1_weight, conv1_bias, out=None, wt1=None):
     """conv1 + ReLU of the A2C Atari network (examples/A2C/atari_model.py:21-104: 4->32 k8 s4 p1,
     84x84 -> 20x20) for uint8 observations [n,4,84,84] as one MFMA kernel with the /255 fused
     (inference only).  Returns f32 [n,32,20,20].  `obs` may be a RingObservation (the actors' step).
@@ -579,8 +588,11 @@ def atari84_conv1(obs, conv1_weight, conv1_bias, out=None):
     if not conv1_weight.is_cuda:
         N.ptr(conv1_weight)   # raises: no CPU path
     # (rebuilt when the tensor's version moved — every optimizer step for the learner, once per rollout for the actors —
-    # and always for parameters a graph replay writes)
-    wt1 = _cached_layout(conv1_weight, 'wt1', lambda w: _mfma_b_layout(_f32(w.detach(), 'conv1_weight').reshape(32, 256)))
+    # and always for parameters a graph replay writes; wt1: the caller's own operand-order copy of the CURRENT weights)
+    if wt1 is None:
+        wt1 = _cached_layout(conv1_weight, 'wt1', lambda w: atari84_conv1_layout(w))
+    elif wt1.dtype != torch.float32 or wt1.numel() != 64 * 2 * 64 or not wt1.is_contiguous():
+        raise N.ParlHipError('atari84_conv1: wt1 must be atari84_conv1_layout\'s buffer')
     if isinstance(obs, RingObservation):
         if obs.dim != 84:
             raise N.ParlHipError('atari84_conv1: an 84x84 ring')
@@ -647,7 +659,18 @@ def _cached_layout(w, kind, fn):
     return out
 
 
-def atari84_conv23(a1, conv2_weight, conv2_bias, conv3_weight, conv3_bias, save_a2=False):
+def atari84_conv1_layout(conv1_weight):
+    """conv1's weight matrix in MFMA operand order: f32 [64, 2, 4, 16] (= [ks][nt][lane])"""
+    return _mfma_b_layout(_f32(conv1_weight.detach(), 'conv1_weight').reshape(32, 256))
+
+
+def atari84_conv23_layouts(conv2_weight, conv3_weight):
+    """(wt2 f32 [128, 4, 4, 16], wt3 f32 [144, 4, 4, 16]): conv2 / conv3 weights in MFMA operand order ([ks][nt][lane])"""
+    return (_mfma_b_layout(_f32(conv2_weight.detach(), 'conv2_weight').reshape(64, 512)),
+            _mfma_b_layout(_f32(conv3_weight.detach(), 'conv3_weight').permute(0, 2, 3, 1).reshape(64, 576)))   # k' = (kh*3 + kw)*64 + c
+
+
+def atari84_conv23(a1, conv2_weight, conv2_bias, conv3_weight, conv3_bias, save_a2=False, wt23=None):
     """conv2 + ReLU + conv3 + ReLU of the A2C Atari network (examples/A2C/atari_model.py:21-104) fused
     in one MFMA kernel: a1 f32 [n,32,20,20] (atari84_conv1's output) -> a3 f32 [n,5184]; with
     save_a2 also the conv2 activation [n,64,11,11] (for the backward pass)."""
@@ -658,7 +681,11 @@ def atari84_conv23(a1, conv2_weight, conv2_bias, conv3_weight, conv3_bias, save_
     n = a1.shape[0]
     w2 = _f32(conv2_weight.detach(), 'conv2_weight')
     w3 = _f32(conv3_weight.detach(), 'conv3_weight')
-    if torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+    if wt23 is not None:   # the caller's own operand-order copies of the CURRENT weights (atari84_conv23_layouts)
+        wt2, wt3 = wt23
+        if wt2.numel() != 64 * 512 or wt3.numel() != 64 * 576 or not (wt2.is_contiguous() and wt3.is_contiguous()):
+            raise N.ParlHipError('atari84_conv23: wt23 must be atari84_conv23_layouts\' pair')
+    elif torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
         wt2 = _mfma_b_layout(w2.reshape(64, 512))
         wt3 = _mfma_b_layout(w3.permute(0, 2, 3, 1).reshape(64, 576))   # k' = (kh*3 + kw)*64 + c
     else:  # the actors: same weights for a whole rollout

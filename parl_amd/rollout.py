@@ -452,6 +452,39 @@ class DeviceA2CRollout(object):
         self.step_count = 0
         self.ep_stats = torch.zeros(3, dtype=torch.float64, device=dev)
         self.started = False
+        self.adv = torch.zeros((T, E), dtype=torch.float32, device=dev)
+        self.target = torch.zeros((T, E), dtype=torch.float32, device=dev)
+        self._step_base = torch.zeros(1, dtype=torch.int64, device=dev)   # number of the rollout's first step (hipGraph replays)
+        self._graphs, self._runs, self._side = {}, {}, None
+
+    def _steps(self, model, base=None):
+        """the T steps of a rollout, the bootstrap value forward, the GAE launch and the batch's observations; with
+        `base` (int64 [1] on the device = the number of the rollout's first step) the Philox offsets are
+        base + t — what a hipGraph of this body needs"""
+        env = self.env
+        ring = getattr(model, 'reads_ring', False)   # a trunk that reads the ring in place: one launch less per step
+        for t in range(self.T):
+            obs = env.current_obs_ref(self._obs_step) if ring else env.current_obs(self._obs_step)
+            logits, values = model.policy_and_value(obs)
+            self.values[t].copy_(values)
+            if base is not None:
+                ops.policy_sample_into(logits, self.actions[t], self.seed, t, env.env_id0, offset_base=base)
+            else:
+                ops.policy_sample_into(logits, self.actions[t], self.seed, self.step_count + t, env.env_id0)
+            env.step_async(self.actions[t], self.rewards[t], self.dones[t], ep_acc=self.ep_stats)
+        next_value = model.value(env.current_obs_ref(self._obs_step) if ring else env.current_obs(self._obs_step))  # ignored where the last step was terminal
+        adv, target = ops.gae(self.rewards, self.values, self.dones, next_value, self.gamma, self.lam)
+        self.adv.copy_(adv)
+        self.target.copy_(target)
+        env.gather(self._slots, self._envs, self.obs)
+
+    def _can_graph(self, model):
+        """the rollout as ONE hipGraph — opt-in (PARL_AMD_A2C_GRAPH=1): measured neutral on configs[1] (256 envs, T = 20:
+        984 k frames/s graphed, 998 k eager on one box — the host already runs ahead of a 0.8 ms env step), so eager
+        launches stay the default.  Needs a model that keeps its operand-order weight copies at fixed addresses and
+        refreshes them on request (AtariModel84) and a device env; identical batches (test_gpu_examples.py)"""
+        return bool(self.env.device.type == 'cuda' and hasattr(model, 'refresh_actor_layout') and
+                    hasattr(model, '_lay_pinned') and os.environ.get('PARL_AMD_A2C_GRAPH', '0') == '1')
 
     @torch.no_grad()
     def collect(self, model):
@@ -461,20 +494,40 @@ class DeviceA2CRollout(object):
             self.started = True
         else:
             env.roll()
-        ring = getattr(model, 'reads_ring', False)   # a trunk that reads the ring in place: one launch less per step
-        for t in range(self.T):
-            obs = env.current_obs_ref(self._obs_step) if ring else env.current_obs(self._obs_step)
-            logits, values = model.policy_and_value(obs)
-            self.values[t].copy_(values)
-            ops.policy_sample_into(logits, self.actions[t], self.seed, self.step_count, env.env_id0)
-            env.step_async(self.actions[t], self.rewards[t], self.dones[t], ep_acc=self.ep_stats)
-            self.step_count += 1
-        next_value = model.value(env.current_obs_ref(self._obs_step) if ring else env.current_obs(self._obs_step))  # ignored where the last step was terminal
-        adv, target = ops.gae(self.rewards, self.values, self.dones, next_value, self.gamma, self.lam)
-        env.gather(self._slots, self._envs, self.obs)
         n = self.T * env.envs_num
-        return {'obs': self.obs, 'actions': self.actions.reshape(n), 'advantages': adv.reshape(n),
-                'target_values': target.reshape(n)}
+        batch = {'obs': self.obs, 'actions': self.actions.reshape(n), 'advantages': self.adv.reshape(n),
+                 'target_values': self.target.reshape(n)}
+        key = id(model)
+        g = self._graphs.get(key) if self._can_graph(model) else None
+        runs = self._runs.get(key, 0)
+        self._runs[key] = runs + 1
+        if g is None and not (self._can_graph(model) and runs >= 1):
+            self._steps(model)           # the first rollout (libraries warm), or a model / env that cannot be graphed
+            self.step_count += self.T
+            return batch
+        cur = torch.cuda.current_stream(env.device)
+        if g is None:
+            # the second rollout is captured: every kernel argument of a rollout is a fixed address (ring slots, the
+            # [T,E] slabs, the model's parameters and its operand-order weight buffers) except the Philox offset
+            side = self._side = torch.cuda.Stream(device=env.device)
+            t0 = env.t
+            g = torch.cuda.CUDAGraph()
+            side.wait_stream(cur)
+            with torch.cuda.graph(g, stream=side):
+                model.refresh_actor_layout()     # inside the graph: every replay starts from the current weights
+                model._lay_pinned = True
+                try:
+                    self._steps(model, base=self._step_base)
+                finally:
+                    model._lay_pinned = False
+            cur.wait_stream(side)
+            env.t = t0                           # the capture enqueued nothing
+            self._graphs[key] = g
+        self._step_base.fill_(self.step_count)
+        g.replay()
+        env.t += self.T
+        self.step_count += self.T
+        return batch
 
     pop_episode_stats = DeviceRollout.pop_episode_stats
 

@@ -91,7 +91,40 @@ def test_a2c_rollout_matches_per_segment_calc_gae(dev, oracle):
     assert np.isfinite(float(total))
 
 
-def test_a2c_rollout_rows_are_aligned(dev):
+def test_a2c_rollout_as_one_graph_equals_eager_launches(dev, monkeypatch):
+    """DeviceA2CRollout replays a rollout as ONE hipGraph from its third call on (first eager, second captured):
+    the same batches as eager launches, rollout after rollout, also after the weights changed in between (the
+    model's operand-order weight buffers are refreshed inside the graph)"""
+    import parl_amd as parl
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel84
+    from parl_amd.rollout import DeviceA2CRollout
+    E, T = 10, 8
+    outs = []
+    for graph in (True, False):
+        monkeypatch.setenv('PARL_AMD_A2C_GRAPH', '1' if graph else '0')
+        torch.manual_seed(4)
+        env = DeviceVectorEnv('BreakoutNoFrameskip-v4', E, dim=84, horizon=T, seed=3, device=dev, max_episode_steps=700)
+        model = AtariModel84(env.act_dim).to(dev)
+        alg = parl.algorithms.A2C(model, vf_loss_coeff=0.5)
+        ro = DeviceA2CRollout(env, T, gamma=0.99, lam=0.95, seed=6)
+        assert ro._can_graph(model) == graph
+        got = []
+        for it in range(6):
+            b = ro.collect(model)
+            got.append({k: v.clone() for k, v in b.items()})
+            if it in (1, 3):   # an update between rollouts: new weights under the same graph
+                alg.learn(b['obs'], b['actions'], b['advantages'], b['target_values'], 3e-4, -0.01)
+        got.append({'ep': ro.ep_stats.clone(), 'values': ro.values.clone()})
+        assert (len(ro._graphs) == 1) == graph
+        env.check_faults()
+        outs.append(got)
+    for i, (a, b) in enumerate(zip(*outs)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (i, k)
+
+
+def test_a2c_rollout_rows_are_aligned(dev, monkeypatch):
     """Row (t, e) of the batch DeviceA2CRollout hands to A2C.learn carries the stacked observation the policy
     saw at step t for env e, the action drawn from THAT forward pass and the value it produced (the sums of
     a2c.py:67-79 do not care about the order of the rows, but they do care that a row's obs, action, advantage
@@ -101,6 +134,7 @@ def test_a2c_rollout_rows_are_aligned(dev):
     from parl_amd.env import DeviceVectorEnv
     from parl_amd.models import AtariModel84
     from parl_amd.rollout import DeviceA2CRollout
+    monkeypatch.setenv('PARL_AMD_A2C_GRAPH', '0')   # the recording below hooks the model call: eager launches
     torch.manual_seed(1)
     E, T = 6, 12
     env = DeviceVectorEnv('PongNoFrameskip-v4', E, dim=84, horizon=T, seed=7, device=dev)
