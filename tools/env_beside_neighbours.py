@@ -33,14 +33,15 @@ NAMES = {0: 'LDS reads (ds_read2 gathers, no MFMA)', 1: 'MFMA chains (no LDS rea
          12: 'LDS gather + 2 VALU FMAs per step (no MFMA)', 13: 'LDS gathers and MFMAs interleaved, independent',
          14: 'as 8, the gather two steps ahead of its MFMAs', 15: 'as 8, gathered value through v_mov_b32 first',
          16: 'as 8, gathered value through v_add_f32 0 first', 17: 'sparse MFMAs, no LDS: s_sleep between pairs',
-         18: 'sparse MFMAs, no LDS: a VALU chain between pairs', 19: 'MFMAs in bursts of 16 with long sleeps, no LDS'}
+         18: 'sparse MFMAs, no LDS: a VALU chain between pairs', 19: 'MFMAs in bursts of 16 with long sleeps, no LDS',
+         20: 'sparse 4x4x1 MFMAs (2 passes), s_sleep between pairs', 21: 'sparse 32x32x2 MFMAs (16 passes), s_sleep between pairs'}
 
 
 def run(mode, grid=512, steps=40):
     if not sc_busy():
         torch.cuda.synchronize()
     if mode is not None:
-        iters = {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2, 8: 60, 9: 60, 10: 60, 11: 60, 12: 60, 13: 60, 14: 60, 15: 60, 16: 60, 17: 60, 18: 60, 19: 60}[mode]
+        iters = {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2, 8: 60, 9: 60, 10: 60, 11: 60, 12: 60, 13: 60, 14: 60, 15: 60, 16: 60, 17: 60, 18: 60, 19: 60, 20: 60, 21: 60}[mode]
         for _ in range(300):   # ~30-100 us each: like the learner's kernels
             nb.neighbour_launch(mode, sink.data_ptr(), iters, grid, sb.cuda_stream)
     with torch.cuda.stream(sa):
@@ -63,19 +64,19 @@ def run(mode, grid=512, steps=40):
 
 
 # one neighbour launch alone, for scale
-for m in range(20):
+for m in range(22):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    nb.neighbour_launch(m, sink.data_ptr(), {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2, 8: 60, 9: 60, 10: 60, 11: 60, 12: 60, 13: 60, 14: 60, 15: 60, 16: 60, 17: 60, 18: 60, 19: 60}[m], 512, sb.cuda_stream)
+    nb.neighbour_launch(m, sink.data_ptr(), {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2, 8: 60, 9: 60, 10: 60, 11: 60, 12: 60, 13: 60, 14: 60, 15: 60, 16: 60, 17: 60, 18: 60, 19: 60, 20: 60, 21: 60}[m], 512, sb.cuda_stream)
     torch.cuda.synchronize()
     with torch.cuda.stream(sb):
         a.record()
-    nb.neighbour_launch(m, sink.data_ptr(), {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2, 8: 60, 9: 60, 10: 60, 11: 60, 12: 60, 13: 60, 14: 60, 15: 60, 16: 60, 17: 60, 18: 60, 19: 60}[m], 512, sb.cuda_stream)
+    nb.neighbour_launch(m, sink.data_ptr(), {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2, 8: 60, 9: 60, 10: 60, 11: 60, 12: 60, 13: 60, 14: 60, 15: 60, 16: 60, 17: 60, 18: 60, 19: 60, 20: 60, 21: 60}[m], 512, sb.cuda_stream)
     with torch.cuda.stream(sb):
         b.record()
     torch.cuda.synchronize()
     print('neighbour %d (%s): one launch %.0f us' % (m, NAMES[m], a.elapsed_time(b) * 1e3))
 run(None)
-for m in range(20):
+for m in range(22):
     run(m)
 run(0, grid=256)
 run(1, grid=256)

@@ -41,6 +41,24 @@ __global__ __launch_bounds__(256, 2) void neighbour_kernel(float* sink, int iter
 #pragma unroll
       for (int k = 0; k < 32; ++k) { x = __builtin_fmaf(x, y, 0.5f); acc = __builtin_fmaf(acc, y, x); }
     }
+  } else if (MODE == 20 || MODE == 21) {   // MODE 17 with other MFMA shapes: 20 v_mfma_f32_4x4x1 (2 passes), 21 v_mfma_f32_32x32x2 (16 passes)
+    const float a = (float)lane * 0.37f, b = 1.0f + lane;
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 d0 = {0.f}, d1 = {0.f};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        __builtin_amdgcn_s_sleep(2);
+        if (MODE == 20) {
+          c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(b, a, c1, 0, 0, 0);
+        } else {
+          d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, d1, 0, 0, 0);
+        }
+      }
+    }
+    acc = c0[0] + c1[1] + d0[0] + d1[5];
   } else if (MODE == 17 || MODE == 18 || MODE == 19) {   // SPARSE MFMAs without any LDS: 17 an s_sleep (~128 clocks) between pairs,
     const float a = (float)lane * 0.37f, b = 1.0f + lane;   // 18 a dependent VALU chain (~40 FMAs) between pairs, 19 bursts of 16 then a long sleep
     float x = a;
@@ -194,6 +212,8 @@ extern "C" int neighbour_launch(int mode, float* sink, int iters, int grid, void
     hipFuncSetAttribute((const void*)neighbour_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)neighbour_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)neighbour_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<21>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)neighbour_kernel<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)neighbour_kernel<18>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)neighbour_kernel<17>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -216,6 +236,8 @@ extern "C" int neighbour_launch(int mode, float* sink, int iters, int grid, void
   else if (mode == 6) neighbour_kernel<6><<<grid, 256, lds, s>>>(sink, iters);
   else if (mode == 7) neighbour_kernel<7><<<grid, 256, lds, s>>>(sink, iters);
   else if (mode == 8) neighbour_kernel<8><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 21) neighbour_kernel<21><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 20) neighbour_kernel<20><<<grid, 256, lds, s>>>(sink, iters);
   else if (mode == 19) neighbour_kernel<19><<<grid, 256, lds, s>>>(sink, iters);
   else if (mode == 18) neighbour_kernel<18><<<grid, 256, lds, s>>>(sink, iters);
   else if (mode == 17) neighbour_kernel<17><<<grid, 256, lds, s>>>(sink, iters);
