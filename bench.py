@@ -76,12 +76,14 @@ class KernelTimer(object):
         if not self.pairs:
             return None
         ts = sorted(s.elapsed_time(e) * 1e3 for s, e in self.pairs)
-        return {'n': len(ts), 'mean': sum(ts) / len(ts), 'median': ts[len(ts) // 2], 'min': ts[0], 'max': ts[-1]}
+        return {'n': len(ts), 'mean': sum(ts) / len(ts), 'median': ts[len(ts) // 2], 'p10': ts[len(ts) // 10],
+                'p90': ts[(len(ts) * 9) // 10], 'min': ts[0], 'max': ts[-1]}
 
 
 # SQ counters of atari_env_kernel<Pong> at E = 1024 (profiles/r05_env_pmc.log: the kernel with the policy head at its head
 # and the observation at its tail): active instructions per wave-clock of the two waves an env occupies
-ENV_PMC = {'issue_slot_utilisation': 80224.0 / 209577.0, 'instructions_per_frame': 80224,
+ENV_PMC = {'game': 'PongNoFrameskip-v4', 'envs': 1024, 'dim': 42,
+           'issue_slot_utilisation': 80224.0 / 209577.0, 'instructions_per_frame': 80224,
            'source': 'profiles/r05_env_pmc.log (rocprofv3 --pmc, tools/pmc_env.sh): SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES per '
                      'wave and emulated frame, both in 4-clock issue slots — a wave of this kernel issues in 38 % of its '
                      'slots, two such waves share a SIMD'}
@@ -104,7 +106,8 @@ def pmc_traffic(key):
 def kernel_only_profile(by):
     try:
         d = json.load(open(os.path.join(ROOT, 'profiles', 'r05_heads_loss_kernel_only.json')))
-        return {'us': d['avg_us'], 'frac': by / (d['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 'source': d['source']}
+        return {'us': d['avg_us'], 'frac': by / (d['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 'source': d['source'],
+                'measured_in_this_run': False}
     except (OSError, KeyError, ValueError):
         return None
 
@@ -194,6 +197,46 @@ def heads_loss_alone(dev, T, B, A, iters=40):
         return tm.mean_seconds(), tm.stats()
     finally:
         undo()
+
+
+def heads_loss_back_to_back(dev, T, B, A, n=50):
+    """the same launch pair with nothing between consecutive calls: the C-ABI entry is called `n` times in a row
+    on pre-allocated buffers (no Python wrapper, no allocation, no zero fill) between ONE pair of HIP events, so
+    the launch gaps of a single bracketed call drop out and what is left per call is the device time of
+    impala_heads_loss_q_kernel + heads_partial_sum_kernel — measured in this run, next to the rocprof
+    figure of the committed profile"""
+    from parl_amd import _native
+    g = torch.Generator(device=dev).manual_seed(1)
+    hd = torch.relu(torch.randn(T, B, 256, device=dev, generator=g))
+    hw = [torch.randn(A, 256, device=dev, generator=g) * 0.1, torch.zeros(A, device=dev),
+          torch.randn(1, 256, device=dev, generator=g) * 0.05, torch.zeros(1, device=dev)]
+    hb = [torch.randn(T, B, A, device=dev, generator=g), torch.randint(0, A, (T, B), device=dev, generator=g),
+          torch.randn(T, B, device=dev, generator=g), torch.rand(T, B, device=dev, generator=g) < 0.01]
+    lib, name, seen = _native.lib(), 'parlhip_impala_heads_loss_f32', []
+    orig = getattr(lib, name)
+
+    def record(*a):
+        seen.append(a)
+        return orig(*a)
+
+    setattr(lib, name, record)
+    try:
+        keep = ops.impala_heads_loss(hd, *hw, *hb, 0.99, 1.0, 1.0, 0.5, -0.01)   # (its outputs stay alive: `keep`)
+    finally:
+        setattr(lib, name, orig)
+    if not seen or keep is None:
+        return None
+    args = seen[0]
+    for _ in range(5):
+        orig(*args)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        orig(*args)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e-3 / n
 
 
 def one_update_leg(dev, E, T, dim, game, K, learn_rows, env_id0=0, warm=2):
@@ -291,6 +334,9 @@ def extra_legs(dev, only=None):
         by = T * E * 17
         return {'workload': 'BASELINE configs[1]: PongNoFrameskip-v4 A2C, 256 on-GPU envs, 84x84, T=20, lambda=1.0; '
                             'rollout then update (synchronous A2C), convolutions on the MFMA kernels',
+                'rollout_then_update_is_serial_by_contract': 'examples/A2C/train.py:82-94 pushes the new weights to every '
+                'actor before each sample and waits for all of them before the one learn(): the emulator idles during '
+                'the update (~4.5 of ~21 ms per iteration) by the algorithm, not by an omission of overlap',
                 'env_frames_per_s': K * T * E * 4 / dt, 'updates_per_s': K / dt, 'ms_per_step': dt / K * 1e3, 'steps': K,
                 'gae_kernel': {'shape': 'T=20 B=256 u8 dones', 'us': g * 1e6, 'bytes': by, 'GBps': by / g / 1e9,
                                'frac_of_hbm_peak': by / g / 1e9 / HBM_PEAK_GBPS,
@@ -694,8 +740,20 @@ def _main():
         wd.beat()
     pdist.barrier()
     torch.cuda.synchronize()
-    dt = pdist.all_reduce_max_scalar(time.time() - t0)
+    dt_local = time.time() - t0
+    dt = pdist.all_reduce_max_scalar(dt_local)
+    dt_ranks = pdist.all_gather_scalar(dt_local)
     wd.beat('after the timed steps')
+    # the gradient all-reduce by itself on the real bucket (every rank, same point of the program; gloo on shared
+    # GPUs is host-staged and only functional): what one update's exchange costs, for reading a scaling record
+    allreduce_us = None
+    if pdist.active() and alg.grad_hook is not None:
+        if pipe is not None:
+            pipe.synchronize()
+        allreduce_us = pdist.time_allreduce(alg.grad_hook, pipe.learn_stream if pipe is not None else None,
+                                            iters=30 if torch.distributed.get_backend() == 'nccl' else 5)
+        pdist.barrier()
+        wd.beat('after the all-reduce timing')
     wd.limit = max(wd.limit, 1200.0)  # the legs behind the headline (CPU baselines, profiles) have no collectives
     for e in envs:
         e.check_faults()
@@ -743,13 +801,23 @@ def _main():
                                                'per rollout and frame size; nothing calibrated at run time)',
             'env_ids_per_rank': [[r * E, r * E + E - 1] for r in range(world)],
             'process_group': pdist.describe(),
+            'dp_update_form': (None if not (graphed_mode and pdist.active()) else
+                               ('ONE hipGraph per update with the RCCL all-reduce captured inside (forward + backward | '
+                                'all-reduce | clip + Adam)'
+                                if all(g.allreduce_in_graph for g in pipe.graphed.values()) else
+                                'two hipGraphs per update with an eager all-reduce between them' +
+                                ''.join(' [capture of the collective failed: %s]' % g.allreduce_capture_error
+                                        for g in list(pipe.graphed.values())[:1] if g.allreduce_capture_error))),
             'collectives': (('none (single process)' if not pdist.active() else 'RCCL, one-rank group (PARL_AMD_FORCE_DIST)')
                             if world == 1 else
                             ('gloo, ranks SHARE GPUs (fewer devices than ranks: functional run, not a scaling number)'
                              if shared else 'RCCL: flat-gradient all-reduce + small-tensor all-gather per update')),
         },
-        'spread_note': 'the timed region is K x ~42 ms of graph replays; on the boxes of this pool the same command of the '
-                       'round\'s final code has given 4.8-4.9 M frames/s (round 4\'s code: 4.3-4.6 M; profiles/README.md)',
+        'timed_region_s': dt,
+        # per rank (index = rank): its own clock around the same K steps and the frames of ITS envs over it; `value`
+        # uses the slowest rank's clock
+        'per_rank': {'timed_region_s': dt_ranks, 'env_frames_per_s': [K * T * E * 4 / x for x in dt_ranks]},
+        'grad_allreduce_alone': allreduce_us,
         'learner_updates_per_sec': ((pipe.updates - updates0) if pipe is not None else K) / dt,
         'agent_steps_per_sec': K * T * E * world / dt,
     }
@@ -787,7 +855,9 @@ def _main():
         # (no collectives), the kernel bracketed by HIP events on the learner stream.
         del pipe, rollout, envs, env, model, alg, step
         torch.cuda.empty_cache()
-        one = one_update_leg(dev, E, T, dim, args.game, 20 if (world == 1 and not args.quick) else 5, args.learn_rows,
+        # (>= 100 in-pipeline launches of the V-trace loss kernel on the full line: its median / p10 / p90 are what
+        # `roofline.frac` is computed from; --quick and N > 1 keep the leg short)
+        one = one_update_leg(dev, E, T, dim, args.game, 100 if (world == 1 and not args.quick) else 5, args.learn_rows,
                              env_id0=rank * E)
         hl_in, hl_in_stats = one.pop('heads_loss_in_pipeline_s'), one.pop('heads_loss_in_pipeline_stats_us')
         torch.cuda.empty_cache()
@@ -802,6 +872,12 @@ def _main():
             alone, alone_stats = heads_loss_alone(dev, T, Bl, A)
             if hl_in is None:  # ranks sharing a GPU / elastic / --no-overlap: no one-update pipeline was run beside it
                 hl_in, hl_in_stats = alone, None
+            b2b = heads_loss_back_to_back(dev, T, Bl, A)
+            # the in-pipeline figure is the MEDIAN of the bracketed launches (>= 100 on the full line) with its spread;
+            # where the kernel was not run beside the actors (hl_in_stats is None) it is the stand-alone figure
+            t_in = (hl_in_stats['median'] * 1e-6) if hl_in_stats else hl_in
+            alone_med = alone_stats['median'] * 1e-6
+            fr = lambda t: by / t / 1e9 / HBM_PEAK_GBPS   # noqa: E731
             out['roofline'] = {
                 'kernel': 'impala_heads_loss_q_kernel (policy_fc + value_fc + log-softmax / entropy / KL + V-trace + loss '
                           'sums + gradient w.r.t. the trunk output and the heads, four waves per sequence, T=%d B=%d A=%d; '
@@ -809,15 +885,22 @@ def _main():
                           'heads_partial_sum_kernel)' % (T, Bl, A),
                 'bound': 'hbm', 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'bytes_per_launch': by,
                 # `frac` is the IN-PIPELINE figure: the kernel beside the actors' emulator / MFMA kernels, wherever in
-                # their step the two free-running streams happen to put it (no launch-phase tuning)
-                'achieved': by / hl_in / 1e9, 'frac': by / hl_in / 1e9 / HBM_PEAK_GBPS,
-                'frac_in_pipeline': (by / hl_in / 1e9 / HBM_PEAK_GBPS) if hl_in_stats else None, 'in_pipeline_us': hl_in_stats,
+                # their step the two free-running streams happen to put it (no launch-phase tuning): median of n launches
+                'achieved': by / t_in / 1e9, 'frac': fr(t_in),
+                'frac_in_pipeline': fr(t_in) if hl_in_stats else None,
+                'frac_in_pipeline_p10_p90': [fr(hl_in_stats['p90'] * 1e-6), fr(hl_in_stats['p10'] * 1e-6)] if hl_in_stats else None,
+                'frac_in_pipeline_of_the_mean': fr(hl_in) if hl_in_stats else None,
+                'in_pipeline_us': hl_in_stats,
+                'in_pipeline_over_alone': (hl_in_stats['median'] / alone_stats['median']) if hl_in_stats else None,
                 'in_pipeline_measured_in': ('impala_one_update leg (this process)' if one is not None else
                                             'the timed region' if hl_in_stats else
                                             'not measured in this configuration: frac is the stand-alone figure'),
-                'frac_alone': by / alone / 1e9 / HBM_PEAK_GBPS, 'achieved_alone': by / alone / 1e9, 'alone_us': alone_stats,
+                'frac_alone': fr(alone_med), 'achieved_alone': by / alone_med / 1e9, 'alone_us': alone_stats,
+                # per call with nothing between the calls (50 C-ABI calls between one event pair, measured in this run):
+                # the two kernels' device time without the launch gaps of a single bracketed call
+                'back_to_back_us': (b2b * 1e6) if b2b else None, 'frac_back_to_back': fr(b2b) if b2b else None,
                 # the main kernel by itself (rocprofv3 --kernel-trace --stats of the committed profile; bench.py cannot
-                # run under rocprof itself): the event-timed figures above add the partial-sum kernel and two launch gaps
+                # run under rocprof itself)
                 'kernel_only': kernel_only_profile(by) if (T, Bl, A) == (50, 1024, 6) else None,
                 'note': 'the V-trace scan at the WORKLOAD shape (T=50 x 1024 sequences), fused with the two heads so that '
                         'the 52 MB trunk output and its gradient cross HBM once each.  In the headline\'s learner mode '
@@ -885,9 +968,11 @@ def _main():
             'bound': 'instruction issue latency (one wave pair per env: 6507 on the scalar unit | picture)',
             'env_step_ms_event_timed': es * 1e3,
             'waves_per_simd': 2.0 * Eg / 1024,
-            'issue_slot_utilisation': ENV_PMC['issue_slot_utilisation'],
-            'instructions_per_wave_pair_and_frame': ENV_PMC['instructions_per_frame'],
-            'source': ENV_PMC['source'],
+            # SQ counters of a committed rocprofv3 --pmc run, quoted only for the configuration they were taken at
+            **({'issue_slot_utilisation': ENV_PMC['issue_slot_utilisation'],
+                'instructions_per_wave_pair_and_frame': ENV_PMC['instructions_per_frame'],
+                'source': ENV_PMC['source'], 'measured_in_this_run': False}
+               if (args.game, Eg, dim) == (ENV_PMC['game'], ENV_PMC['envs'], ENV_PMC['dim']) else {}),
             'observation_in_the_same_launch': fused_obs,
             'note': 'no HBM roofline fraction is quoted for this kernel; the event-timed call also contains frame_post',
         }

@@ -283,8 +283,20 @@ if __name__ == '__main__':
         from parl_amd import dist as pdist
         learner = PipelineLearner(config)
         t0 = t_log = time.time()
-        # every update holds a collective in a data-parallel run: all ranks stop in the same iteration (max over ranks)
-        while not pdist.all_reduce_max_scalar(float(args.minutes is not None and time.time() - t0 >= args.minutes * 60)):
+        # Every update holds a collective in a data-parallel run, so all ranks must stop in the SAME iteration: the
+        # stop flag is the max over ranks.  That all-reduce ends in a blocking .item() behind everything the rank
+        # has enqueued — taken every iteration it would drain the learner pass each step and remove the
+        # host-runs-ahead overlap of actors and learner — so it is taken every `stop_check_every`
+        # iterations (the ranks count iterations identically; one iteration is ~40 ms); a single process reads
+        # its own clock every iteration as before.
+        every = int(config.get('stop_check_every', 16)) if pdist.active() else 1
+        it = 0
+
+        def time_is_up():
+            return float(args.minutes is not None and time.time() - t0 >= args.minutes * 60)
+
+        while not (it % every == 0 and pdist.all_reduce_max_scalar(time_is_up())):
+            it += 1
             learner.step()
             if time.time() - t_log >= config['log_metrics_interval_s']:
                 learner.log_metrics()

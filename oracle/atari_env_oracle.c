@@ -44,6 +44,7 @@ typedef struct {
   int has_episode;                       /* MonitorEnv: _current_reward is not None */
   double cur_reward;
   int64_t num_steps;
+  int64_t total_steps;                   /* MonitorEnv._total_steps: every raw step of the run (:77) */
   int64_t elapsed_steps, compat_count, max_episode_steps;
   int skip;
   uint64_t seed, env_id, reset_count;
@@ -71,6 +72,7 @@ static int raw_step(EnvO* v, int ale_action, int* reward) {
   if (v->compat_count >= v->max_episode_steps) { done = 1; v->compat_count = 0; }
   v->cur_reward += r;                                   /* atari_wrappers.py:75-77 */
   v->num_steps++;
+  v->total_steps++;
   *reward = r;
   return done;
 }
@@ -248,3 +250,5 @@ void oracle_vec_raw_frames(void* p, int env, uint8_t* out) {
   memcpy(out, ((VecO*)p)->envs[env].obs_buf, 2 * ATARI_FRAME_BYTES);
 }
 int oracle_vec_lives(void* p, int env) { return ((VecO*)p)->envs[env].lives; }
+/* MonitorEnv.get_total_steps atari_wrappers.py:73-77,90-91 */
+int64_t oracle_vec_total_steps(void* p, int env) { return ((VecO*)p)->envs[env].total_steps; }

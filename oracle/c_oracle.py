@@ -219,6 +219,11 @@ class VecEnv:
     def lives(self, env):
         return self.L.oracle_vec_lives(self.h, env)
 
+    def total_steps(self, env):
+        """MonitorEnv.get_total_steps() of env (parl/env/atari_wrappers.py:73-77,90-91): every raw step so far"""
+        self.L.oracle_vec_total_steps.restype = ctypes.c_int64
+        return int(self.L.oracle_vec_total_steps(self.h, env))
+
     def __del__(self):
         try:
             self.L.oracle_vec_free(self.h)

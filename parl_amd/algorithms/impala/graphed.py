@@ -13,8 +13,10 @@ and replayed per update: one host call, no Python between the kernels.
   * the learning rate is a DEVICE scalar (Adam `capturable`, tensor lr): a piecewise schedule
     (impala_config.py:34-36) is one `fill_` when the value changes, no re-capture; the entropy
     coefficient is a kernel argument — a new value re-captures (the reference's schedule is constant);
-  * with a data-parallel grad_hook (parl_amd.dist.FlatGradAllReduce) the update is TWO graphs with the
-    RCCL all-reduce between them (forward + backward into the flat bucket | clip + Adam);
+  * with a data-parallel grad_hook (parl_amd.dist.FlatGradAllReduce) over RCCL the all-reduce is captured INSIDE
+    the graph (forward + backward into the flat bucket | ncclAllReduce | clip + Adam: still one launch per
+    update, round 6); over gloo (ranks sharing a test GPU) or with PARL_AMD_GRAPH_ALLREDUCE=0 the update is TWO
+    graphs with the eager collective between them;
   * the four loss terms + KL of every replay are accumulated on the device (`pop_stats()` = means
     since the last pop: one D2H per log interval instead of one per update, atari_agent.py:40-41).
 
@@ -134,6 +136,8 @@ class GraphedLearn(object):
         self.pool = pool
         self.graphs = None
         self.replays = 0
+        self.allreduce_in_graph = False
+        self.allreduce_capture_error = None
         self._capture(float(entropy_coeff))
 
     # ---- the captured body -------------------------------------------------------------------
@@ -243,8 +247,30 @@ class GraphedLearn(object):
         torch.cuda.synchronize(dev)
         self.graphs = []
         kw = {'pool': self.pool} if self.pool is not None else {}
-        g1 = torch.cuda.CUDAGraph()
-        if split:
+        self.allreduce_in_graph = False
+        if split and self._collective_capturable():
+            # Data-parallel update as ONE hipGraph: forward + backward | RCCL all-reduce of the flat bucket | clip +
+            # Adam.  RCCL's kernels are capturable (torch's ProcessGroupNCCL enqueues them on its own stream behind
+            # events, which a capture records as graph dependencies); the eager collective between two graphs cost a
+            # host call, two graph launches and an idle learner stream 51 times per rollout.  thread_local capture
+            # mode: the process group's watchdog thread queries events while we capture.  If the capture fails
+            # (a backend that cannot be captured), the two-graph form below takes over.
+            g1 = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g1, capture_error_mode='thread_local', **kw):
+                    self._forward_backward()
+                    alg.grad_hook(alg.model)
+                    self._clip_and_step()
+                self.graphs = [g1]
+                self.allreduce_in_graph = True
+            except Exception as e:   # noqa: BLE001 (any capture failure: fall back, keep the reason)
+                self.allreduce_capture_error = '%s: %s' % (type(e).__name__, str(e).split('\n')[0])
+                torch.cuda.synchronize(dev)
+                g1 = None
+        if self.graphs:
+            pass
+        elif split:
+            g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, **kw):
                 self._forward_backward()
             g2 = torch.cuda.CUDAGraph()
@@ -252,6 +278,7 @@ class GraphedLearn(object):
                 self._clip_and_step()
             self.graphs = [g1, g2]
         else:
+            g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, **kw):
                 self._forward_backward()
                 self._clip_and_step()
@@ -261,6 +288,14 @@ class GraphedLearn(object):
         _guard_load_state_dict(alg.optimizer)
         for p in list(alg.model.parameters()) + list(alg.model.buffers()):
             p._parl_graph_written = True  # replays write it without moving its version counter (ops._cached_layout)
+
+    @staticmethod
+    def _collective_capturable():
+        """the gradient all-reduce can be captured into the update's graph: an RCCL group (gloo moves the bucket
+        through the host) and not switched off (PARL_AMD_GRAPH_ALLREDUCE=0: the two-graph form, for A/B runs)"""
+        import torch.distributed as dist
+        return bool(dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl' and
+                    os.environ.get('PARL_AMD_GRAPH_ALLREDUCE', '1') != '0')
 
     # ---- per update --------------------------------------------------------------------------
     def load(self, batch, b0, E):

@@ -20,6 +20,21 @@ namespace parlhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// MFMA accumulators live in AccVGPRs (round 6).  hipcc selects the VGPR-destination form of v_mfma for a kernel that may
+// use at most 256 registers and names no AGPR itself (SIMachineFunctionInfo: MayNeedAGPRs = false) — and a VGPR-form
+// MFMA issued into a matrix pipe that is not already streaming costs the SIMD far more than its passes: the issuing
+// wave ~50 extra clocks per MFMA (tools/neighbour_kernels.hip modes 17 / 28: 255 vs 147 clocks per [sleep, 2 MFMAs]
+// step) and, worse, every OTHER wave on the SIMD — the emulator's waves beside the learner ran 1.9x longer beside the
+// VGPR form, 1.00x beside the same loop with AGPR accumulators (profiles/r06_env_beside_neighbours.log).  hipBLASLt's
+// kernels (MIAV0) keep their accumulators in AGPRs, which is why its GEMMs never showed the effect.  One inline-asm
+// operand with an "a" constraint makes the backend select the AGPR form for every MFMA intrinsic of the kernel;
+// hazards, scheduling and sched_group_barrier stay the compiler's.
+#ifndef PARLHIP_ACC_VGPR
+#define MFMA_ACC_IN_AGPRS() asm volatile("" ::"a"(0))
+#else
+#define MFMA_ACC_IN_AGPRS() do {} while (0)
+#endif
+
 #ifdef PARLHIP_CONV_REGIONS  // diagnostic build only (tools/conv_regions.py): s_memtime clocks per phase, summed over
 __device__ unsigned long long g_conv_regions[16];   // the workgroups' wave 0; [15] = observations
 #define CONV_REGION(i)                                                                       \
@@ -150,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv12_u8_mfma_kernel(
     const uint8_t* __restrict__ obs, RingObs ro, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ out, int n_obs,
     const float* __restrict__ packed) {
+  MFMA_ACC_IN_AGPRS();
   extern __shared__ float lds[];
   float* in_pad = lds;                  // [4][44][44]
   float* c1_pad = in_pad + kLdsIn;      // [16][25][25]
@@ -358,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
     const uint8_t* __restrict__ obs, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ a2, const float* __restrict__ dy,
     float* __restrict__ partial, int n_obs) {
+  MFMA_ACC_IN_AGPRS();
   extern __shared__ float lds[];
   uint8_t* in_u8 = reinterpret_cast<uint8_t*>(lds);   // [4][44][44] uint8, zero-padded
   float* lut = lds + kLdsBwdU8 / 4;                   // [256] (float)u / 255.0f
@@ -712,6 +729,7 @@ template <bool RING, bool PACKED>
 __global__ __launch_bounds__(256, 2) void conv1_84_u8_mfma_kernel(
     const uint8_t* __restrict__ obs, RingObs ro, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, int n_obs) {
+  MFMA_ACC_IN_AGPRS();
   extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
   uint8_t* tile = lds8;                                          // [88 guard][4][84][84]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -848,6 +866,7 @@ __global__ __launch_bounds__(256) void conv23_84_mfma_kernel(
     const float* __restrict__ a1, const float* __restrict__ wt2, const float* __restrict__ b2,
     const float* __restrict__ wt3, const float* __restrict__ b3, float* __restrict__ a2_out,
     float* __restrict__ a3_out, int n_obs) {
+  MFMA_ACC_IN_AGPRS();
   extern __shared__ float lds[];
   float* a1p = lds;                       // [8][24][24]: one quarter of a1's channels at a time
   float* a2s = lds + kA1Q * kA1Plane;     // [64][121]
@@ -1003,6 +1022,7 @@ constexpr int kPart3 = 64 * 576 + 64;                                  // dW3 [o
 __global__ __launch_bounds__(256) void conv3_84_bwd_kernel(
     const float* __restrict__ a2, const float* __restrict__ a3, const float* __restrict__ dy3,
     const float* __restrict__ wt3b, float* __restrict__ dz2, float* __restrict__ partial, int n_obs) {
+  MFMA_ACC_IN_AGPRS();
   extern __shared__ float lds[];
   float* a2s = lds;                         // [64][121]
   float* z3p = lds + 64 * kM2b;             // [64][13][13], zero border
@@ -1157,6 +1177,7 @@ constexpr int kPart2 = 64 * 512 + 64;
 __global__ __launch_bounds__(256) void conv2_84_bwd_kernel(
     const float* __restrict__ a1, const float* __restrict__ dz2, const float* __restrict__ wt2b,
     float* __restrict__ dz1, float* __restrict__ partial, int n_obs) {
+  MFMA_ACC_IN_AGPRS();
   extern __shared__ float lds[];
   float* a1p = lds;                       // [32][24][24], zero border
   float* z2s = lds + 32 * kA1Plane;       // [64][11][11]
@@ -1301,6 +1322,7 @@ constexpr int kPart1 = 32 * 256 + 32;
 
 __global__ __launch_bounds__(256, 2) void conv1_84_bwd_kernel(
     const uint8_t* __restrict__ obs, const float* __restrict__ dz1, float* __restrict__ partial, int n_obs) {
+  MFMA_ACC_IN_AGPRS();
   extern __shared__ float lds[];
   uint8_t* tile = reinterpret_cast<uint8_t*>(lds);        // [4][84][84] uint8, shifted by the padding
   float* lut = lds + kPlane84;                            // [256]

@@ -35,12 +35,24 @@ def describe():
     return '%s, %d rank(s) in the group' % (dist.get_backend(), dist.get_world_size())
 
 
-def init(backend=None, force=False, timeout_s=None):
+def _rendezvous_store(addr, port, rank, world, timeout):
+    """the store `init_method='env://'` would create (torch.distributed.rendezvous._create_c10d_store), with OUR
+    timeout: under torchrun the workers are clients of the agent's store (TORCHELASTIC_USE_AGENT_STORE) behind a
+    per-attempt prefix; otherwise rank 0 hosts it"""
+    if os.environ.get('TORCHELASTIC_USE_AGENT_STORE') == 'True':
+        tcp = dist.TCPStore(addr, port, world, False, timeout=timeout)
+        return dist.PrefixStore('/worker/attempt_%s' % os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'), tcp)
+    return dist.TCPStore(addr, port, world, rank == 0, timeout=timeout, multi_tenant=True)
+
+
+def init(backend=None, force=False, timeout_s=None, collective_timeout_s=None):
     """Initialise from the torchrun env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  A single
     process creates no group unless force=True (one-rank RCCL group: tests, PARL_AMD_FORCE_DIST=1).
-    timeout_s (default PARL_AMD_DIST_TIMEOUT or 120): rendezvous AND collective timeout — a rank that never
-    shows up makes init raise after this long instead of hanging (torch's default is 10-30 minutes), a collective
-    one rank never joins makes RCCL's watchdog abort the process after it."""
+    Two separate limits: `timeout_s` (default PARL_AMD_DIST_TIMEOUT or 120) bounds the RENDEZVOUS — a
+    rank that never shows up makes init raise after this long instead of hanging (torch's default is 10-30
+    minutes); `collective_timeout_s` (default PARL_AMD_COLLECTIVE_TIMEOUT or 900) is what RCCL's watchdog allows a
+    single collective before it aborts the process — long enough for a peer's first-iteration graph captures,
+    checkpoint or log I/O, short enough that a dead peer does not hang the job for good."""
     global _debug_log
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -58,6 +70,8 @@ def init(backend=None, force=False, timeout_s=None):
         os.environ.setdefault('MASTER_PORT', '29533')
         if timeout_s is None:
             timeout_s = float(os.environ.get('PARL_AMD_DIST_TIMEOUT', '120'))
+        if collective_timeout_s is None:
+            collective_timeout_s = float(os.environ.get('PARL_AMD_COLLECTIVE_TIMEOUT', str(max(900.0, timeout_s))))
         if backend == 'nccl':   # RCCL's own complaints, kept per process for error reports (collective_log_tail)
             os.environ.setdefault('NCCL_DEBUG', 'WARN')
             if 'NCCL_DEBUG_FILE' not in os.environ:
@@ -66,8 +80,11 @@ def init(backend=None, force=False, timeout_s=None):
             else:
                 _debug_log = os.environ['NCCL_DEBUG_FILE']
         try:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world,
-                                    timeout=datetime.timedelta(seconds=timeout_s))
+            # the store carries the rendezvous limit, the group the collective limit
+            store = _rendezvous_store(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']), rank, world,
+                                      datetime.timedelta(seconds=timeout_s))
+            dist.init_process_group(backend=backend, store=store, rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=collective_timeout_s))
         except Exception as e:
             raise RuntimeError('process group rendezvous failed on rank %d of %d (%s at %s:%s, timeout %.0f s): %s: %s' %
                                (rank, world, backend, os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'], timeout_s,
@@ -174,6 +191,44 @@ def all_reduce_max_scalar(x):
     t = torch.tensor([x], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_gather_scalar(x):
+    """[x of rank 0, x of rank 1, ...] for a python float (bench.py: per-rank timings on rank 0's line)"""
+    if not active():
+        return [float(x)]
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.zeros(world_size(), dtype=torch.float64, device=dev)
+    t[dist.get_rank()] = float(x)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
+
+
+def time_allreduce(hook, stream=None, iters=30):
+    """the gradient all-reduce of a FlatGradAllReduce bucket by itself: median / min / max microseconds of `iters`
+    event-timed calls on `stream` (every rank calls this at the same point; the collective is the real one on the
+    real bucket, whose contents are garbage afterwards — call it outside an update)"""
+    if not active() or hook is None:
+        return None
+    st = stream or torch.cuda.current_stream(hook.flat.device)
+    ts = []
+    with torch.cuda.stream(st):
+        for _ in range(3):
+            hook.flat.zero_()
+            dist.all_reduce(hook.flat, op=dist.ReduceOp.SUM)
+        st.synchronize()
+        evs = []
+        for _ in range(iters):
+            hook.flat.zero_()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(st)
+            dist.all_reduce(hook.flat, op=dist.ReduceOp.SUM)
+            b.record(st)
+            evs.append((a, b))
+        st.synchronize()
+        ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+    return {'n': len(ts), 'median_us': ts[len(ts) // 2], 'min_us': ts[0], 'max_us': ts[-1],
+            'bytes': hook.flat.numel() * hook.flat.element_size()}
 
 
 def barrier():

@@ -50,15 +50,17 @@ class MonitorEnv(object):
     episodes.  Same bookkeeping as the reference: CUMULATIVE `_episode_rewards` / `_episode_lengths` lists
     plus the `_num_returned` cursor of next_episode_results() (:97-100), so get_episode_rewards() /
     get_episode_lengths() keep returning every episode of the run.  Filled by the VectorEnv that owns the
-    env: the device reports an episode when it closes, so get_total_steps() counts the frames of closed
-    episodes (the reference also counts the running episode's frames, which live on the device here)."""
+    env: the device reports an episode when it closes; get_total_steps() is the reference's count of EVERY raw
+    step (:73-77,90-91) — the closed episodes' lengths plus the running episode's counter, read from the env's
+    state blob on the device (`_running_steps`, installed by VectorEnv; one 4-byte D2H per call)."""
 
     def __init__(self):
         self._episode_rewards = []
         self._episode_lengths = []
         self._num_episodes = 0
         self._num_returned = 0
-        self._total_steps = 0
+        self._total_steps = 0       # raw steps of the closed episodes
+        self._running_steps = None  # () -> raw steps of the running episode (device counter)
 
     def _push(self, ret, length):
         self._episode_rewards.append(float(ret))
@@ -78,7 +80,7 @@ class MonitorEnv(object):
         return self._episode_lengths
 
     def get_total_steps(self):
-        return self._total_steps
+        return self._total_steps + (int(self._running_steps()) if self._running_steps is not None else 0)
 
 
 class TestEnv(object):

@@ -353,6 +353,17 @@ class DeviceVectorEnv(object):
         info = {'episode_returns': self.ep_returns, 'episode_lengths': self.ep_lengths}
         return self.current_obs(), self.rewards, self.dones.bool(), info
 
+    # MonitorEnv's step counter of the RUNNING episode (csrc/atari_defs.hpp: int32 scalar slot S_NUM_STEPS of an env's
+    # state blob; tests/test_capi_symbols.py checks both constants against the header)
+    _STATE_SCALARS_OFFSET, _SLOT_NUM_STEPS = 192, 32
+
+    def running_episode_steps(self):
+        """int32 [E]: raw (per emulated frame) steps of every env's unfinished episode — what MonitorEnv.step has
+        added to `_num_steps` since the last real reset (parl/env/atari_wrappers.py:73-77)"""
+        blob = self.states.view(self.envs_num, -1)
+        o = self._STATE_SCALARS_OFFSET + 4 * self._SLOT_NUM_STEPS
+        return blob[:, o:o + 4].contiguous().view(torch.int32).view(-1)
+
     # ---------------------------------------------------------------- checkpoint (SURVEY 8 f4)
     _STATE_TENSORS = ('states', 'raw_frames', 'ring', 'since', 'rewards', 'dones', 'obs_flags', 'ep_returns',
                       'ep_lengths', 'jam')

@@ -34,6 +34,8 @@ class VectorEnv(object):
         self.dev_env = DeviceVectorEnv(first.env_id, self.envs_num, dim=first.dim, horizon=64, seed=seed,
                                        env_id0=id0, device=device)
         self._nhwc = first.obs_format == 'NHWC'
+        for i, e in enumerate(envs):  # MonitorEnv.get_total_steps also counts the running episode (atari_wrappers.py:73-77)
+            e.monitor._running_steps = lambda i=i: self.dev_env.running_episode_steps()[i].item()
 
     def _obs_list(self, obs):
         a = obs.cpu().numpy()

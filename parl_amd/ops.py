@@ -589,7 +589,12 @@ def atari84_conv1(obs, conv1_weight, conv1_bias, out=None, wt1=None):
         N.ptr(conv1_weight)   # raises: no CPU path
     # (rebuilt when the tensor's version moved — every optimizer step for the learner, once per rollout for the actors —
     # and always for parameters a graph replay writes; wt1: the caller's own operand-order copy of the CURRENT weights)
-    if wt1 is None:
+    if wt1 is None and (torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing()):
+        # the learner (weights change every update) and captures (a layout built OUTSIDE the graph would be baked in
+        # and go stale on replay; the cache would also record an event inside the capture): built inline, as
+        # atari84_conv23 does
+        wt1 = atari84_conv1_layout(conv1_weight)
+    elif wt1 is None:
         wt1 = _cached_layout(conv1_weight, 'wt1', lambda w: atari84_conv1_layout(w))
     elif wt1.dtype != torch.float32 or wt1.numel() != 64 * 2 * 64 or not wt1.is_contiguous():
         raise N.ParlHipError('atari84_conv1: wt1 must be atari84_conv1_layout\'s buffer')

@@ -116,6 +116,7 @@ class DeviceRollout(object):
         self._step_base = torch.zeros(1, dtype=torch.int64, device=dev)
         self._base_count = 0
         self._graphs, self._graph_pool, self._segment_runs = {}, None, {}
+        self._graph_models, self._live_cuts = {}, set()   # models the graphs refer to; the [t0, t1) cuts in use
         # MonitorEnv statistics (atari_wrappers.py:44-100), reduced on the device:
         # (episodes closed, sum of unclipped returns, sum of lengths)
         self.ep_stats = torch.zeros(3, dtype=torch.float64, device=dev)
@@ -191,7 +192,14 @@ class DeviceRollout(object):
                 self.collect_step(model, t)
             return
         env = self.env
-        key = (self._cur, env.ring_index, int(t0), int(t1), id(model))   # the slabs of buffer _cur, the frames of ring ring_index
+        # the slabs of buffer _cur, the frames of ring ring_index.  The entry holds a reference to the model (its id
+        # cannot be reused by another module while a graph with its parameter addresses is alive), and graphs of
+        # segment cuts nobody asks for any more (recalibrated / checkpoint-loaded refresh points) are dropped
+        key = (self._cur, env.ring_index, int(t0), int(t1), id(model))
+        self._graph_models[id(model)] = model
+        if (int(t0), int(t1)) not in self._live_cuts:
+            self._live_cuts = {c for c in self._live_cuts if not (c[0] < t1 and t0 < c[1])} | {(int(t0), int(t1))}
+            self._drop_graphs(lambda k: (k[2], k[3]) not in self._live_cuts)
         g = self._graphs.get(key)
         if g is None:
             runs = self._segment_runs.get(key, 0)
@@ -215,6 +223,12 @@ class DeviceRollout(object):
         g.replay()
         self.step_count += t1 - t0
         env.t += t1 - t0
+
+    def _drop_graphs(self, stale):
+        for k in [k for k in self._graphs if stale(k)]:
+            del self._graphs[k]
+        for k in [k for k in self._segment_runs if stale(k)]:
+            del self._segment_runs[k]
 
     def _batch_view(self):
         """the time-major batch over the selected trajectory buffer"""
@@ -256,19 +270,34 @@ class DeviceRollout(object):
         if self.ep_stats.is_cuda:
             torch.cuda.synchronize(self.ep_stats.device)
         return {'step_count': self.step_count, 'started': self.started, 'cur': self._cur, 'seed': self.seed,
-                'ep_stats': self.ep_stats.detach().cpu().clone(), 'ring_of_buf': list(self._ring_of_buf)}
+                'ep_stats': self.ep_stats.detach().cpu().clone(), 'ring_of_buf': list(self._ring_of_buf),
+                'lazy_obs': self.lazy_obs}
 
     def buffer_state(self, k):
         """the trajectory slabs of buffer k (a collected batch somebody still has to learn from)"""
         return {n: v.detach().cpu().clone() for n, v in self._bufs[k].items()}
 
     def load_buffer_state(self, k, d):
+        missing = [n for n in self._bufs[k] if n not in d]
+        if missing:   # e.g. a checkpoint whose observations stayed in the frame rings (lazy_obs) loaded without it
+            raise ValueError('trajectory buffer %d: the checkpoint holds no %s (saved with lazy_obs=%s, this rollout has '
+                             'lazy_obs=%s: PARL_AMD_LAZY_OBS must be what it was when the checkpoint was written)' %
+                             (k, ', '.join(repr(n) for n in missing), 'obs' not in d, self.lazy_obs))
         for n, v in self._bufs[k].items():
             v.copy_(d[n].to(v.device))
 
     def load_state_dict(self, d):
         if d['seed'] != self.seed:
             raise ValueError('rollout seed %r differs from the checkpoint (%r)' % (self.seed, d['seed']))
+        if bool(d.get('lazy_obs', self.lazy_obs)) != self.lazy_obs:
+            raise ValueError('the checkpoint was written with lazy_obs=%s (observations %s), this rollout has lazy_obs=%s: '
+                             'build the pipeline with the same PARL_AMD_LAZY_OBS' %
+                             (d['lazy_obs'], 'in the env\'s frame rings' if d['lazy_obs'] else 'materialised per buffer',
+                              self.lazy_obs))
+        if self.lazy_obs and ('ring_of_buf' not in d or len(d['ring_of_buf']) != len(self._ring_of_buf)):
+            raise ValueError('the checkpoint names the frame ring of %s trajectory buffers, this rollout has %d: a pending '
+                             'batch would read whichever ring is current' %
+                             (len(d['ring_of_buf']) if 'ring_of_buf' in d else 'no', len(self._ring_of_buf)))
         self.step_count, self.started, self._cur = int(d['step_count']), bool(d['started']), int(d['cur'])
         if 'ring_of_buf' in d and len(d['ring_of_buf']) == len(self._ring_of_buf):
             self._ring_of_buf = [int(x) for x in d['ring_of_buf']]
@@ -455,7 +484,7 @@ class DeviceA2CRollout(object):
         self.adv = torch.zeros((T, E), dtype=torch.float32, device=dev)
         self.target = torch.zeros((T, E), dtype=torch.float32, device=dev)
         self._step_base = torch.zeros(1, dtype=torch.int64, device=dev)   # number of the rollout's first step (hipGraph replays)
-        self._graphs, self._runs, self._side = {}, {}, None
+        self._graphs, self._runs, self._side, self._graph_models = {}, {}, None, {}
 
     def _steps(self, model, base=None):
         """the T steps of a rollout, the bootstrap value forward, the GAE launch and the batch's observations; with
@@ -498,6 +527,7 @@ class DeviceA2CRollout(object):
         batch = {'obs': self.obs, 'actions': self.actions.reshape(n), 'advantages': self.adv.reshape(n),
                  'target_values': self.target.reshape(n)}
         key = id(model)
+        self._graph_models[key] = model   # the graph holds its parameter addresses: the id must not be reused while it lives
         g = self._graphs.get(key) if self._can_graph(model) else None
         runs = self._runs.get(key, 0)
         self._runs[key] = runs + 1

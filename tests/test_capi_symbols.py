@@ -143,3 +143,17 @@ def test_frame_post_tables_have_the_structure_the_observation_tail_assumes(built
     assert (per_band[:, :, 1] == per_band[0, :, 1]).all()                       # the same weights in every band
     assert (per_band[:, :, 0] == per_band[0, :, 0] + 5 * np.arange(42)[:, None]).all()   # the same rows, shifted by the band
     assert per_band[0, :, 0].min() == 0 and per_band[0, :, 0].max() == 4
+
+
+def test_state_blob_constants_python_side_match_the_header():
+    """DeviceVectorEnv.running_episode_steps reads MonitorEnv's step counter out of an env's state blob: the byte
+    offset of the scalar slots and the slot index are csrc/atari_defs.hpp's"""
+    import re
+    from parl_amd.env.device_vector_env import DeviceVectorEnv
+    src = open(os.path.join(ROOT, 'parl_amd', 'csrc', 'atari_defs.hpp')).read()
+    off = int(re.search(r'constexpr int kOffScalars = (\d+);', src).group(1))
+    body = re.search(r'enum Slot : int \{(.*?)\};', src, re.S).group(1)
+    body = re.sub(r'//[^\n]*', '', body)
+    names = [x.strip().split('=')[0].strip() for x in body.split(',') if x.strip()]
+    assert DeviceVectorEnv._STATE_SCALARS_OFFSET == off
+    assert names[DeviceVectorEnv._SLOT_NUM_STEPS] == 'S_NUM_STEPS'

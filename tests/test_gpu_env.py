@@ -342,7 +342,12 @@ def test_reference_style_vector_env_on_device(dev, oracle):
                 assert got == [(float(r), int(n)) for r, n in exp]
                 n_eps += len(got)
                 assert ('episode' in info[e]) == bool(exp)
+            if t % 50 == 49 or t == 399:  # MonitorEnv.get_total_steps: EVERY raw step, the running episode's too (:73-77)
+                for e in range(E):
+                    assert get_wrapper_by_cls(envs[e], MonitorEnv).get_total_steps() == orc.total_steps(e)
         assert n_eps >= 1
+        mon = get_wrapper_by_cls(envs[0], MonitorEnv)
+        assert mon.get_total_steps() > sum(mon.get_episode_lengths())   # an episode is running
     finally:
         sys.path.remove(os.path.join(ROOT, 'compat'))
 

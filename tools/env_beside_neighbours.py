@@ -34,14 +34,21 @@ NAMES = {0: 'LDS reads (ds_read2 gathers, no MFMA)', 1: 'MFMA chains (no LDS rea
          14: 'as 8, the gather two steps ahead of its MFMAs', 15: 'as 8, gathered value through v_mov_b32 first',
          16: 'as 8, gathered value through v_add_f32 0 first', 17: 'sparse MFMAs, no LDS: s_sleep between pairs',
          18: 'sparse MFMAs, no LDS: a VALU chain between pairs', 19: 'MFMAs in bursts of 16 with long sleeps, no LDS',
-         20: 'sparse 4x4x1 MFMAs (2 passes), s_sleep between pairs', 21: 'sparse 32x32x2 MFMAs (16 passes), s_sleep between pairs'}
+         20: 'sparse 4x4x1 MFMAs (2 passes), s_sleep between pairs', 21: 'sparse 32x32x2 MFMAs (16 passes), s_sleep between pairs',
+         22: 'ONE accumulator: dense dependent MFMA chain, no LDS', 23: 'software-pipelined tiles: gathers of tile t+1 before the 32 MFMAs of tile t, epilogue',
+         24: 'as 23 + a workgroup barrier every 4 tiles', 25: 'as 23 without the epilogue', 26: 'as 23 NOT pipelined (gathers waited for in front of their MFMAs)',
+         27: 'as 8, accumulators in AGPRs', 28: 'as 17, accumulators in AGPRs', 29: 'as 26, accumulators in AGPRs (one pair across tiles)',
+         30: 'as 8 at s_setprio 3', 31: 'as 26 at s_setprio 3 (one accumulator pair across tiles)',
+         32: 'as 17, every wave starts after a pseudo-random delay', 33: 'as 26 (one accumulator pair), every wave starts after a pseudo-random delay'}
+ITERS = {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2, 22: 200, 23: 100, 24: 100, 25: 100, 26: 100, 29: 100, 31: 100, 33: 100}
+MODES = [int(x) for x in os.environ['NEIGHBOUR_MODES'].split(',')] if os.environ.get('NEIGHBOUR_MODES') else list(range(34))
 
 
 def run(mode, grid=512, steps=40):
     if not sc_busy():
         torch.cuda.synchronize()
     if mode is not None:
-        iters = {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2, 8: 60, 9: 60, 10: 60, 11: 60, 12: 60, 13: 60, 14: 60, 15: 60, 16: 60, 17: 60, 18: 60, 19: 60, 20: 60, 21: 60}[mode]
+        iters = ITERS.get(mode, 60)
         for _ in range(300):   # ~30-100 us each: like the learner's kernels
             nb.neighbour_launch(mode, sink.data_ptr(), iters, grid, sb.cuda_stream)
     with torch.cuda.stream(sa):
@@ -64,22 +71,23 @@ def run(mode, grid=512, steps=40):
 
 
 # one neighbour launch alone, for scale
-for m in range(22):
+for m in MODES:
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    nb.neighbour_launch(m, sink.data_ptr(), {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2, 8: 60, 9: 60, 10: 60, 11: 60, 12: 60, 13: 60, 14: 60, 15: 60, 16: 60, 17: 60, 18: 60, 19: 60, 20: 60, 21: 60}[m], 512, sb.cuda_stream)
+    nb.neighbour_launch(m, sink.data_ptr(), ITERS.get(m, 60), 512, sb.cuda_stream)
     torch.cuda.synchronize()
     with torch.cuda.stream(sb):
         a.record()
-    nb.neighbour_launch(m, sink.data_ptr(), {0: 400, 1: 400, 2: 400, 3: 30, 4: 40, 5: 30, 6: 6, 7: 2, 8: 60, 9: 60, 10: 60, 11: 60, 12: 60, 13: 60, 14: 60, 15: 60, 16: 60, 17: 60, 18: 60, 19: 60, 20: 60, 21: 60}[m], 512, sb.cuda_stream)
+    nb.neighbour_launch(m, sink.data_ptr(), ITERS.get(m, 60), 512, sb.cuda_stream)
     with torch.cuda.stream(sb):
         b.record()
     torch.cuda.synchronize()
     print('neighbour %d (%s): one launch %.0f us' % (m, NAMES[m], a.elapsed_time(b) * 1e3))
 run(None)
-for m in range(22):
+for m in MODES:
     run(m)
-run(0, grid=256)
-run(1, grid=256)
+if not os.environ.get('NEIGHBOUR_MODES'):
+    run(0, grid=256)
+    run(1, grid=256)
 
 # a "heater": dense MFMAs on a THIRD stream (one workgroup per CU) beside the sparse-MFMA neighbour — does a matrix pipe that
 # never goes idle take the stretch away?

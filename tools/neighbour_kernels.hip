@@ -41,6 +41,141 @@ __global__ __launch_bounds__(256, 2) void neighbour_kernel(float* sink, int iter
 #pragma unroll
       for (int k = 0; k < 32; ++k) { x = __builtin_fmaf(x, y, 0.5f); acc = __builtin_fmaf(acc, y, x); }
     }
+  } else if (MODE == 22) {   // ONE accumulator: a dense but DEPENDENT chain (conv1's tile loop without its gathers; 40 clocks per MFMA, not 32)
+    const float a = (float)lane * 0.37f, b = 1.0f + lane;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int k = 0; k < 64; ++k) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c0, 0, 0, 0);
+    }
+    acc = c0[0] + c0[1];
+  } else if (MODE >= 23 && MODE <= 26) {   // SOFTWARE-PIPELINED tiles: the 16 gathers of tile t+1 are issued before the 32 MFMAs of tile t
+    // (two accumulators), a small epilogue (ReLU + 4 LDS stores) per tile.  23: as described; 24: + a workgroup barrier every 4 tiles;
+    // 25: no epilogue; 26: the gathers of tile t are waited for right before its MFMAs (NOT pipelined: the control, conv1's form today)
+    float bw[16][2];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { bw[k][0] = lds[(lane * 3 + k * 17) & 8191] * 1.37f; bw[k][1] = lds[(lane * 5 + k * 29) & 8191] * 0.73f; }
+    const float* base = lds + (lane & 15) * 2 + (lane >> 4) + (tid >> 6) * 1100;
+    float* wr = lds + 12000 + tid * 4;
+    float cur[16], nxt[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cur[k] = base[(k >> 2) * 1936 + (k & 3) * 44];
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll 1
+      for (int t = 0; t < 4; ++t) {
+        const float* nb = base + ((i + t) & 7) * 3;
+        if (MODE != 26) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) nxt[k] = nb[(k >> 2) * 1936 + (k & 3) * 44];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) cur[k] = nb[(k >> 2) * 1936 + (k & 3) * 44];
+        }
+        asm volatile("" ::: "memory");
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[k], bw[k][0], d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[k], bw[k][1], d1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+        if (MODE != 25) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = d0[r] + d1[r]; wr[r] = v > 0.f ? v : 0.f; }
+        } else {
+          c0 += d0; c1 += d1;
+        }
+        if (MODE != 26) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
+        }
+      }
+      if (MODE == 24) __syncthreads();
+    }
+    acc = c0[0] + c1[1] + wr[0];
+  } else if (MODE >= 27 && MODE <= 31) {   // 27 / 28 / 29 = modes 8 / 17 / 26 with the accumulators in AGPRs (inline asm: what hipBLASLt's
+    // kernels do, MIAV0); 30 / 31 = modes 8 / 26 at s_setprio 3
+#define MFMA_AGPR(acc, a, b) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+    if (MODE >= 30) __builtin_amdgcn_s_setprio(3);
+    float bw[32][2];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { bw[k][0] = lds[(lane * 3 + k * 17) & 8191] * 1.37f; bw[k][1] = lds[(lane * 5 + k * 29) & 8191] * 0.73f; }
+    const float* base = lds + (lane & 15) * 2 + (lane >> 4) + (tid >> 6) * 1100;
+    const float ca = (float)lane * 0.37f, cb = 1.0f + lane;
+    for (int i = 0; i < iters; ++i) {
+      if (MODE == 27 || MODE == 30) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          const float a = base[(k >> 2) * 625 + (k & 3) * 25 + (i & 7)];
+          if (MODE == 27) { MFMA_AGPR(c0, a, bw[k][0]); MFMA_AGPR(c1, a, bw[k][1]); }
+          else {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[k][0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[k][1], c1, 0, 0, 0);
+          }
+        }
+      } else if (MODE == 28) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          __builtin_amdgcn_s_sleep(2);
+          MFMA_AGPR(c0, ca, cb);
+          MFMA_AGPR(c1, cb, ca);
+        }
+      } else {
+#pragma unroll 1
+        for (int t = 0; t < 4; ++t) {
+          const float* nb = base + ((i + t) & 7) * 3;
+          float cur[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) cur[k] = nb[(k >> 2) * 1936 + (k & 3) * 44];
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            if (MODE == 29) { MFMA_AGPR(c0, cur[k], bw[k][0]); MFMA_AGPR(c1, cur[k], bw[k][1]); }
+            else {
+              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[k], bw[k][0], c0, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[k], bw[k][1], c1, 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    acc = c0[0] + c1[1] + c0[2] + c1[3];
+  } else if (MODE == 32 || MODE == 33) {   // modes 17 / 26 with every wave's START delayed by a pseudo-random 0 .. ~8 k clocks: are
+    // the waves of a launch hurting the emulator because they burst IN PHASE (a chip-wide current swing)?
+    const unsigned h = (blockIdx.x * 2654435761u + (tid >> 6) * 40503u) >> 7;
+    for (unsigned z = 0; z < (h & 15u); ++z) __builtin_amdgcn_s_sleep(8);
+    const float ca = (float)lane * 0.37f, cb = 1.0f + lane;
+    if (MODE == 32) {
+      for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          __builtin_amdgcn_s_sleep(2);
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca, cb, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cb, ca, c1, 0, 0, 0);
+        }
+      }
+    } else {
+      float bw[16][2];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { bw[k][0] = lds[(lane * 3 + k * 17) & 8191] * 1.37f; bw[k][1] = lds[(lane * 5 + k * 29) & 8191] * 0.73f; }
+      const float* base = lds + (lane & 15) * 2 + (lane >> 4) + (tid >> 6) * 1100;
+      for (int i = 0; i < iters; ++i) {
+#pragma unroll 1
+        for (int t = 0; t < 4; ++t) {
+          const float* nb = base + ((i + t) & 7) * 3;
+          float cur[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) cur[k] = nb[(k >> 2) * 1936 + (k & 3) * 44];
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[k], bw[k][0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[k], bw[k][1], c1, 0, 0, 0);
+          }
+        }
+      }
+    }
+    acc = c0[0] + c1[1] + c0[2] + c1[3];
   } else if (MODE == 20 || MODE == 21) {   // MODE 17 with other MFMA shapes: 20 v_mfma_f32_4x4x1 (2 passes), 21 v_mfma_f32_32x32x2 (16 passes)
     const float a = (float)lane * 0.37f, b = 1.0f + lane;
     typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -199,6 +334,34 @@ __global__ __launch_bounds__(256, 2) void neighbour_kernel(float* sink, int iter
   if (acc == 123.456f) sink[tid] = acc;
 }
 
+// Clock probe: one wave per workgroup runs a fixed dependent VALU chain and reads both counters around it: s_memtime
+// (shader clock ticks) and s_memrealtime (constant 100 MHz).  ticks / realtime = the EFFECTIVE shader clock while the
+// chain ran (rocm-smi shows the PLL target, not what droop / di-dt mitigation makes of it); ticks per iteration = how
+// much of the SIMD the wave got.  out[3 b .. 3 b + 2] = (ticks, realtime ticks, XCC_ID / CU id bits) of workgroup b.
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, int iters, float* sink) {
+  float x = (float)threadIdx.x;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 64; ++k) x = __builtin_fmaf(x, 1.0001f, 0.25f);
+  }
+  asm volatile("" : "+v"(x));
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    out[3 * blockIdx.x] = t1 - t0;
+    out[3 * blockIdx.x + 1] = r1 - r0;
+    out[3 * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+  }
+  if (x == 123.456f) sink[threadIdx.x] = x;
+}
+
+extern "C" int clock_probe_launch(unsigned long long* out, int iters, int grid, float* sink, void* stream) {
+  clock_probe_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(out, iters, sink);
+  return (int)hipGetLastError();
+}
+
 extern "C" int neighbour_launch(int mode, float* sink, int iters, int grid, void* stream) {
   const size_t lds = 70000;
   static bool set = false;
@@ -225,6 +388,18 @@ extern "C" int neighbour_launch(int mode, float* sink, int iters, int grid, void
     hipFuncSetAttribute((const void*)neighbour_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)neighbour_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)neighbour_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<22>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<23>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<26>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<27>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<28>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<29>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<31>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)neighbour_kernel<33>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     set = true;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -236,6 +411,18 @@ extern "C" int neighbour_launch(int mode, float* sink, int iters, int grid, void
   else if (mode == 6) neighbour_kernel<6><<<grid, 256, lds, s>>>(sink, iters);
   else if (mode == 7) neighbour_kernel<7><<<grid, 256, lds, s>>>(sink, iters);
   else if (mode == 8) neighbour_kernel<8><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 22) neighbour_kernel<22><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 23) neighbour_kernel<23><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 24) neighbour_kernel<24><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 25) neighbour_kernel<25><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 26) neighbour_kernel<26><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 27) neighbour_kernel<27><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 28) neighbour_kernel<28><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 29) neighbour_kernel<29><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 30) neighbour_kernel<30><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 31) neighbour_kernel<31><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 32) neighbour_kernel<32><<<grid, 256, lds, s>>>(sink, iters);
+  else if (mode == 33) neighbour_kernel<33><<<grid, 256, lds, s>>>(sink, iters);
   else if (mode == 21) neighbour_kernel<21><<<grid, 256, lds, s>>>(sink, iters);
   else if (mode == 20) neighbour_kernel<20><<<grid, 256, lds, s>>>(sink, iters);
   else if (mode == 19) neighbour_kernel<19><<<grid, 256, lds, s>>>(sink, iters);
