@@ -478,6 +478,23 @@ int parlhip_atari42_conv12_bwd_packed_f32(const uint8_t* obs, const float* packe
                                           float* dw1, float* db1, float* dw2, float* db2,
                                           parlhip_stream_t stream);
 
+/* The learner's pair with the conv1 activation SAVED instead of recomputed (round 6; same reference lines: the
+ * framework's autograd keeps relu(conv1) of atari_model.py:59-71 for the backward pass — so does this pair).  The
+ * forward writes, next to `out`, the zero-padded conv1 tile of every observation as it stands in LDS
+ * (a1_out f32, parlhip_atari42_conv12_a1_bytes(n_obs) bytes = 16 x 25 x 25 floats per observation, 16-byte aligned;
+ * `out` bit-identical to the entries above); the backward reads it back with an LDS-DMA copy in place of its
+ * conv1 recompute (448 of its 2,812 MFMAs per observation and the slowest of its phases) and runs its dz1 / dW1
+ * sums as two interleaved accumulator chains — gradients equal to parlhip_atari42_conv12_bwd_packed_f32's up to the
+ * order of those sums (deterministic, run-to-run bit-identical).  Meant for the learner's 1000-row updates
+ * (40 MB per update); at 40 KB per observation a 51,200-row pass would move 2 GB each way: use the recompute there. */
+size_t parlhip_atari42_conv12_a1_bytes(int n_obs);
+int parlhip_atari42_conv12_packed_save_u8_f32(const uint8_t* obs, const float* packed, const float* b1,
+                                              const float* b2, float* out, float* a1_out, int n_obs,
+                                              parlhip_stream_t stream);
+int parlhip_atari42_conv12_bwd_saved_f32(const uint8_t* obs, const float* packed, const float* b1, const float* a1,
+                                         const float* a2, const float* dy, int n_obs, float* workspace,
+                                         float* dw1, float* db1, float* dw2, float* db2, parlhip_stream_t stream);
+
 /* examples/A2C/atari_model.py:21-104 (AtariModel trunk), first layer — the 84x84 -> 20x20
  * contraction: x = obs / 255; conv1 4->32 k8 s4 p1 + ReLU.  obs u8 [n,4,84,84], w1 f32
  * [32,4,8,8], b1 [32] (nn.Conv2d layout), out f32 [n,32,20,20] (NCHW, the input of conv2).

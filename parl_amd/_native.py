@@ -113,6 +113,9 @@ SIGNATURES = {
     'parlhip_atari42_conv12_bwd_workspace_bytes': (_sz, [_i]),
     'parlhip_atari42_conv12_bwd_f32': (_i, [_p] * 6 + [_i] + [_p] * 6),
     'parlhip_atari42_conv12_bwd_packed_f32': (_i, [_p] * 5 + [_i] + [_p] * 6),
+    'parlhip_atari42_conv12_a1_bytes': (_sz, [_i]),
+    'parlhip_atari42_conv12_packed_save_u8_f32': (_i, [_p] * 6 + [_i, _p]),
+    'parlhip_atari42_conv12_bwd_saved_f32': (_i, [_p] * 6 + [_i] + [_p] * 6),
     'parlhip_vecnorm_obs_f64': (_i, [_p] * 7 + [_i, _i, _d, _d, _i, _p]),
     'parlhip_vecnorm_reward_f64': (_i, [_p] * 8 + [_i, _d, _d, _d, _p]),
     'parlhip_ppo_sample_batch_f32': (_i, [_p] * 13 + [_i64, _i64, _i, _i, _p]),

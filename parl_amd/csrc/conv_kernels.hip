@@ -20,21 +20,6 @@ namespace parlhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// MFMA accumulators live in AccVGPRs (round 6).  hipcc selects the VGPR-destination form of v_mfma for a kernel that may
-// use at most 256 registers and names no AGPR itself (SIMachineFunctionInfo: MayNeedAGPRs = false) — and a VGPR-form
-// MFMA issued into a matrix pipe that is not already streaming costs the SIMD far more than its passes: the issuing
-// wave ~50 extra clocks per MFMA (tools/neighbour_kernels.hip modes 17 / 28: 255 vs 147 clocks per [sleep, 2 MFMAs]
-// step) and, worse, every OTHER wave on the SIMD — the emulator's waves beside the learner ran 1.9x longer beside the
-// VGPR form, 1.00x beside the same loop with AGPR accumulators (profiles/r06_env_beside_neighbours.log).  hipBLASLt's
-// kernels (MIAV0) keep their accumulators in AGPRs, which is why its GEMMs never showed the effect.  One inline-asm
-// operand with an "a" constraint makes the backend select the AGPR form for every MFMA intrinsic of the kernel;
-// hazards, scheduling and sched_group_barrier stay the compiler's.
-#ifndef PARLHIP_ACC_VGPR
-#define MFMA_ACC_IN_AGPRS() asm volatile("" ::"a"(0))
-#else
-#define MFMA_ACC_IN_AGPRS() do {} while (0)
-#endif
-
 #ifdef PARLHIP_CONV_REGIONS  // diagnostic build only (tools/conv_regions.py): s_memtime clocks per phase, summed over
 __device__ unsigned long long g_conv_regions[16];   // the workgroups' wave 0; [15] = observations
 #define CONV_REGION(i)                                                                       \
@@ -89,6 +74,14 @@ struct Batch {
   }
 };
 
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4): the wave's 1 KiB lands at the
+// wave-uniform `lds_chunk` + 16 * lane, no staging registers, no ds_write; completion is counted on vmcnt (the fence of
+// the next __syncthreads() waits for it).
+__device__ __forceinline__ void glds16(const float* gsrc_lane, float* lds_chunk) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                   (__attribute__((address_space(3))) void*)lds_chunk, 16, 0, 0);
+}
+
 // (float)u / 255.0f without the division: one Newton step makes the product correctly rounded for u = 0 .. 255
 __device__ __forceinline__ float byte_over_255(uint32_t u) {
   const float x = (float)u, r = 1.0f / 255.0f;
@@ -105,6 +98,7 @@ constexpr int kK1 = 64, kK2 = 256;
 constexpr int kLdsIn = 4 * kP1 * kP1;     // 7744 floats
 constexpr int kLdsC1 = kC1 * kP2 * kP2;   // 10000
 constexpr int kLdsFloats = kLdsIn + kLdsC1;  // 17,744 floats = 70,976 B: two workgroups per CU
+constexpr int kA1Row = kLdsC1;               // floats per observation of a saved conv1 activation (the padded tile)
 
 // Both weight matrices live in registers (B operands: 16 + 128 VGPRs per lane, loaded once per
 // workgroup), so an MFMA needs one LDS gather (conv1) or half of one (conv2: both N-tiles reuse
@@ -160,12 +154,14 @@ __global__ __launch_bounds__(256) void conv12_weights_pack_kernel(const float* _
 // PACKED: `packed` holds the operand-order weights (w1 / w2 unused); otherwise w1 / w2 in the nn.Conv2d layout.  Two
 // instantiations, not a run-time branch: with both fetch sequences in one function the allocator went from 240 to 280
 // registers (24 of them AGPRs) — one wave per SIMD instead of two, 67 -> 78 us per 1024 observations.
-template <bool RING, bool PACKED>
+// SAVE (round 6, the learner's forward): the conv1 activation leaves for HBM as the zero-padded LDS tile it is
+// ([16][25][25] floats, kA1Row per observation, 16-byte copies, no index arithmetic) and the backward kernel loads it
+// instead of recomputing conv1 (conv12_bwd_u8_mfma_kernel<.., true>).
+template <bool RING, bool PACKED, bool SAVE>
 __global__ __launch_bounds__(256, 2) void conv12_u8_mfma_kernel(
     const uint8_t* __restrict__ obs, RingObs ro, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ out, int n_obs,
-    const float* __restrict__ packed) {
-  MFMA_ACC_IN_AGPRS();
+    const float* __restrict__ packed, float* __restrict__ a1_out) {
   extern __shared__ float lds[];
   float* in_pad = lds;                  // [4][44][44]
   float* c1_pad = in_pad + kLdsIn;      // [16][25][25]
@@ -252,40 +248,75 @@ __global__ __launch_bounds__(256, 2) void conv12_u8_mfma_kernel(
     C12_ABL_EXIT(3)
     // ---- conv1: 28 M-tiles of 16 positions, 7 per wave ----
     // Positions advance incrementally (a tile is 64 positions further = 3 rows + 1 column of 21; rounds 1-3 divided
-    // by 21 five times per tile), and a tile's 16 operands are all read before its MFMAs (sched_group_barrier:
-    // left alone the scheduler reads one pair ahead, 64 clocks of cover for an LDS round trip of ~130).
+    // by 21 five times per tile).  Round 6: TWO tiles per step (t and t + 4) on two accumulators — a tile's 16 MFMAs
+    // are one dependent chain (40 clocks per MFMA instead of 32, and nothing to issue while its operands are on
+    // their way): with a second, independent chain interleaved the pipe sees a back-to-back stream and one LDS wait
+    // per 32 MFMAs.  The order of a tile's sum is unchanged (bit-identical a1).
     {
       int oy = oy1, ox = ox1, ey = ey1, ex = ex1;
 #pragma unroll 1
-      for (int t = wave; t < 28; t += 4) {
-        const bool in = oy < kO1;                             // m < 441 (the last tile: clamp to the last position)
+      for (int t = wave; t < 28; t += 8) {
+        const bool two = t + 4 < 28;                          // wave-uniform (the last step of a wave: one tile)
+        int oyb = oy + 3, oxb = ox + 1;                       // tile t + 4: 64 positions further
+        if (oxb >= kO1) { oxb -= kO1; oyb += 1; }
+        int eyb = ey + 3, exb = ex + 1;
+        if (exb >= kO1) { exb -= kO1; eyb += 1; }
+        const bool in = oy < kO1, inb = oyb < kO1;            // m < 441 (the last tile: clamp to the last position)
         const float* a_base = in_pad + (2 * (in ? oy : kO1 - 1)) * kP1 + 2 * (in ? ox : kO1 - 1) + q;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* b_base = in_pad + (2 * (inb ? oyb : kO1 - 1)) * kP1 + 2 * (inb ? oxb : kO1 - 1) + q;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+        if (two) {
+          float av[16], bv[16];
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          const float a = a_base[(ks >> 2) * kP1 * kP1 + (ks & 3) * kP1];
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw1[ks], acc, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    // (ds_read2: two operands per instruction)
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-        float* crow = c1_pad + col * kP2 * kP2 + (ey + 2) * kP2 + (ex + 2);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                         // rows 4q + r of D: positions (ey, ex + r), wrapping into the next row
-          const bool w = ex + r >= kO1;
-          const int yy = ey + (w ? 1 : 0);
-          if (yy < kO1) {
-            const float v = acc[r] + bias1;
-            crow[r + (w ? kP2 - kO1 : 0)] = v > 0.f ? v : 0.f;
+          for (int ks = 0; ks < 16; ++ks) {
+            av[ks] = a_base[(ks >> 2) * kP1 * kP1 + (ks & 3) * kP1];
+            bv[ks] = b_base[(ks >> 2) * kP1 * kP1 + (ks & 3) * kP1];
           }
+          LDS_FENCE();
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bw1[ks], acc, 0, 0, 0);
+            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[ks], bw1[ks], accb, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // (ds_read2: two operands per instruction)
+          __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {
+            const float a = a_base[(ks >> 2) * kP1 * kP1 + (ks & 3) * kP1];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw1[ks], acc, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
         }
-        oy += 3; ox += 1;                                     // 64 positions further
+        auto put = [&](const f32x4& d, int ey_, int ex_) {   // rows 4q + r of D: positions (ey, ex + r), wrapping into the next row
+          float* crow = c1_pad + col * kP2 * kP2 + (ey_ + 2) * kP2 + (ex_ + 2);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool w = ex_ + r >= kO1;
+            const int yy = ey_ + (w ? 1 : 0);
+            if (yy < kO1) {
+              const float v = d[r] + bias1;
+              crow[r + (w ? kP2 - kO1 : 0)] = v > 0.f ? v : 0.f;
+            }
+          }
+        };
+        put(acc, ey, ex);
+        if (two) put(accb, eyb, exb);
+        oy += 6; ox += 2;                                     // 128 positions further = 6 rows + 2 columns
         if (ox >= kO1) { ox -= kO1; oy += 1; }
-        ey += 3; ex += 1;
+        ey += 6; ex += 2;
         if (ex >= kO1) { ex -= kO1; ey += 1; }
       }
     }
     __syncthreads();
     C12_ABL_EXIT(4)
+    if constexpr (SAVE) {   // the padded conv1 tile as it stands in LDS (borders included; the last 16 floats are border)
+      float4* d4 = reinterpret_cast<float4*>(a1_out + (size_t)n * kA1Row);
+      const float4* s4 = reinterpret_cast<const float4*>(c1_pad);
+#pragma unroll 2
+      for (int i = tid; i < kLdsC1 / 4; i += 256) d4[i] = s4[i];
+    }
     // ---- conv2: 8 M-tiles, 2 per wave, both N-tiles per A gather; D goes straight to HBM ----
     float* dst = out + (size_t)n * kC2 * kM2;
     for (int mt = wave; mt < 8; mt += 4) {
@@ -369,12 +400,17 @@ constexpr int kBwdPartial = 1040 + 8192 + 32;            // 9264 floats per work
 constexpr int kLdsBwdU8 = 4 * kP1 * kP1;                                   // 7,744 bytes = 1,936 floats
 constexpr int kLdsBwdFloats = kLdsBwdU8 / 4 + 256 + kLdsC1 + 32 * kZ2 + 384;  // 17,568 floats = 70,272 B
 
-template <bool PACKED>   // PACKED: `w1` is parlhip_atari42_conv12_weights_f32's buffer (operand order), w2 unused
+// PACKED: `w1` is parlhip_atari42_conv12_weights_f32's buffer (operand order), w2 unused.
+// HAVE_A1 (round 6): `a1` holds the forward kernel's conv1 activation as padded tiles (conv12_u8_mfma_kernel<.., SAVE>,
+// kA1Row floats per observation) and phase (1) is a 40 KB copy instead of 448 MFMAs behind two dependent LDS gathers
+// per operand — per-phase clocks of round 4 (profiles/r04_conv12_bwd_regions.log): conv1 15.9 k of 72.5 k per observation
+// and wave at 142 clocks per MFMA.  At the learner's 1000-row updates the tiles are 40 MB written and read once per
+// update; the recompute stays for callers without the buffer (and for batches where 40 KB per row would not pay).
+template <bool PACKED, bool HAVE_A1>
 __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
     const uint8_t* __restrict__ obs, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ a2, const float* __restrict__ dy,
-    float* __restrict__ partial, int n_obs) {
-  MFMA_ACC_IN_AGPRS();
+    float* __restrict__ partial, int n_obs, const float* __restrict__ a1) {
   extern __shared__ float lds[];
   uint8_t* in_u8 = reinterpret_cast<uint8_t*>(lds);   // [4][44][44] uint8, zero-padded
   float* lut = lds + kLdsBwdU8 / 4;                   // [256] (float)u / 255.0f
@@ -389,11 +425,13 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
   const int py = wave >> 1, px = wave & 1, ta = q >> 1, tb = q & 1;
   float bt[32];
   if constexpr (PACKED) {   // 4 + 8 coalesced float4 loads instead of 48 dword loads over 16 cache lines each
-    const float4* pk = reinterpret_cast<const float4*>(w1) + lane;
+    if constexpr (!HAVE_A1) {
+      const float4* pk = reinterpret_cast<const float4*>(w1) + lane;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 v = pk[g * 64];
-      bw1[4 * g] = v.x; bw1[4 * g + 1] = v.y; bw1[4 * g + 2] = v.z; bw1[4 * g + 3] = v.w;
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = pk[g * 64];
+        bw1[4 * g] = v.x; bw1[4 * g + 1] = v.y; bw1[4 * g + 2] = v.z; bw1[4 * g + 3] = v.w;
+      }
     }
     const float4* pb = reinterpret_cast<const float4*>(w1 + kPackedFwdFloats) + wave * 8 * 64 + lane;
 #pragma unroll
@@ -402,12 +440,14 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
       bt[4 * g] = v.x; bt[4 * g + 1] = v.y; bt[4 * g + 2] = v.z; bt[4 * g + 3] = v.w;
     }
   } else {
+    if constexpr (!HAVE_A1) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) bw1[ks] = w1[col * kK1 + ks * 4 + q];
+      for (int ks = 0; ks < 16; ++ks) bw1[ks] = w1[col * kK1 + ks * 4 + q];
+    }
 #pragma unroll
     for (int o = 0; o < 32; ++o) bt[o] = w2[o * kK2 + col * 16 + (py + 2 * ta) * 4 + (px + 2 * tb)];
   }
-  f32x4 acc2[2][4], acc1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc2[2][4], acc1 = {0.f, 0.f, 0.f, 0.f}, acc1b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -461,13 +501,35 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
         dz2p[o * kZ2 + oy * kZ2W + ox] = pre_a.v[j] > 0.f ? pre_d.v[j] : 0.f;
       }
     }
-    if (n + (int)gridDim.x < n_obs) {
-      const size_t nn = (size_t)n + gridDim.x;
-      if (words) pre_x.load(reinterpret_cast<const uint32_t*>(obs + nn * 4 * kD * kD), tid);
-      pre_a.load(a2 + nn * kC2 * kM2, tid);
-      pre_d.load(dy + nn * kC2 * kM2, tid);
+    // (HAVE_A1) the saved conv1 tile: 39 chunks of 1 KiB by LDS-DMA (ten per wave), no staging registers.  Issued BEHIND
+    // the other tiles' LDS stores: the backend cannot tell those stores from the DMA's destination (one dynamic LDS
+    // array) and waits for vmcnt(0) in front of the first LDS access after a DMA.  The tile's last 16 floats (channel
+    // 15, border row 24) are never written by anybody and stay zero from the initialisation.
+    if constexpr (HAVE_A1) {
+      const float* srow = a1 + (size_t)n * kA1Row + 4 * lane;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        const int c = wave + 4 * j;   // wave-uniform
+        if (c < kLdsC1 / 256) glds16(srow + 256 * c, c1_pad + 256 * c);
+      }
+    }
+    if constexpr (!HAVE_A1) {   // (with the LDS-DMA in flight the barrier's fence waits for vmcnt(0): the prefetch goes behind it)
+      if (n + (int)gridDim.x < n_obs) {
+        const size_t nn = (size_t)n + gridDim.x;
+        if (words) pre_x.load(reinterpret_cast<const uint32_t*>(obs + nn * 4 * kD * kD), tid);
+        pre_a.load(a2 + nn * kC2 * kM2, tid);
+        pre_d.load(dy + nn * kC2 * kM2, tid);
+      }
     }
     __syncthreads();
+    if constexpr (HAVE_A1) {   // the NEXT observation's inputs: in flight during (2) - (4)
+      if (n + (int)gridDim.x < n_obs) {
+        const size_t nn = (size_t)n + gridDim.x;
+        if (words) pre_x.load(reinterpret_cast<const uint32_t*>(obs + nn * 4 * kD * kD), tid);
+        pre_a.load(a2 + nn * kC2 * kM2, tid);
+        pre_d.load(dy + nn * kC2 * kM2, tid);
+      }
+    }
     CONV_REGION(1);   // fill
     // ---- (1) conv1 forward into c1_pad (operand values and order of conv12_u8_mfma_kernel) ----
     // Round 4: the phases below spent 3/4 of their time on index arithmetic, not on MFMAs (per-phase clocks of
@@ -477,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
     // loops walk ROWS padded to a multiple of 4 positions ((2): 11 -> 12, (4): 21 -> 24): the padding positions read
     // the zero borders of the dz tiles (A = 0) and any finite B, so they add exact zeros, and every LDS offset
     // inside a row is an immediate.
-    {
+    if constexpr (!HAVE_A1) {
       int oy = oy1, ox = ox1, ey = ey1, ex = ex1;             // tile t = wave: gather position / first output row of this lane
 #pragma unroll 1
       for (int t = wave; t < 28; t += 4) {
@@ -515,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
         if (ex >= kO1) { ex -= kO1; ey += 1; }
       }
     }
-    __syncthreads();
+    if constexpr (!HAVE_A1) __syncthreads();
     CONV_REGION(2);   // (1) conv1 recompute
     // ---- (2) dW2: this wave owns input channels 4*wave .. 4*wave+3 (k tiles), both o tiles ----
     // 11 rows of 12 positions (ox = 11: dz2p column 11 is zero), three k-steps per row with immediate offsets.
@@ -553,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
       for (int t = 0; t * 16 < M; ++t) {
         const bool in = iy < ny;                              // m < M (clamp to the last position)
         const float* ab = dz2p + ((in ? iy : ny - 1) + 1 - ta) * kZ2W + ((in ? ix : nx - 1) + 1 - tb);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accx = {0.f, 0.f, 0.f, 0.f};
         // the a1 values under this tile's outputs (for the ReLU mask) are read first, the A operands eight k-steps
         // ahead of their MFMAs (LDS_FENCE, see (1))
         float* pz[4];
@@ -578,7 +640,11 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
           }
           LDS_FENCE();
 #pragma unroll
-          for (int o = 0; o < 8; ++o) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][o], bt[8 * g + o], acc, 0, 0, 0);
+          for (int o = 0; o < 8; o += 2) {   // HAVE_A1: two interleaved chains (even / odd o), added below — a single chain waits 40 clocks per MFMA
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][o], bt[8 * g + o], acc, 0, 0, 0);
+            if constexpr (HAVE_A1) accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][o + 1], bt[8 * g + o + 1], accx, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][o + 1], bt[8 * g + o + 1], acc, 0, 0, 0);
+          }
         }
         // the order of the block for the scheduler: the a1 reads + the first eight A operands (ds_read2: two values
         // per instruction), then three times [the next eight operands | eight MFMAs], then the last eight MFMAs
@@ -589,6 +655,7 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
           __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        if constexpr (HAVE_A1) acc += accx;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (ok[r]) {
@@ -607,7 +674,7 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
     CONV_REGION(4);   // (3) dz1 (incl. its barrier)
     // ---- (4) dW1: this wave owns input channel `wave` (16 taps = one k tile) ----
     // 21 rows of 24 positions (x = 21 .. 23: the zero border of c1_pad / column 0 of its next row), six k-steps per
-    // row with immediate offsets; ONE accumulator (the order of the sum is the order of the positions).
+    // row with immediate offsets; two accumulators (even / odd k-steps of a row: fixed order, summed at the end).
     {
       const float* pa = c1_pad + col * kP2 * kP2 + 2 * kP2 + 2 + q;     // c1_pad[col][y + 2][4 xs + q + 2]
       const uint8_t* pb = in_u8 + wave * kP1 * kP1 + kh * kP1 + 2 * q + kw;   // in_u8[wave][2 y + kh][2 (4 xs + q) + kw]
@@ -623,13 +690,21 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
 #pragma unroll
         for (int xs = 0; xs < 6; ++xs) { na[xs] = pa[kP2 + 4 * xs]; nb[xs] = pb[2 * kP1 + 8 * xs]; }
 #pragma unroll
-        for (int xs = 0; xs < 6; ++xs) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[xs], byte_over_255(cb[xs]), acc1, 0, 0, 0);
+        for (int xs = 0; xs < 6; xs += 2) {   // two interleaved chains (even / odd k-steps of a row), added at the end
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[xs], byte_over_255(cb[xs]), acc1, 0, 0, 0);
+          if constexpr (HAVE_A1) acc1b = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[xs + 1], byte_over_255(cb[xs + 1]), acc1b, 0, 0, 0);
+          else acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[xs + 1], byte_over_255(cb[xs + 1]), acc1, 0, 0, 0);
+        }
         pa += 2 * kP2;
         pb += 4 * kP1;
 #pragma unroll
         for (int xs = 0; xs < 6; ++xs) { ca[xs] = pa[4 * xs]; cb[xs] = pb[8 * xs]; }
 #pragma unroll
-        for (int xs = 0; xs < 6; ++xs) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(na[xs], byte_over_255(nb[xs]), acc1, 0, 0, 0);
+        for (int xs = 0; xs < 6; xs += 2) {
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(na[xs], byte_over_255(nb[xs]), acc1, 0, 0, 0);
+          if constexpr (HAVE_A1) acc1b = __builtin_amdgcn_mfma_f32_16x16x4f32(na[xs + 1], byte_over_255(nb[xs + 1]), acc1b, 0, 0, 0);
+          else acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(na[xs + 1], byte_over_255(nb[xs + 1]), acc1, 0, 0, 0);
+        }
         __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);    // the order of the block for the scheduler: reads of row
         __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    // y + 1, MFMAs of row y, reads of row y + 2, MFMAs of y + 1
         __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
@@ -643,6 +718,7 @@ __global__ __launch_bounds__(256, 2) void conv12_bwd_u8_mfma_kernel(
   if (threadIdx.x == 0) atomicAdd(&g_conv_regions[15], (unsigned long long)((n_obs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x));
 #endif
   float* P = partial + (size_t)blockIdx.x * kBwdPartial;
+  if constexpr (HAVE_A1) acc1 += acc1b;   // even + odd k-steps (the two interleaved chains of (4))
 #pragma unroll
   for (int r = 0; r < 4; ++r) P[kBwdDW1 + (4 * q + r) * kK1 + 16 * wave + col] = acc1[r];
 #pragma unroll
@@ -729,7 +805,6 @@ template <bool RING, bool PACKED>
 __global__ __launch_bounds__(256, 2) void conv1_84_u8_mfma_kernel(
     const uint8_t* __restrict__ obs, RingObs ro, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, int n_obs) {
-  MFMA_ACC_IN_AGPRS();
   extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
   uint8_t* tile = lds8;                                          // [88 guard][4][84][84]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -866,7 +941,6 @@ __global__ __launch_bounds__(256) void conv23_84_mfma_kernel(
     const float* __restrict__ a1, const float* __restrict__ wt2, const float* __restrict__ b2,
     const float* __restrict__ wt3, const float* __restrict__ b3, float* __restrict__ a2_out,
     float* __restrict__ a3_out, int n_obs) {
-  MFMA_ACC_IN_AGPRS();
   extern __shared__ float lds[];
   float* a1p = lds;                       // [8][24][24]: one quarter of a1's channels at a time
   float* a2s = lds + kA1Q * kA1Plane;     // [64][121]
@@ -1022,7 +1096,6 @@ constexpr int kPart3 = 64 * 576 + 64;                                  // dW3 [o
 __global__ __launch_bounds__(256) void conv3_84_bwd_kernel(
     const float* __restrict__ a2, const float* __restrict__ a3, const float* __restrict__ dy3,
     const float* __restrict__ wt3b, float* __restrict__ dz2, float* __restrict__ partial, int n_obs) {
-  MFMA_ACC_IN_AGPRS();
   extern __shared__ float lds[];
   float* a2s = lds;                         // [64][121]
   float* z3p = lds + 64 * kM2b;             // [64][13][13], zero border
@@ -1177,7 +1250,6 @@ constexpr int kPart2 = 64 * 512 + 64;
 __global__ __launch_bounds__(256) void conv2_84_bwd_kernel(
     const float* __restrict__ a1, const float* __restrict__ dz2, const float* __restrict__ wt2b,
     float* __restrict__ dz1, float* __restrict__ partial, int n_obs) {
-  MFMA_ACC_IN_AGPRS();
   extern __shared__ float lds[];
   float* a1p = lds;                       // [32][24][24], zero border
   float* z2s = lds + 32 * kA1Plane;       // [64][11][11]
@@ -1322,7 +1394,6 @@ constexpr int kPart1 = 32 * 256 + 32;
 
 __global__ __launch_bounds__(256, 2) void conv1_84_bwd_kernel(
     const uint8_t* __restrict__ obs, const float* __restrict__ dz1, float* __restrict__ partial, int n_obs) {
-  MFMA_ACC_IN_AGPRS();
   extern __shared__ float lds[];
   uint8_t* tile = reinterpret_cast<uint8_t*>(lds);        // [4][84][84] uint8, shifted by the padding
   float* lut = lds + kPlane84;                            // [256]
@@ -1439,12 +1510,14 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restric
 using namespace parlhip;
 
 static int launch_conv12(const uint8_t* obs, const RingObs& ro, const float* w1, const float* b1, const float* w2,
-                         const float* b2, float* out, int n_obs, const float* packed, hipStream_t stream) {
+                         const float* b2, float* out, int n_obs, const float* packed, hipStream_t stream,
+                         float* a1_out = nullptr) {
   const size_t lds_bytes = kLdsFloats * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    const void* fns[4] = {(const void*)conv12_u8_mfma_kernel<false, false>, (const void*)conv12_u8_mfma_kernel<false, true>,
-                          (const void*)conv12_u8_mfma_kernel<true, false>, (const void*)conv12_u8_mfma_kernel<true, true>};
+    const void* fns[5] = {(const void*)conv12_u8_mfma_kernel<false, false, false>, (const void*)conv12_u8_mfma_kernel<false, true, false>,
+                          (const void*)conv12_u8_mfma_kernel<true, false, false>, (const void*)conv12_u8_mfma_kernel<true, true, false>,
+                          (const void*)conv12_u8_mfma_kernel<false, true, true>};
     for (const void* f : fns) {
       int rc = check(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       if (rc) return rc;
@@ -1452,13 +1525,17 @@ static int launch_conv12(const uint8_t* obs, const RingObs& ro, const float* w1,
     attr_set = true;
   }
   const int grid = n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU;  // 71 KB of LDS: two workgroups per CU
-#define PARLHIP_C12(R, P, O, RO) conv12_u8_mfma_kernel<R, P><<<grid, 256, lds_bytes, stream>>>(O, RO, w1, b1, w2, b2, out, n_obs, packed)
-  if (ro.ring) {
-    if (packed) PARLHIP_C12(true, true, nullptr, ro);
-    else PARLHIP_C12(true, false, nullptr, ro);
+#define PARLHIP_C12(R, P, S, O, RO) \
+  conv12_u8_mfma_kernel<R, P, S><<<grid, 256, lds_bytes, stream>>>(O, RO, w1, b1, w2, b2, out, n_obs, packed, a1_out)
+  if (a1_out) {
+    if (ro.ring || !packed) return PARLHIP_EINVAL;
+    PARLHIP_C12(false, true, true, obs, RingObs{});
+  } else if (ro.ring) {
+    if (packed) PARLHIP_C12(true, true, false, nullptr, ro);
+    else PARLHIP_C12(true, false, false, nullptr, ro);
   } else {
-    if (packed) PARLHIP_C12(false, true, obs, RingObs{});
-    else PARLHIP_C12(false, false, obs, RingObs{});
+    if (packed) PARLHIP_C12(false, true, false, obs, RingObs{});
+    else PARLHIP_C12(false, false, false, obs, RingObs{});
   }
 #undef PARLHIP_C12
   return check_launch();
@@ -1502,6 +1579,20 @@ PARLHIP_EXPORT int parlhip_atari42_conv12_packed_u8_f32(const uint8_t* obs, cons
   if (!obs || !packed || !b1 || !b2 || !out) return PARLHIP_EINVAL;
   if (reinterpret_cast<uintptr_t>(packed) & 15) return PARLHIP_EINVAL;
   return launch_conv12(obs, RingObs{}, nullptr, b1, nullptr, b2, out, n_obs, packed, (hipStream_t)stream);
+}
+
+PARLHIP_EXPORT size_t parlhip_atari42_conv12_a1_bytes(int n_obs) {
+  return n_obs <= 0 ? 0 : (size_t)n_obs * kA1Row * sizeof(float);
+}
+
+PARLHIP_EXPORT int parlhip_atari42_conv12_packed_save_u8_f32(const uint8_t* obs, const float* packed, const float* b1,
+                                                             const float* b2, float* out, float* a1_out, int n_obs,
+                                                             parlhip_stream_t stream) {
+  if (n_obs < 0) return PARLHIP_EINVAL;
+  if (n_obs == 0) return PARLHIP_OK;
+  if (!obs || !packed || !b1 || !b2 || !out || !a1_out) return PARLHIP_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(a1_out)) & 15) return PARLHIP_EINVAL;
+  return launch_conv12(obs, RingObs{}, nullptr, b1, nullptr, b2, out, n_obs, packed, (hipStream_t)stream, a1_out);
 }
 
 PARLHIP_EXPORT int parlhip_atari42_conv12_ring_packed_u8_f32(const uint8_t* ring, const uint8_t* since, int num_slots,
@@ -1593,7 +1684,7 @@ PARLHIP_EXPORT size_t parlhip_atari42_conv12_bwd_workspace_bytes(int n_obs) {
 
 static int launch_conv12_bwd(const uint8_t* obs, const float* w1_or_packed, const float* b1, const float* w2,
                              const float* a2, const float* dy, int n_obs, float* workspace, float* dw1, float* db1,
-                             float* dw2, float* db2, bool packed, hipStream_t s) {
+                             float* dw2, float* db2, bool packed, hipStream_t s, const float* a1 = nullptr) {
   if (n_obs < 0) return PARLHIP_EINVAL;
   if (!dw1 || !db1 || !dw2 || !db2) return PARLHIP_EINVAL;
   if (n_obs == 0) {
@@ -1607,18 +1698,20 @@ static int launch_conv12_bwd(const uint8_t* obs, const float* w1_or_packed, cons
   if (packed && (reinterpret_cast<uintptr_t>(w1_or_packed) & 15)) return PARLHIP_EINVAL;
   static bool attr_set = false;
   const size_t lds_bytes = kLdsBwdFloats * sizeof(float);
+  if (a1 && (!packed || (reinterpret_cast<uintptr_t>(a1) & 15))) return PARLHIP_EINVAL;
   if (!attr_set) {
-    int rc = check(hipFuncSetAttribute((const void*)conv12_bwd_u8_mfma_kernel<false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    if (rc) return rc;
-    rc = check(hipFuncSetAttribute((const void*)conv12_bwd_u8_mfma_kernel<true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    if (rc) return rc;
+    const void* fns[3] = {(const void*)conv12_bwd_u8_mfma_kernel<false, false>, (const void*)conv12_bwd_u8_mfma_kernel<true, false>,
+                          (const void*)conv12_bwd_u8_mfma_kernel<true, true>};
+    for (const void* f : fns) {
+      int rc = check(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      if (rc) return rc;
+    }
     attr_set = true;
   }
   const int grid = conv12_bwd_grid(n_obs);
-  if (packed) conv12_bwd_u8_mfma_kernel<true><<<grid, 256, lds_bytes, s>>>(obs, w1_or_packed, b1, nullptr, a2, dy, workspace, n_obs);
-  else conv12_bwd_u8_mfma_kernel<false><<<grid, 256, lds_bytes, s>>>(obs, w1_or_packed, b1, w2, a2, dy, workspace, n_obs);
+  if (a1) conv12_bwd_u8_mfma_kernel<true, true><<<grid, 256, lds_bytes, s>>>(obs, w1_or_packed, b1, nullptr, a2, dy, workspace, n_obs, a1);
+  else if (packed) conv12_bwd_u8_mfma_kernel<true, false><<<grid, 256, lds_bytes, s>>>(obs, w1_or_packed, b1, nullptr, a2, dy, workspace, n_obs, nullptr);
+  else conv12_bwd_u8_mfma_kernel<false, false><<<grid, 256, lds_bytes, s>>>(obs, w1_or_packed, b1, w2, a2, dy, workspace, n_obs, nullptr);
   int rc = check_launch();
   if (rc) return rc;
   conv12_bwd_reduce_kernel<<<(kBwdPartial + 15) / 16, 256, 0, s>>>(workspace, grid, dw1, db1, dw2, db2);
@@ -1638,6 +1731,15 @@ PARLHIP_EXPORT int parlhip_atari42_conv12_bwd_packed_f32(const uint8_t* obs, con
                                                          float* db2, parlhip_stream_t stream) {
   return launch_conv12_bwd(obs, packed, b1, nullptr, a2, dy, n_obs, workspace, dw1, db1, dw2, db2, true,
                            (hipStream_t)stream);
+}
+
+PARLHIP_EXPORT int parlhip_atari42_conv12_bwd_saved_f32(const uint8_t* obs, const float* packed, const float* b1,
+                                                        const float* a1, const float* a2, const float* dy, int n_obs,
+                                                        float* workspace, float* dw1, float* db1, float* dw2,
+                                                        float* db2, parlhip_stream_t stream) {
+  if (n_obs > 0 && !a1) return PARLHIP_EINVAL;
+  return launch_conv12_bwd(obs, packed, b1, nullptr, a2, dy, n_obs, workspace, dw1, db1, dw2, db2, true,
+                           (hipStream_t)stream, a1);
 }
 
 PARLHIP_EXPORT int parlhip_atari84_conv23_f32(const float* a1, const float* wt2, const float* b2, const float* wt3,

@@ -129,6 +129,7 @@ class FlatGradAllReduce(object):
         self.params = [p for p in model.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.params[0].device)
+        self._shared = None   # SharedDeviceAllReduce when the ranks share one GPU (decided at the first call)
         off = 0
         self.views = []
         for p in self.params:
@@ -150,9 +151,66 @@ class FlatGradAllReduce(object):
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
                 p.grad = v
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if self._shared is None:
+            self._shared = SharedDeviceAllReduce.create(self.flat) or False
+        if self._shared:
+            self._shared(self.flat)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         if self.average:
             self.flat.div_(world_size())
+
+
+class SharedDeviceAllReduce(object):
+    """SUM all-reduce for ranks that SHARE one GPU (PARL_AMD_SHARE_GPU: a test box with fewer devices than ranks, where
+    RCCL cannot be used — it refuses two ranks on one device — and gloo stages every 4 MB bucket through the host:
+    ~25 updates/s, too few to see a data-parallel run learn).  Every rank owns two device slots of the bucket's size and
+    opens its peers' slots through HIP IPC (torch's CUDA tensor sharing; dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0).
+    One call: copy the bucket into my slot of this call's parity -> wait for the copy on the host -> gloo barrier
+    (every rank's slot is complete) -> bucket = slot of rank 0 + slot of rank 1 + ... in rank order on the device
+    (the same order on every rank: bit-identical replicas).  The other parity is written by the next call, and a slot
+    is rewritten only two barriers later, when every peer's sum of it has long been waited for.  Functional
+    infrastructure for one-GPU tests of the data-parallel path, not a scaling path (one host wait per update)."""
+
+    @staticmethod
+    def create(flat):
+        if not (active() and os.environ.get('PARL_AMD_SHARE_GPU') and flat.is_cuda and dist.get_backend() == 'gloo'
+                and os.environ.get('PARL_AMD_SHARED_ALLREDUCE', '1') != '0'):
+            return None
+        try:
+            return SharedDeviceAllReduce(flat)
+        except Exception as e:   # noqa: BLE001 (IPC not available: gloo's own all-reduce takes over, all ranks alike)
+            import warnings
+            warnings.warn('shared-device all-reduce unavailable (%s: %s); using gloo' % (type(e).__name__, e))
+            return None
+
+    def __init__(self, flat):
+        from torch.multiprocessing.reductions import reduce_tensor
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.mine = torch.zeros((2, flat.numel()), dtype=flat.dtype, device=flat.device)
+        torch.cuda.synchronize(flat.device)
+        handles = [None] * self.world
+        ok = True
+        try:
+            mine = reduce_tensor(self.mine)
+        except Exception:   # noqa: BLE001
+            mine, ok = None, False
+        dist.all_gather_object(handles, mine)
+        if not ok or any(h is None for h in handles):   # every rank takes the same decision
+            raise RuntimeError('a rank could not export its slots')
+        self.slots = [self.mine if r == self.rank else handles[r][0](*handles[r][1]) for r in range(self.world)]
+        self.parity = 0
+        dist.barrier()
+
+    def __call__(self, flat):
+        p = self.parity
+        self.mine[p].copy_(flat)
+        torch.cuda.current_stream(flat.device).synchronize()
+        dist.barrier()
+        flat.copy_(self.slots[0][p])
+        for r in range(1, self.world):
+            flat.add_(self.slots[r][p])
+        self.parity = p ^ 1
 
 
 _gather_bufs = {}

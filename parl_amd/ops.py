@@ -5,6 +5,8 @@ torch's current stream and returns torch tensors.  Nothing here computes on the 
 nothing falls back: a CPU tensor or a missing library raises ``ParlHipError``/``ImportError``.
 """
 
+import os
+
 import torch
 
 from . import _native as N
@@ -472,11 +474,16 @@ def atari42_conv12_pack(conv1_weight, conv2_weight, out=None):
     return out
 
 
-def atari42_conv12(obs, conv1_weight, conv1_bias, conv2_weight, conv2_bias, out=None, packed=None):
+A1_SAVE_MAX_ROWS = 8192   # rows up to which the learner's forward keeps the conv1 activation (40 KB per row) for its backward
+
+
+def atari42_conv12(obs, conv1_weight, conv1_bias, conv2_weight, conv2_bias, out=None, packed=None, save_a1=False):
     """conv1 + ReLU + conv2 + ReLU of the IMPALA Atari network (examples/IMPALA/atari_model.py:59-71)
     for uint8 observations [n,4,42,42], as ONE fused MFMA kernel (inference only).  Returns f32
     [n, 3872] = the NCHW-flattened [n,32,11,11] activation.  `obs` may be a RingObservation (the actors' step).
-    packed: atari42_conv12_pack(conv1_weight, conv2_weight) of the CURRENT weights (same result, faster start)."""
+    packed: atari42_conv12_pack(conv1_weight, conv2_weight) of the CURRENT weights (same result, faster start).
+    save_a1 (needs `packed`, a materialised obs): returns (out, a1) with a1 f32 [n, 10000] = every observation's
+    zero-padded conv1 tile, for atari42_conv12_backward(a1=...) — the learner's pair (parlhip_atari42_conv12_packed_save_u8_f32)."""
     if tuple(conv1_weight.shape) != (16, 4, 4, 4) or tuple(conv2_weight.shape) != (32, 16, 4, 4):
         raise N.ParlHipError('atari42_conv12: weights must be [16,4,4,4] and [32,16,4,4]')
     if packed is not None and (packed.dtype != torch.float32 or not packed.is_contiguous() or
@@ -486,6 +493,8 @@ def atari42_conv12(obs, conv1_weight, conv1_bias, conv2_weight, conv2_bias, out=
     if isinstance(obs, RingObservation):
         if obs.dim != 42:
             raise N.ParlHipError('atari42_conv12: a 42x42 ring')
+        if save_a1:
+            raise N.ParlHipError('atari42_conv12: save_a1 is the learner\'s form (a materialised batch)')
         S, E = obs.ring.shape[0], obs.ring.shape[1]
         if out is None:
             out = torch.empty((E, 32 * 11 * 11), dtype=torch.float32, device=obs.device)
@@ -507,6 +516,15 @@ def atari42_conv12(obs, conv1_weight, conv1_bias, conv2_weight, conv2_bias, out=
     n = obs.shape[0]
     if out is None:
         out = torch.empty((n, 32 * 11 * 11), dtype=torch.float32, device=obs.device)
+    if save_a1:
+        if packed is None:
+            raise N.ParlHipError('atari42_conv12: save_a1 needs the packed weights')
+        a1 = torch.empty((n, N.lib().parlhip_atari42_conv12_a1_bytes(1) // 4), dtype=torch.float32, device=obs.device)
+        N.check(
+            N.lib().parlhip_atari42_conv12_packed_save_u8_f32(N.ptr(obs.contiguous()), N.ptr(packed), N.ptr(b1), N.ptr(b2),
+                                                             N.ptr(out), N.ptr(a1), n, N.stream_ptr()),
+            'parlhip_atari42_conv12_packed_save_u8_f32')
+        return out, a1
     if packed is not None:
         N.check(
             N.lib().parlhip_atari42_conv12_packed_u8_f32(N.ptr(obs.contiguous()), N.ptr(packed), N.ptr(b1), N.ptr(b2),
@@ -520,10 +538,11 @@ def atari42_conv12(obs, conv1_weight, conv1_bias, conv2_weight, conv2_bias, out=
     return out
 
 
-def atari42_conv12_backward(obs, conv1_weight, conv1_bias, conv2_weight, a2, grad_a2, packed=None):
+def atari42_conv12_backward(obs, conv1_weight, conv1_bias, conv2_weight, a2, grad_a2, packed=None, a1=None):
     """Gradient of atari42_conv12 w.r.t. its four parameters given its output a2 [n,3872] and
     d loss / d a2 (the learner side of examples/IMPALA/atari_model.py:59-71; the observations get
-    no gradient).  conv1 is recomputed inside the kernel; deterministic.  Returns
+    no gradient).  conv1 is recomputed inside the kernel — or, with `a1` (the forward's save_a1 output, needs
+    `packed`), read back; deterministic.  Returns
     (d conv1_weight [16,4,4,4], d conv1_bias [16], d conv2_weight [32,16,4,4], d conv2_bias [32])."""
     if obs.dtype != torch.uint8 or obs.dim() != 4 or tuple(obs.shape[1:]) != (4, 42, 42):
         raise N.ParlHipError('atari42_conv12_backward: obs must be uint8 [n,4,42,42]')
@@ -540,6 +559,16 @@ def atari42_conv12_backward(obs, conv1_weight, conv1_bias, conv2_weight, a2, gra
     ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=dev)
     w1, b1 = _f32(conv1_weight.detach(), 'conv1_weight'), _f32(conv1_bias.detach(), 'conv1_bias')
     w2 = _f32(conv2_weight.detach(), 'conv2_weight')
+    if a1 is not None:
+        if packed is None or a1.dtype != torch.float32 or not a1.is_contiguous() or \
+                a1.numel() * 4 != N.lib().parlhip_atari42_conv12_a1_bytes(n):
+            raise N.ParlHipError('atari42_conv12_backward: a1 must be the forward\'s save_a1 output (and needs `packed`)')
+        N.check(
+            N.lib().parlhip_atari42_conv12_bwd_saved_f32(N.ptr(obs.contiguous()), N.ptr(packed), N.ptr(b1), N.ptr(a1),
+                                                        N.ptr(a2), N.ptr(grad_a2), n, N.ptr(ws), N.ptr(dw1), N.ptr(db1),
+                                                        N.ptr(dw2), N.ptr(db2), N.stream_ptr()),
+            'parlhip_atari42_conv12_bwd_saved_f32')
+        return dw1, db1, dw2, db2
     if packed is not None:   # atari42_conv12_pack of the weights the forward ran with (they have not changed since)
         N.check(
             N.lib().parlhip_atari42_conv12_bwd_packed_f32(N.ptr(obs.contiguous()), N.ptr(packed), N.ptr(b1), N.ptr(a2),
@@ -563,15 +592,22 @@ class Atari42Conv12Fn(torch.autograd.Function):
         # the learner's weights change with every update: the operand-order copy is made per call (one 9,216-thread
         # launch, also inside a captured update) — cheaper than fetching the operands scattered in every workgroup
         pk = atari42_conv12_pack(w1, w2) if obs.shape[0] >= 256 else None
-        a2 = atari42_conv12(obs, w1, b1, w2, b2, packed=pk)
+        # batches of the reference's learner size keep the conv1 activation (40 KB per row) for the backward kernel,
+        # which then loads it instead of recomputing conv1; a whole-rollout pass (51,200 rows = 2 GB) recomputes
+        save = pk is not None and obs.shape[0] <= A1_SAVE_MAX_ROWS and os.environ.get('PARL_AMD_SAVE_A1', '1') != '0'
+        if save:
+            a2, a1 = atari42_conv12(obs, w1, b1, w2, b2, packed=pk, save_a1=True)
+        else:
+            a2, a1 = atari42_conv12(obs, w1, b1, w2, b2, packed=pk), None
         ctx.save_for_backward(obs, w1, b1, w2, a2)
-        ctx.packed = pk   # (not a saved tensor: an internal buffer nobody else writes)
+        ctx.packed, ctx.a1 = pk, a1   # (not saved tensors: internal buffers nobody else writes)
         return a2
 
     @staticmethod
     def backward(ctx, grad_a2):
         obs, w1, b1, w2, a2 = ctx.saved_tensors
-        dw1, db1, dw2, db2 = atari42_conv12_backward(obs, w1, b1, w2, a2, grad_a2, packed=ctx.packed)
+        dw1, db1, dw2, db2 = atari42_conv12_backward(obs, w1, b1, w2, a2, grad_a2, packed=ctx.packed, a1=ctx.a1)
+        ctx.a1 = None
         return None, dw1, db1, dw2, db2
 
 

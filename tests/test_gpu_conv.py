@@ -196,6 +196,62 @@ def test_conv12_backward_matches_fp64_autograd(dev, n):
         assert err <= 1e-5 * scale * max(1.0, (n / 64.0) ** 0.5), (name, err, scale)
 
 
+@pytest.mark.parametrize('n', [1, 5, 300, 1100])
+def test_conv12_saved_activation_pair(dev, n):
+    """The learner's pair of round 6 (parlhip_atari42_conv12_packed_save_u8_f32 / parlhip_atari42_conv12_bwd_saved_f32):
+    the forward's `out` is bit-identical to the plain forward, its saved a1 is the zero-padded relu(conv1) tile (against
+    fp64 torch, 1e-5 of scale, borders exactly zero), and the backward that reads a1 back instead of recomputing conv1
+    gives the fp64 autograd gradients at the tolerance of the recompute kernel, run-to-run bit-identical, and equal to
+    the recompute kernel's up to the order of two sums."""
+    from parl_amd import ops
+    g = torch.Generator().manual_seed(400 + n)
+    dy = torch.randn(n, 3872, generator=g)
+    if n <= 8:
+        for _ in range(20):
+            obs = torch.randint(0, 256, (n, 4, 42, 42), generator=g, dtype=torch.uint8)
+            obs[0, :, :5] = 0
+            w1 = torch.randn(16, 4, 4, 4, generator=g) * 0.2
+            b1 = torch.randn(16, generator=g) * 0.1
+            w2 = torch.randn(32, 16, 4, 4, generator=g) * 0.1
+            b2 = torch.randn(32, generator=g) * 0.1
+            z1 = F.conv2d(obs.double() / 255.0, w1.double(), b1.double(), stride=2, padding=1)
+            z2 = F.conv2d(F.relu(z1), w2.double(), b2.double(), stride=2, padding=2)
+            if float(z1.abs().min()) > 2e-6 and float(z2.abs().min()) > 2e-6:
+                break
+        else:
+            pytest.fail('no tie-free draw')
+    else:   # tie-free by construction (see test_conv12_backward_matches_fp64_autograd)
+        obs = torch.randint(0, 2, (n, 4, 42, 42), generator=g, dtype=torch.uint8) * 255
+        w1 = torch.randint(-12, 13, (16, 4, 4, 4), generator=g).float() / 64.0
+        b1 = (2 * torch.randint(-8, 8, (16, ), generator=g).float() + 1) / 128.0
+        w2 = torch.randint(-6, 7, (32, 16, 4, 4), generator=g).float() / 64.0
+        b2 = (2 * torch.randint(-64, 64, (32, ), generator=g).float() + 1) / 16384.0
+    d = [t.to(dev) for t in (obs, w1, b1, w2, b2)]
+    pk = ops.atari42_conv12_pack(d[1], d[3])
+    plain = ops.atari42_conv12(*d, packed=pk)
+    a2, a1 = ops.atari42_conv12(*d, packed=pk, save_a1=True)
+    assert torch.equal(a2, plain) and a1.shape == (n, 10000)
+    ref1 = F.pad(F.relu(F.conv2d(obs.double() / 255.0, w1.double(), b1.double(), stride=2, padding=1)), (2, 2, 2, 2))
+    t = a1.view(n, 16, 25, 25).cpu().double()
+    assert float((t - ref1).abs().max()) <= 1e-5 * float(ref1.abs().max())
+    border = torch.ones(25, 25, dtype=torch.bool)
+    border[2:23, 2:23] = False
+    assert float(t[:, :, border].abs().max()) == 0.0
+    got = ops.atari42_conv12_backward(d[0], d[1], d[2], d[3], a2, dy.to(dev), packed=pk, a1=a1)
+    again = ops.atari42_conv12_backward(d[0], d[1], d[2], d[3], a2, dy.to(dev), packed=pk, a1=a1)
+    recompute = ops.atari42_conv12_backward(d[0], d[1], d[2], d[3], a2, dy.to(dev), packed=pk)
+    ref = _ref_grads(obs, w1, b1, w2, b2, dy)
+    for name, a, b, c, r in zip(('dw1', 'db1', 'dw2', 'db2'), got, again, recompute, ref):
+        assert torch.equal(a, b), name + ': not deterministic'
+        scale = float(r.abs().max())
+        err = float((a.cpu().double() - r).abs().max())
+        assert err <= 1e-5 * scale * max(1.0, (n / 64.0) ** 0.5), (name, err, scale)
+        assert float((a - c).abs().max()) <= 2e-5 * scale * max(1.0, (n / 64.0) ** 0.5), name
+    assert torch.equal(got[2], recompute[2]) and torch.equal(got[3], recompute[3])   # dW2 / db2: the same sums in the same order
+    with pytest.raises(Exception):
+        ops.atari42_conv12_backward(d[0], d[1], d[2], d[3], a2, dy.to(dev), packed=pk, a1=a1[:, :9999].contiguous())
+
+
 def test_conv12_backward_one_hot_gradient_selects_single_taps(dev):
     """dy = one-hot at (o, oy, ox): dW2[o] must be exactly the a1 patch under that output (zero
     elsewhere) and db2 = e_o — checks the gather arithmetic of (2) without summation noise."""

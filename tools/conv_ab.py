@@ -42,15 +42,23 @@ def main():
     pk = ops.atari42_conv12_pack(w1, w2)
     f12 = 2.0 * (441 * 16 * 64 + 121 * 32 * 256)
     b12 = 2.0 * 16 * 2812 * 64          # issued MFMA work of the backward kernel per observation (16*16*4 FMAs each)
-    for n in (1000, 1024, 51200):
+    for n in (1000, 1024, 8000, 51200):
         obs = torch.randint(0, 256, (n, 4, 42, 42), dtype=torch.uint8, device=dev)
         out = torch.empty((n, 3872), device=dev)
         row('conv12 forward, %d rows' % n, ev(lambda: ops.atari42_conv12(obs, w1, b1, w2, b2, out=out, packed=pk)), n * f12)
         if n != 1024:
             a2 = ops.atari42_conv12(obs, w1, b1, w2, b2, packed=pk)
             dy = torch.randn_like(a2)
-            row('conv12 backward, %d rows' % n, ev(lambda: ops.atari42_conv12_backward(obs, w1, b1, w2, a2, dy, packed=pk)),
-                n * b12)
+            row('conv12 backward (recompute), %d rows' % n,
+                ev(lambda: ops.atari42_conv12_backward(obs, w1, b1, w2, a2, dy, packed=pk)), n * b12)
+            if n <= 8192 and hasattr(ops, 'A1_SAVE_MAX_ROWS'):
+                a1 = torch.empty((n, 10000), device=dev)
+                row('conv12 forward + a1 saved, %d rows' % n,
+                    ev(lambda: ops.atari42_conv12(obs, w1, b1, w2, b2, out=out, packed=pk, save_a1=True)), n * f12)
+                _, a1 = ops.atari42_conv12(obs, w1, b1, w2, b2, packed=pk, save_a1=True)
+                row('conv12 backward (a1 read back), %d rows' % n,
+                    ev(lambda: ops.atari42_conv12_backward(obs, w1, b1, w2, a2, dy, packed=pk, a1=a1)),
+                    n * 2.0 * 16 * (2812 - 448) * 64)
         del obs, out
     # ---- the 84x84 network (examples/A2C/atari_model.py) ----
     c1w, c1b = torch.randn(32, 4, 8, 8, device=dev) * 0.05, torch.randn(32, device=dev) * 0.1

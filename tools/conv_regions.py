@@ -22,16 +22,23 @@ if __name__ == '__main__':
     w1, b1 = torch.randn(16, 4, 4, 4, device=dev) * 0.2, torch.randn(16, device=dev) * 0.1
     w2, b2 = torch.randn(32, 16, 4, 4, device=dev) * 0.1, torch.randn(32, device=dev) * 0.1
     out = torch.empty((n, 3872), device=dev)
-    ops.atari42_conv12(obs, w1, b1, w2, b2, out=out)
+    saved = len(sys.argv) > 2 and sys.argv[2] == 'a1'   # the round-6 pair: conv1 saved by the forward, read back here
+    pk = ops.atari42_conv12_pack(w1, w2)
+    a1 = None
+    if saved:
+        _, a1 = ops.atari42_conv12(obs, w1, b1, w2, b2, out=out, packed=pk, save_a1=True)
+    else:
+        ops.atari42_conv12(obs, w1, b1, w2, b2, out=out, packed=pk)
     dy = torch.randn((n, 3872), device=dev)
     buf = np.zeros(16, np.uint64)
     for it in range(3):
         torch.cuda.synchronize()
         f(buf.ctypes.data, 1)
-        ops.atari42_conv12_backward(obs, w1, b1, w2, out, dy)
+        ops.atari42_conv12_backward(obs, w1, b1, w2, out, dy, packed=pk, a1=a1)
         torch.cuda.synchronize()
         f(buf.ctypes.data, 0)
-    names = ['barrier at the top', 'fill', '(1) conv1 recompute', '(2) dW2', '(3) dz1', '(4) dW1']
+    names = ['barrier at the top', 'fill', '(1) conv1 recompute' if not saved else '(1) -', '(2) dW2', '(3) dz1', '(4) dW1']
+    print('a1 read back' if saved else 'conv1 recomputed')
     nobs = float(buf[15])
     tot = float(buf[:6].sum())
     print('conv12_bwd n=%d: %.0f clocks per observation (wave 0 of each workgroup)' % (n, tot / nobs))

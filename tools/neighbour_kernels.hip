@@ -334,19 +334,52 @@ __global__ __launch_bounds__(256, 2) void neighbour_kernel(float* sink, int iter
   if (acc == 123.456f) sink[tid] = acc;
 }
 
-// Clock probe: one wave per workgroup runs a fixed dependent VALU chain and reads both counters around it: s_memtime
-// (shader clock ticks) and s_memrealtime (constant 100 MHz).  ticks / realtime = the EFFECTIVE shader clock while the
-// chain ran (rocm-smi shows the PLL target, not what droop / di-dt mitigation makes of it); ticks per iteration = how
-// much of the SIMD the wave got.  out[3 b .. 3 b + 2] = (ticks, realtime ticks, XCC_ID / CU id bits) of workgroup b.
-__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, int iters, float* sink) {
+// Probes: one wave per workgroup runs a fixed DEPENDENT chain of one instruction class and reads both counters around it:
+// s_memtime (shader clock ticks) and s_memrealtime (constant 100 MHz).  ticks / realtime = the EFFECTIVE shader clock
+// while the chain ran (rocm-smi shows the PLL target, not what droop / di-dt mitigation makes of it); ticks per step =
+// how that instruction class fares beside the neighbour.  KIND 0: VALU FMAs; 1: SALU adds; 2: LDS pointer chase
+// (ds_read_b32 -> address); 3: scalar-cache pointer chase (s_load_dword -> address); 4: VALU + a taken branch per
+// step.  PRIO: s_setprio of the probe (the emulator runs at 3).  out[3 b .. 3 b + 2] = (ticks, realtime, HW_ID).
+template <int KIND, int PRIO>
+__global__ __launch_bounds__(64) void probe_kernel(unsigned long long* out, int iters, float* sink, const int* chase) {
+  __shared__ int ring[256];
+  __builtin_amdgcn_s_setprio(PRIO);
+  ring[threadIdx.x] = (threadIdx.x * 4 + 68) & 1020;          // byte offset of the next element: a 256-element cycle
+  ring[threadIdx.x + 64] = ((threadIdx.x + 64) * 4 + 68) & 1020;
+  ring[threadIdx.x + 128] = ((threadIdx.x + 128) * 4 + 68) & 1020;
+  ring[threadIdx.x + 192] = ((threadIdx.x + 192) * 4 + 68) & 1020;
+  __syncthreads();
   float x = (float)threadIdx.x;
+  int si = iters, li = (int)threadIdx.x * 4;
   const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   const unsigned long long t0 = __builtin_readcyclecounter();
-  for (int i = 0; i < iters; ++i) {
+  if (KIND == 0) {
+    for (int i = 0; i < iters; ++i) {
 #pragma unroll
-    for (int k = 0; k < 64; ++k) x = __builtin_fmaf(x, 1.0001f, 0.25f);
+      for (int k = 0; k < 64; ++k) x = __builtin_fmaf(x, 1.0001f, 0.25f);
+    }
+  } else if (KIND == 1) {
+    for (int i = 0; i < iters; ++i) {
+      asm volatile(".rept 64\n s_add_i32 %0, %0, 3\n s_xor_b32 %0, %0, 5\n .endr" : "+s"(si));
+    }
+  } else if (KIND == 2) {
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) li = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(ring) + li);
+    }
+  } else if (KIND == 3) {
+    int off = 0;   // the table holds BYTE offsets of the next element
+    for (int i = 0; i < iters; ++i) {
+      asm volatile(".rept 8\n s_load_dword %0, %1, %0\n s_waitcnt lgkmcnt(0)\n .endr" : "+s"(off) : "s"(chase));
+    }
+    si = off;
+  } else {
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll 1
+      for (int k = 0; k < 32; ++k) { x = __builtin_fmaf(x, 1.0001f, 0.25f); asm volatile("" : "+v"(x)); }
+    }
   }
-  asm volatile("" : "+v"(x));
+  asm volatile("" : "+v"(x), "+s"(si), "+v"(li));
   const unsigned long long t1 = __builtin_readcyclecounter();
   const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
   if (threadIdx.x == 0) {
@@ -354,11 +387,19 @@ __global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out
     out[3 * blockIdx.x + 1] = r1 - r0;
     out[3 * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
   }
-  if (x == 123.456f) sink[threadIdx.x] = x;
+  if (x == 123.456f || si == 123457 || li == -7) sink[threadIdx.x] = x;
 }
 
-extern "C" int clock_probe_launch(unsigned long long* out, int iters, int grid, float* sink, void* stream) {
-  clock_probe_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(out, iters, sink);
+extern "C" int probe_launch(int kind, int prio, unsigned long long* out, int iters, int grid, float* sink, const int* chase,
+                            void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+#define PK(K, P) probe_kernel<K, P><<<grid, 64, 0, s>>>(out, iters, sink, chase)
+  if (prio == 0) {
+    if (kind == 0) PK(0, 0); else if (kind == 1) PK(1, 0); else if (kind == 2) PK(2, 0); else if (kind == 3) PK(3, 0); else PK(4, 0);
+  } else {
+    if (kind == 0) PK(0, 3); else if (kind == 1) PK(1, 3); else if (kind == 2) PK(2, 3); else if (kind == 3) PK(3, 3); else PK(4, 3);
+  }
+#undef PK
   return (int)hipGetLastError();
 }
 
