@@ -1311,7 +1311,10 @@ __device__ __forceinline__ float hq_tree(const f4v (&hr)[NG], const f4v (&wj)[A_
 #ifndef PARLHIP_HQ_ABL
 #define PARLHIP_HQ_ABL 0
 #endif
-template <int A_CT, int NG>  // 4 NG >= T rows
+// WIDE: a name tag only (same code) — launches over >= 256 sequences (the workload shape, 107 MB) and the 20-sequence
+// launches of a 1000-row update (2 MB, launch-bound) appear as two rows in a rocprofv3 kernel summary instead of one
+// average over both.
+template <int A_CT, int NG, bool WIDE>  // 4 NG >= T rows
 __global__ __launch_bounds__(512, 4) void impala_heads_loss_q_kernel(
     const float* __restrict__ h, const float* __restrict__ wpi, const float* __restrict__ bpi,
     const float* __restrict__ wv, const float* __restrict__ bv, const float* __restrict__ blog,
@@ -1658,12 +1661,12 @@ PARLHIP_EXPORT int parlhip_impala_heads_loss_f32(const float* hidden, const floa
   if (!err) return PARLHIP_ELAUNCH;
   const int nblk = ceil_div(B, 2);  // two sequences (four half-sequence waves) per workgroup
   float* wpart = (float*)workspace;
-#define HQT(AA, NGG)                                                                                           \
-  impala_heads_loss_q_kernel<AA, NGG><<<nblk, 512, 0, s>>>(hidden, w_policy, b_policy, w_value, b_value,      \
+#define HQT(AA, NGG, WW)                                                                                       \
+  impala_heads_loss_q_kernel<AA, NGG, WW><<<nblk, 512, 0, s>>>(hidden, w_policy, b_policy, w_value, b_value,  \
       behaviour_logits, actions, rewards, dones, vs, pg, grad_hidden, wpart, sums, T, B, gamma, clip_rho,     \
       clip_pg, vf_coeff, ent_coeff, err)
   if (B > (1 << 20)) return PARLHIP_ENOSUP;  // 32-bit lane offsets of the row-group layout
-#define HL(AA) do { if (T <= 52) HQT(AA, 13); else HQT(AA, 16); } while (0)
+#define HL(AA) do { if (B >= 256) { if (T <= 52) HQT(AA, 13, true); else HQT(AA, 16, true); } else { if (T <= 52) HQT(AA, 13, false); else HQT(AA, 16, false); } } while (0)
   switch (A) {
     case 4: HL(4); break;
     case 6: HL(6); break;
