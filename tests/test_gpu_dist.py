@@ -95,6 +95,27 @@ def test_bench_reference_train_batch_over_rccl_with_one_rank():
     out = json.loads(line[0])
     assert 'RCCL' in out['config']['collectives'] and out['config']['learner_updates_per_step'] == 4
     assert out['learner_updates_per_sec'] > 0 and out['value'] > 0
+    # round 6: the collective is captured INSIDE the update's graph (one launch per update), and the line says so; the
+    # all-reduce of the real bucket is event-timed after the timed region; per-rank figures ride along
+    assert out['config']['dp_update_form'].startswith('ONE hipGraph per update'), out['config']['dp_update_form']
+    assert out['grad_allreduce_alone']['n'] == 30 and out['grad_allreduce_alone']['median_us'] > 0
+    assert len(out['per_rank']['env_frames_per_s']) == 1
+
+
+def test_update_graph_falls_back_to_two_graphs_when_the_collective_is_not_captured():
+    """PARL_AMD_GRAPH_ALLREDUCE=0 (and any backend whose collective cannot be captured): forward + backward graph | eager
+    all-reduce | clip + Adam graph — round 3's form, still selectable, same results path"""
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', PARL_AMD_FORCE_DIST='1', PARL_AMD_GRAPH_ALLREDUCE='0',
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'PARL_AMD_SHARE_GPU', 'PARL_AMD_DIST_BACKEND'):
+        env.pop(k, None)
+    cmd = [sys.executable, 'bench.py', '--gpus', '1', '--steps', '3', '--warmup', '1', '--envs', '32',
+           '--sample-batch-steps', '10', '--train-batch', '80', '--no-cpu-baseline', '--quick']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][0])
+    assert out['config']['dp_update_form'].startswith('two hipGraphs per update'), out['config']['dp_update_form']
+    assert out['learner_updates_per_sec'] > 0 and out['value'] > 0
 
 
 def _bench_env(**kw):

@@ -423,3 +423,31 @@ def test_async_pipeline_checkpoint_resumes_bit_identically(dev, tmp_path):
     os.remove(path + '.env')
     with pytest.raises(FileNotFoundError):
         agent.restore(path)
+
+
+def test_rollout_checkpoint_names_its_observation_layout(dev):
+    """a checkpoint written with the observations in the env's frame rings (lazy_obs) cannot be resumed into a
+    rollout that materialises them per buffer (or the other way round) — the mismatch is a descriptive error, not a
+    bare KeyError / a pending batch that silently reads whichever ring is current"""
+    from parl_amd.env import DeviceVectorEnv
+    from parl_amd.models import AtariModel42
+    from parl_amd.rollout import DeviceRollout
+    E, T = 8, 6
+    mk = lambda lazy: DeviceRollout(DeviceVectorEnv('PongNoFrameskip-v4', E, dim=42, horizon=T, seed=3, device=dev), T,
+                                    seed=1, n_buffers=2, lazy_obs=lazy)
+    model = AtariModel42(6).to(dev)
+    lazy, plain = mk(True), mk(False)
+    lazy.collect(model)
+    plain.collect(model)
+    d_lazy, d_plain = lazy.state_dict(), plain.state_dict()
+    assert d_lazy['lazy_obs'] is True and d_plain['lazy_obs'] is False
+    with pytest.raises(ValueError, match='lazy_obs'):
+        plain.load_state_dict(d_lazy)
+    with pytest.raises(ValueError, match='lazy_obs'):
+        lazy.load_state_dict(d_plain)
+    with pytest.raises(ValueError, match="holds no 'obs'"):
+        plain.load_buffer_state(0, lazy.buffer_state(0))
+    bad = dict(d_lazy, ring_of_buf=[0])
+    with pytest.raises(ValueError, match='frame ring'):
+        lazy.load_state_dict(bad)
+    lazy.load_state_dict(d_lazy)   # the matching layout loads

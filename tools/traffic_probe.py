@@ -87,12 +87,22 @@ w1, b1 = torch.randn(16, 4, 4, 4, device=dev) * 0.2, torch.zeros(16, device=dev)
 w2, b2 = torch.randn(32, 16, 4, 4, device=dev) * 0.1, torch.zeros(32, device=dev)
 flush_cache()
 a2 = ops.atari42_conv12(obs, w1, b1, w2, b2)
-out['conv12_fwd_n8192'] = {'kernel': 'conv12_u8_mfma_kernel', 'read': n * 7056, 'write': n * 15488}
+out['conv12_fwd_n8192'] = {'kernel': 'conv12_u8_mfma_kernel<false, false, false>', 'read': n * 7056, 'write': n * 15488}
 dy = torch.randn((n, 3872), device=dev)
 flush_cache()
 ops.atari42_conv12_backward(obs, w1, b1, w2, a2, dy)
-out['conv12_bwd_n8192'] = {'kernel': 'conv12_bwd_u8_mfma_kernel', 'read': n * (7056 + 2 * 15488), 'write': 512 * 9264 * 4}
-del obs, a2, dy
+out['conv12_bwd_n8192'] = {'kernel': 'conv12_bwd_u8_mfma_kernel<false, false>', 'read': n * (7056 + 2 * 15488), 'write': 512 * 9264 * 4}
+# the learner's pair of round 6: the forward also writes the padded conv1 tile (40,000 B per observation), the backward
+# reads it back (matched on the template arguments: <false, true, true> / <true, true>)
+pk = ops.atari42_conv12_pack(w1, w2)
+flush_cache()
+a2, a1s = ops.atari42_conv12(obs, w1, b1, w2, b2, packed=pk, save_a1=True)
+out['conv12_fwd_save_n8192'] = {'kernel': 'conv12_u8_mfma_kernel<false, true, true>', 'read': n * 7056, 'write': n * (15488 + 40000)}
+flush_cache()
+ops.atari42_conv12_backward(obs, w1, b1, w2, a2, dy, packed=pk, a1=a1s)
+out['conv12_bwd_saved_n8192'] = {'kernel': 'conv12_bwd_u8_mfma_kernel<true, true>', 'read': n * (7056 + 2 * 15488 + 39936),
+                                 'write': 512 * 9264 * 4}
+del obs, a2, dy, a1s
 a1 = torch.relu(torch.randn(n, 32, 20, 20, device=dev))
 w2c, w3c = torch.randn(64, 32, 4, 4, device=dev) * 0.05, torch.randn(64, 64, 3, 3, device=dev) * 0.05
 z = torch.zeros(64, device=dev)
