@@ -188,7 +188,7 @@ __device__ __attribute__((noinline)) int picture_wave_main(uint8_t* blob_v, cons
   const uint8_t* snap = (const uint8_t*)(uintptr_t)uni(snap_v);
   Emu r;
   r.lane = (int)(threadIdx.x & 63);
-  r.rq = (RenderQueue*)(uintptr_t)uni(rq_v);
+  r.rq = (LdsRenderQueue*)(RenderQueue*)(uintptr_t)uni(rq_v);   // generic -> LDS address space
 #ifdef PARLHIP_ENV_REGIONS
   for (int i = 0; i < 5; ++i) { r.rt[i] = 0; r.rn[i] = 0; }
 #endif
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
 #endif
   emu.rom_mask = prm.rom_size - 1;
   emu.lane = lane;
-  emu.rq = &rqs[slot];
+  emu.rq = (LdsRenderQueue*)&rqs[slot];
   emu.rq_wr = 0;
   emu.cx_spec = 0;
   emu.cx_spec_seq = 0;
