@@ -15,6 +15,18 @@
 // machine whose ONLY action is "emulate one more frame with this input, into that buffer" so
 // that the 6507/TIA code exists once in the kernel (instruction-cache footprint).
 #include "common.hpp"
+#ifdef PARLHIP_ENV_ENTRYHIST  // diagnostic build only (tools/env_entry_hist.py): clocks / 6507 instructions / entries of the translated code by entry PC
+namespace parlhip { namespace atari { __device__ unsigned long long g_env_entryhist[8192][3]; } }
+#define PARLHIP_ENTRY_HIST(pc, clocks, instrs)                                                  \
+  do {                                                                                          \
+    if (lane == 0) {                                                                            \
+      const int k_ = (pc) & 8191;                                                               \
+      atomicAdd(&g_env_entryhist[k_][0], (unsigned long long)(clocks));                         \
+      atomicAdd(&g_env_entryhist[k_][1], (unsigned long long)(instrs));                         \
+      atomicAdd(&g_env_entryhist[k_][2], 1ull);                                                 \
+    }                                                                                           \
+  } while (0)
+#endif
 #include "atari_core.hpp"
 #include "frame_tail.hpp"
 #include "philox.hpp"
@@ -173,6 +185,9 @@ __device__ unsigned long long g_env_t0[8192], g_env_t1[8192];
 #ifdef PARLHIP_ENV_REGIONS  // diagnostic build only (tools/env_regions.py): where a wave's launch goes
 __device__ unsigned long long g_env_regions[8192][16];
 #endif
+#ifdef PARLHIP_ENV_TRACEITER
+__device__ unsigned long long g_env_traceiter[8192][16];
+#endif
 
 // The env's picture: render-side TIA registers, collision latches, frame buffers (Emu::render_main).  NOT inlined
 // into the env kernel: a function of its own is register-allocated on its own — inside the kernel it shared one
@@ -269,6 +284,10 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
 #ifdef PARLHIP_ENV_REGIONS
   const unsigned long long k0 = __builtin_readcyclecounter();
   for (int i = 0; i < 5; ++i) { emu.rt[i] = 0; emu.rn[i] = 0; }
+#endif
+#ifdef PARLHIP_ENV_TRACEITER
+  emu.ti_sum = emu.ti_cnt = emu.ti_other = 0;
+  emu.ti_last = 0;
 #endif
 #ifdef PARLHIP_ROM_SCALAR
   emu.romw = (Emu::RomWords)romw_g;
@@ -583,6 +602,9 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
     g_env_regions[e][8] = __builtin_readcyclecounter() - k0;
   }
 #endif
+#ifdef PARLHIP_ENV_TRACEITER
+  if (lane == 0 && e < 8192) { g_env_traceiter[e][0] = emu.ti_sum; g_env_traceiter[e][1] = emu.ti_cnt; g_env_traceiter[e][2] = emu.ti_other; }
+#endif
 }
 
 // Row accounting of an elastic launch, before the emulator: who starts a row, who goes on, who waits.
@@ -878,6 +900,17 @@ PARLHIP_EXPORT int parlhip_atari_vec_step_elastic_obs(void* states, const uint32
 #ifdef PARLHIP_ENV_REGIONS
 PARLHIP_EXPORT int parlhip_debug_env_regions(unsigned long long* host, int n) {
   if (n > 8192) return PARLHIP_EINVAL;
+#ifdef PARLHIP_ENV_ENTRYHIST
+  if (n == -8192) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(parlhip::atari::g_env_entryhist), sizeof(unsigned long long) * 8192 * 3) != hipSuccess) return PARLHIP_EINVAL;
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(parlhip::atari::g_env_entryhist)) != hipSuccess) return PARLHIP_EINVAL;
+    return hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 3) == hipSuccess ? PARLHIP_OK : PARLHIP_EINVAL;
+  }
+#endif
+#ifdef PARLHIP_ENV_TRACEITER
+  if (n < 0) return hipMemcpyFromSymbol(host, HIP_SYMBOL(parlhip::atari::g_env_traceiter), (size_t)(-n) * 128) == hipSuccess ? PARLHIP_OK : PARLHIP_EINVAL;
+#endif
   if (hipMemcpyFromSymbol(host, HIP_SYMBOL(parlhip::atari::g_env_regions), (size_t)n * 128) != hipSuccess) return PARLHIP_EINVAL;
   return PARLHIP_OK;
 }

@@ -10,7 +10,7 @@ touched), plays the game with random actions and reports, per emulated frame:
     instruction trace (<game>.trace: uint16 pairs pc, real-write flag) for
     tools/cart_profile.py and for simulating dispatch-entry sets (gen_cart_native.Cart.entries).
 
-    python tests/tools/oracle_profile.py [outdir=/tmp/prof]
+    python tests/tools/oracle_profile.py [outdir=/tmp/prof] [agent steps: a long run writes <game>.cov, the addresses executed, and no trace]
 """
 import os
 import subprocess
@@ -83,10 +83,10 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 64; i++) g_real_reg[i] = g_tot_reg[i] = 0;
   for (int i = 0; i < 65536; i++) g_real_pc[i] = g_pc_hist[i] = 0;
   for (int i = 0; i < 256; i++) g_opc[i] = 0;
-  g_trace = fopen(argv[4], "wb");
-  int F = 400;
+  int F = argc > 5 ? atoi(argv[5]) : 400;   /* agent steps; long runs (coverage: cart_branch_profile.json "executed") write no trace */
+  g_trace = F <= 1000 ? fopen(argv[4], "wb") : 0;
   for (int i = 0; i < F; i++) { const int a = acts[rand() % na]; for (int k = 0; k < 4; k++) ale_act(&e, a, fb); if (e.terminal) ale_reset(&e, fb); }
-  F *= 4; fclose(g_trace); g_trace = 0;
+  F *= 4; if (g_trace) fclose(g_trace); g_trace = 0;
   printf("segments per frame: catch-ups %.1f partial %.1f whole lines %.1f (of which replicas %.1f)\n", (double)g_spans / F, (double)g_seg_partial / F, (double)g_seg_full / F, (double)g_seg_repl / F);
   printf("per frame: instructions %.0f  TIA writes %.0f  real picture changes %.0f\n", (double)g_nins / F, (double)g_tiaw / F, (double)g_real / F);
   for (int r = 0; r < 64; r++) if (g_tot_reg[r]) printf("  reg %02x: writes %.1f real %.1f\n", r, (double)g_tot_reg[r] / F, (double)g_real_reg[r] / F);
@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
 '''
 
 
-def main(out):
+def main(out, steps=None):
     os.makedirs(out, exist_ok=True)
     src = open(os.path.join(ROOT, 'oracle', 'atari_oracle.c')).read()
 
@@ -124,8 +124,9 @@ def main(out):
         rom = os.path.join(ROOT, 'roms', name + '.bin')
         if os.path.exists(rom):
             print('==', name)
-            subprocess.check_call(['./prof', rom, str(game), name + '.hist', name + '.trace'], cwd=out)
+            subprocess.check_call(['./prof', rom, str(game), name + ('.hist' if steps is None else '.cov'), name + '.trace'] +
+                                  ([] if steps is None else [str(steps)]), cwd=out)
 
 
 if __name__ == '__main__':
-    main(sys.argv[1] if len(sys.argv) > 1 else '/tmp/prof')
+    main(sys.argv[1] if len(sys.argv) > 1 else '/tmp/prof', int(sys.argv[2]) if len(sys.argv) > 2 else None)

@@ -19,7 +19,7 @@ def main(asm, hist, kernel_index=0, top=30):
             kernels.append(cur)
         elif cur is not None:
             cur.append(ln)
-            if 's_endpgm' in ln:
+            if ln.startswith('.Lfunc_end'):
                 cur = None
     lines = kernels[kernel_index]
     counts, kinds = collections.Counter(), collections.defaultdict(collections.Counter)
