@@ -77,6 +77,8 @@ BRANCH_PGO = bool(int(os.environ.get('PARLHIP_BRANCH_PGO', '1')))
 # from the RIOT's state — the timer value stays >= 2 — are skipped in one step (PARLHIP_WAIT_LOOPS=0: off).
 WAIT_LOOPS = bool(int(os.environ.get('PARLHIP_WAIT_LOOPS', '1')))
 TRACE_LOOPS = bool(int(os.environ.get('PARLHIP_TRACE_LOOPS', '1')))
+# translate only what a long oracle run executed + its static successors (Cart.discover); PARLHIP_PRUNE=0: every address
+PRUNE = bool(int(os.environ.get('PARLHIP_PRUNE', '1')))
 # Measured on MI355X, E=1024, after reset (profiles/r04_trace_loops.log): Pong 1.12 -> 1.02 ms per agent step (PMC per
 # frame: 111.8 k -> 100.5 k instructions, 13.9 k -> 12.7 k branches; the translated code's share of a frame 400 k -> 295 k
 # clocks).  Breakout, whose loops index RAM with X (`LDA zp,X`, `DEC zp,X`: nothing to hoist): 1.81 -> 1.98 ms while its
@@ -299,6 +301,13 @@ class Cart(object):
                     if nt + tk >= 16:
                         self.branch_prob[int(a, 16)] = tk / float(nt + tk)
         self.code = {}  # 16-bit address -> (mode, kind, op, b1, b2)
+        self.executed = set()
+        if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'cart_branch_profile.json')):
+            import json
+            ent = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'cart_branch_profile.json'))).get(
+                '%08x' % (zlib.crc32(rom) & 0xffffffff))
+            if ent and ent.get('executed'):
+                self.executed = {int(x, 16) for x in ent['executed'].split()}
         self.discover()
         self.s_hint = self.stack_hints()
         self.cur = None       # block being emitted (goto() needs the source of an edge)
@@ -344,6 +353,14 @@ class Cart(object):
         reset = self.word(0xfffc)
         lo = reset & ~self.mask & 0xffff
         work = [reset, self.word(0xfffe)] + list(range(lo, lo + len(self.rom)))
+        if PRUNE and self.executed:
+            # Round 6: with the coverage of a long oracle run at hand (cart_branch_profile.json "executed"), only what that
+            # run executed plus everything reachable from it by the program's static edges is translated — data bytes and
+            # misaligned decodes are not (Pong: 2,116 -> ~900 blocks).  An address outside the set is still safe: a jump to
+            # it is a hand-over and the interpreter steps until it reaches a translated entry.  The kernel loses the dead
+            # blocks LLVM cannot prove dead (each is a dispatch entry's fall-through) and with them code size, long
+            # branches and compile time.
+            work = [reset, self.word(0xfffe)] + sorted(self.executed)
         while work:
             a = work.pop() & 0xffff
             while True:

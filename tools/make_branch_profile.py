@@ -1,5 +1,6 @@
 """Dev tool (CPU only): taken / not-taken counts of every conditional branch of the cartridges from the oracle's
-instruction trace (tests/tools/oracle_profile.py [outdir=/tmp/prof] first) -> parl_amd/csrc/cart_branch_profile.json,
+instruction trace (tests/tools/oracle_profile.py [outdir=/tmp/prof] first; and once more with `<outdir> 30000` for the
+coverage of a long run, the "executed" list) -> parl_amd/csrc/cart_branch_profile.json,
 which gen_cart_native.py turns into branch-probability hints.  Tuning data derived from a run of the user-supplied
 cartridges (like a compiler's PGO profile), keyed by the cartridge's CRC-32."""
 import collections
@@ -28,7 +29,12 @@ if __name__ == '__main__':
         c = collections.defaultdict(lambda: [0, 0])
         for p, t in zip(bp, taken):
             c[int(p)][int(t)] += 1
-        out['%08x' % (zlib.crc32(rom) & 0xffffffff)] = {
-            'game': name, 'branches': {'%04x' % p: [v[0], v[1]] for p, v in sorted(c.items())}}
+        ent = {'game': name, 'branches': {'%04x' % p: [v[0], v[1]] for p, v in sorted(c.items())}}
+        # every address an instruction was executed at in a LONG oracle run (tests/tools/oracle_profile.py <outdir> 30000
+        # writes <game>.cov): the roots of the translator's recursive descent (gen_cart_native.Cart.discover)
+        cov = os.path.join(prof, name + '.cov')
+        if os.path.exists(cov):
+            ent['executed'] = ' '.join(sorted({ln.split()[0] for ln in open(cov)} | {'%04x' % p for p in set(pcs.tolist())}))
+        out['%08x' % (zlib.crc32(rom) & 0xffffffff)] = ent
     json.dump(out, open(os.path.join(ROOT, 'parl_amd', 'csrc', 'cart_branch_profile.json'), 'w'), indent=0)
-    print({k: len(v['branches']) for k, v in out.items()})
+    print({k: (len(v['branches']), len(v.get('executed', '').split())) for k, v in out.items()})
