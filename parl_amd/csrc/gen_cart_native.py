@@ -621,7 +621,7 @@ class Cart(object):
         if tc is None or reg not in tc.shadows or reg in (T_DGRP0, T_DGRP1, T_DENABL):
             return 'if (__builtin_expect(!e.tia_store(0x%02x, %s, %s, %s), 0)) %s' % (reg, val, cw, self.quiet_ok, pend)
         # inside a trace: the no-op test against the loop's scalar shadows of the CPU-side register file
-        v = '((%s) & 0xfe)' % val if 0x06 <= reg <= 0x09 else '(%s)' % val
+        v = '((%s) & 0xfe)' % val if 0x06 <= reg <= 0x09 else ('((%s) & 0x02)' % val if 0x1d <= reg <= 0x1f else '(%s)' % val)  # Emu::tia_wired
         upd = 'ts_%02x = v_;' % reg
         if reg == 0x1b:      # Emu::tia_store_is_nop: GRP0 also latches the delayed GRP1
             nop = '(ts_1b == v_) & (ts_%02x == ts_1c)' % T_DGRP1
