@@ -23,6 +23,7 @@ Output: cart_native.gen.hpp (not committed: derived from user-supplied ROM data)
 Usage: gen_cart_native.py <out.hpp> [name=path.bin ...]   (name in {pong, breakout})
 """
 import os
+import re
 import sys
 import zlib
 
@@ -79,6 +80,19 @@ WAIT_LOOPS = bool(int(os.environ.get('PARLHIP_WAIT_LOOPS', '1')))
 TRACE_LOOPS = bool(int(os.environ.get('PARLHIP_TRACE_LOOPS', '1')))
 # translate only what a long oracle run executed + its static successors (Cart.discover); PARLHIP_PRUNE=0: every address
 PRUNE = bool(int(os.environ.get('PARLHIP_PRUNE', '1')))
+# Dead flags (round 6; PARLHIP_DEAD_FLAGS=0: off).  V and C cost the scalar unit six and two instructions per ADC / SBC
+# (two per compare / shift) and almost nothing ever reads them: a backward liveness pass over the cartridge's static control
+# flow (Cart.flag_liveness: readers BVC / BVS / PHP / BRK resp. ADC / SBC / ROL / ROR / BCC / BCS / PHP / BRK; RTS, RTI,
+# JMP (), JAM and edges out of the translated set count as readers) says where a flag is dead, and the defining
+# instruction is then emitted without it.  Inside a trace the walk is over the trace's own instructions, where a PHP
+# onto ENAM0 / ENAM1 / ENABL (stack pointer a fact) reads only Z (Emu::tia_wired), and every possible exit falls back on
+# the static answer for the generic code behind it.  The stale bit is unobservable by construction; the state blob's P
+# differs from the interpreter's in those bits (tests/test_gpu_env.py masks V and C in that one comparison).
+DEAD_FLAGS = bool(int(os.environ.get('PARLHIP_DEAD_FLAGS', '1')))
+F_READS = {'V': {'BVC', 'BVS', 'PHP', 'BRK'},
+           'C': {'ADC', 'SBC', 'ROL', 'ROR', 'ROL_A', 'ROR_A', 'BCC', 'BCS', 'PHP', 'BRK'}}
+F_KILLS = {'V': {'ADC', 'SBC', 'BIT', 'CLV', 'PLP'},
+           'C': {'ADC', 'SBC', 'CMP', 'CPX', 'CPY', 'ASL', 'LSR', 'ROL', 'ROR', 'ASL_A', 'LSR_A', 'ROL_A', 'ROR_A', 'SEC', 'CLC', 'PLP'}}
 # Measured on MI355X, E=1024, after reset (profiles/r04_trace_loops.log): Pong 1.12 -> 1.02 ms per agent step (PMC per
 # frame: 111.8 k -> 100.5 k instructions, 13.9 k -> 12.7 k branches; the translated code's share of a frame 400 k -> 295 k
 # clocks).  Breakout, whose loops index RAM with X (`LDA zp,X`, `DEC zp,X`: nothing to hoist): 1.81 -> 1.98 ms while its
@@ -332,6 +346,9 @@ class Cart(object):
                     self.traces[h] = Trace(self, h, stream)
                     for x in stream:
                         self.trace_of[x] = h
+        self.flag_live = self.flag_liveness() if DEAD_FLAGS else None   # flag -> addresses where it is live BEFORE the instruction
+        self._can_exit = {}
+        self._in_analysis = False
         self.loop_of = {}     # instruction start inside a re-entry loop -> index of the loop
         for i, (h, stream) in enumerate(self.loops):
             for x in stream:
@@ -478,6 +495,97 @@ class Cart(object):
                 taken |= set(range(stream[0], stream[-1] + 3))
                 out.append((h, stream))
         return out
+
+    def static_succ(self, a):
+        """static successors of the instruction at `a`, or None when control can go somewhere unknown"""
+        mode, kind, op, b1, b2 = self.code[a]
+        nxt = (a + length(mode)) & 0xffff
+        if op in ('RTS', 'RTI', 'JMPI', 'BRK', 'JAM'):
+            return None
+        if op in ('JMP', 'JSR'):   # (a subroutine's RTS is "unknown": the flags a caller defines are live through a call)
+            succ = [b1 | (b2 << 8)]
+        elif mode == M_REL:
+            succ = [(a + 2 + (b1 - 256 if b1 & 0x80 else b1)) & 0xffff, nxt]
+        else:
+            succ = [nxt]
+        return None if any(t not in self.code for t in succ) else succ
+
+    def flag_liveness(self):
+        live = {}
+        for f in ('V', 'C'):
+            rd, kl = F_READS[f], F_KILLS[f]
+            li = {a: False for a in self.code}   # least fixed point: grow from the readers
+            changed = True
+            while changed:
+                changed = False
+                for a in self.code:
+                    if li[a]:
+                        continue
+                    op = self.code[a][2]
+                    if op in rd:
+                        v = True
+                    elif op in kl:
+                        v = False
+                    else:
+                        succ = self.static_succ(a)
+                        v = True if succ is None else any(li[t] for t in succ)
+                    if v:
+                        li[a] = True
+                        changed = True
+            live[f] = {a for a, v in li.items() if v}
+        return live
+
+    def live_out(self, f, a):
+        succ = self.static_succ(a)
+        return True if succ is None else any(t in self.flag_live[f] for t in succ)
+
+    def trace_can_exit(self, a):
+        """can the trace's copy of the instruction at `a` leave the trace (hand-over, pend, instruction budget, a jump to a
+        generic block)?  Read off its emitted text, like entries() does."""
+        key = (self.tc.head, a)
+        if key not in self._can_exit:
+            cur, self._in_analysis = self.cur, True
+            try:
+                body = ' '.join(self.emit(a))
+            finally:
+                self.cur, self._in_analysis = cur, False
+            self._can_exit[key] = ('return' in body) or ('goto L_' in body)
+        return self._can_exit[key]
+
+    def flag_dead_after(self, f, a):
+        """may the instruction at `a` (being emitted: generic block or trace copy) leave flag `f` stale?"""
+        if not DEAD_FLAGS or self._in_analysis:
+            return False
+        if self.tc is None:
+            return not self.live_out(f, a)
+        tc, rd, kl = self.tc, F_READS[f], F_KILLS[f]
+        seen = set()
+
+        def dead_from(j):   # is f dead before the trace's copy of instruction j?
+            if j not in tc.sset:
+                return j in self.code and j not in self.flag_live[f]   # left the trace: the generic code's answer
+            if j not in self.flag_live[f]:
+                return True     # dead on every static path from here: exits included
+            if j in seen:
+                return True     # a cycle that met no reader
+            seen.add(j)
+            mode, kind, op, b1, b2 = self.code[j]
+            nxt = (j + length(mode)) & 0xffff
+            tS = tc.S.get(j)
+            php_tia = op == 'PHP' and tS is not None and not (tS & 0x80) and 0x1d <= (tS & 0x3f) <= 0x1f
+            if php_tia:         # reads Z only; its pend exit continues in the generic code behind it
+                return nxt in self.code and nxt not in self.flag_live[f] and dead_from(nxt)
+            if op in rd:
+                return False
+            if op in kl:
+                return True
+            if self.trace_can_exit(j):
+                return False    # (live in the generic code from j on, and j can hand over)
+            succ = self.static_succ(j)
+            return succ is not None and all(dead_from(t) for t in succ)
+
+        succ = self.static_succ(a)
+        return succ is not None and all(dead_from(t) for t in succ)
 
     def stack_hints(self):
         """Likely value of the stack pointer BEFORE each instruction, by an optimistic forward dataflow
@@ -638,8 +746,15 @@ class Cart(object):
                 % (v, nop, reg, cw, quiet, upd, pend))
 
     def emit_read_op(self, op):
-        if self.tc is not None and self.tc.d_clear and op in ('ADC', 'SBC'):
-            return 'e.%s_bin(m);' % op.lower()
+        a = self.cur
+        kv, kc = ('false' if self.flag_dead_after('V', a) else 'true'), ('false' if self.flag_dead_after('C', a) else 'true')
+        if op in ('ADC', 'SBC'):
+            binary = self.tc is not None and self.tc.d_clear
+            return 'e.%s%s_f<%s, %s>(m);' % (op.lower(), '_bin' if binary else '', kv, kc)
+        if op in ('CMP', 'CPX', 'CPY'):
+            return 'e.cmp_f<%s>(e.%s, m);' % (kc, {'CMP': 'A', 'CPX': 'X', 'CPY': 'Y'}[op])
+        if op == 'BIT':
+            return 'e.bit_f<%s>(m);' % kv
         return {
             'LDA': 'e.A = m; e.set_nz(e.A);', 'LDX': 'e.X = m; e.set_nz(e.X);', 'LDY': 'e.Y = m; e.set_nz(e.Y);',
             'ORA': 'e.A |= m; e.set_nz(e.A);', 'AND': 'e.A &= m; e.set_nz(e.A);', 'EOR': 'e.A ^= m; e.set_nz(e.A);',
@@ -789,7 +904,12 @@ class Cart(object):
                 'SED': 'e.P |= FD;', 'NOP': '',
             }
             if op in simple:
-                return [simple[op], 'e.cyc += 2;']
+                txt = simple[op]
+                if op in F_KILLS['C'] and self.flag_dead_after('C', a):
+                    txt = re.sub(r'e\.cf = [^;]*; ?', '', txt)
+                if op == 'CLV' and self.flag_dead_after('V', a):
+                    txt = ''
+                return [txt, 'e.cyc += 2;']
             if mode == M_REL:
                 flag, want = {
                     'BPL': ('FN', 0), 'BMI': ('FN', 1), 'BVC': ('FV', 0), 'BVS': ('FV', 1), 'BCC': ('FC', 0),
@@ -917,6 +1037,8 @@ class Cart(object):
         }[op]
         if static is not None and not (static & 0x80):
             return fb
+        if op in F_KILLS['C'] and self.flag_dead_after('C', a):
+            rmw = re.sub(r'e\.cf = [^;]*; ?', '', rmw)
         return [
             'const int ea = %s;' % ea, 'if (!(ea & 0x80)) { --n; e.PC = 0x%04x; return; }' % a,
             'const int m = e.ram_rd(ea & 0x7f);', 'int wv;', rmw, 'e.set_nz(wv);', 'e.ram_wr(ea & 0x7f, wv);',

@@ -293,7 +293,13 @@ def test_translated_cartridge_equals_interpreter(dev, game):
         act = torch.randint(0, a_env.act_dim, (E, ), generator=g).to(dev)
         oa, ra, da, _ = a_env.step(act)
         ob, rb, db, _ = b_env.step(act)
-        assert torch.equal(a_env.states, b_env.states), 'state blob, step %d' % i
+        # (the translated code leaves V and C alone where nothing can read them before they are defined again —
+        # gen_cart_native.py, DEAD_FLAGS — so the saved processor status may differ from the interpreter's in exactly
+        # those two bits: byte kOffScalars + 4 * S_P = 208 of the blob; everything else is compared bit for bit)
+        sa, sb_ = a_env.states.view(E, -1).clone(), b_env.states.view(E, -1).clone()
+        sa[:, 208] &= 0xbe
+        sb_[:, 208] &= 0xbe
+        assert torch.equal(sa, sb_), 'state blob, step %d' % i
         assert torch.equal(a_env.raw_frames, b_env.raw_frames), 'raw frames, step %d' % i
         assert torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(oa, ob), 'step %d' % i
     a_env.check_faults()

@@ -104,6 +104,13 @@ struct Emu {
     set_nz(A);
   }
   void cmp(int r, int m) { const int d = r - m; cf = ((d >> 8) & 1) ^ 1; set_nz(d & 0xff); }
+  // the translated code's forms with a statically dead V / C left alone (Emu::adc_f ... in atari_core.hpp)
+  template <bool KV, bool KC> void adc_f(int m) { const int sp = P, sc = cf; adc(m); if (!KV) P = (P & ~FV) | (sp & FV); if (!KC) cf = sc; }
+  template <bool KV, bool KC> void sbc_f(int m) { const int sp = P, sc = cf; sbc(m); if (!KV) P = (P & ~FV) | (sp & FV); if (!KC) cf = sc; }
+  template <bool KV, bool KC> void adc_bin_f(int m) { const int sp = P, sc = cf; adc_bin(m); if (!KV) P = (P & ~FV) | (sp & FV); if (!KC) cf = sc; }
+  template <bool KV, bool KC> void sbc_bin_f(int m) { const int sp = P, sc = cf; sbc_bin(m); if (!KV) P = (P & ~FV) | (sp & FV); if (!KC) cf = sc; }
+  template <bool KC> void cmp_f(int r, int m) { const int sc = cf; cmp(r, m); if (!KC) cf = sc; }
+  template <bool KV> void bit_f(int m) { const int sp = P; bit(m); if (!KV) P = (P & ~FV) | (sp & FV); }
 
   // the lanes of the device's TIA register file a translated loop keeps scalar shadows of (Emu::t / tset):
   // the write registers its stores are compared with, and the delayed-graphics latches (atari_defs.hpp TiaLane)
