@@ -316,12 +316,14 @@ class Cart(object):
                         self.branch_prob[int(a, 16)] = tk / float(nt + tk)
         self.code = {}  # 16-bit address -> (mode, kind, op, b1, b2)
         self.executed = set()
+        self.indirect_targets = set()   # where the profile run's JMP () went: dispatch entries (Cart.entries)
         if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'cart_branch_profile.json')):
             import json
             ent = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'cart_branch_profile.json'))).get(
                 '%08x' % (zlib.crc32(rom) & 0xffffffff))
             if ent and ent.get('executed'):
                 self.executed = {int(x, 16) for x in ent['executed'].split()}
+            self.indirect_targets = {int(x, 16) for x in ent.get('indirect_targets', '').split()} if ent else set()
         self.discover()
         self.s_hint = self.stack_hints()
         self.cur = None       # block being emitted (goto() needs the source of an edge)
@@ -660,7 +662,7 @@ class Cart(object):
         merge) — with every address a switch case, each block had the dispatch as a predecessor.
         A PC outside this set (computed JMP (), RTS tricks) is always safe: the switch returns, the
         interpreter executes that instruction and dispatch is tried again at the next one."""
-        ent = {self.word(0xfffc), self.word(0xfffe)} | set(self.traces)
+        ent = {self.word(0xfffc), self.word(0xfffe)} | set(self.traces) | self.indirect_targets
         for a in self.code:
             mode, kind, op, b1, b2 = self.code[a]
             if mode == M_REL or op == 'JMP':

@@ -19,7 +19,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 PATCH_DECL = '''#include <stdio.h>
-long g_pc_hist[65536]; FILE* g_trace; int g_trace_real;
+long g_pc_hist[65536], g_ind_tgt[65536]; FILE* g_trace; int g_trace_real; int g_prev_op = -1;
 long g_nins, g_tiaw, g_real, g_real_reg[64], g_tot_reg[64], g_real_pc[65536], g_opc[256];
 long g_seg_partial, g_seg_full, g_seg_repl, g_spans; static int32_t g_dev_last = -1000000000; int g_cur_pc;
 static int is_nop_write(Atari* a, int reg, int v);
@@ -69,7 +69,7 @@ MAIN = r'''
 #include <stdio.h>
 #include <stdlib.h>
 #include "atari_oracle.h"
-extern long g_nins, g_tiaw, g_real, g_real_reg[64], g_tot_reg[64], g_real_pc[65536], g_opc[256], g_pc_hist[65536];
+extern long g_nins, g_tiaw, g_real, g_real_reg[64], g_tot_reg[64], g_real_pc[65536], g_opc[256], g_pc_hist[65536], g_ind_tgt[65536];
 extern long g_seg_partial, g_seg_full, g_seg_repl, g_spans; extern FILE* g_trace;
 int main(int argc, char** argv) {
   FILE* f = fopen(argv[1], "rb"); static uint8_t rom[4096]; int n = (int)fread(rom, 1, 4096, f); fclose(f);
@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
   for (int r = 0; r < 64; r++) if (g_tot_reg[r]) printf("  reg %02x: writes %.1f real %.1f\n", r, (double)g_tot_reg[r] / F, (double)g_real_reg[r] / F);
   printf("opcodes per frame: JSR %.1f RTS %.1f BRK %.1f RTI %.1f PLA %.1f PLP %.1f PHA %.1f PHP %.1f\n", (double)g_opc[0x20] / F, (double)g_opc[0x60] / F, (double)g_opc[0] / F, (double)g_opc[0x40] / F, (double)g_opc[0x68] / F, (double)g_opc[0x28] / F, (double)g_opc[0x48] / F, (double)g_opc[0x08] / F);
   FILE* o = fopen(argv[3], "w");
-  for (int p = 0; p < 65536; p++) if (g_pc_hist[p] || g_real_pc[p]) fprintf(o, "%04x %.3f %.3f\n", p, (double)g_pc_hist[p] / F, (double)g_real_pc[p] / F);
+  for (int p = 0; p < 65536; p++) if (g_pc_hist[p] || g_real_pc[p]) fprintf(o, "%04x %.3f %.3f%s\n", p, (double)g_pc_hist[p] / F, (double)g_real_pc[p] / F, g_ind_tgt[p] ? " J" : "");
   fclose(o);
   return 0;
 }
@@ -114,7 +114,7 @@ def main(out, steps=None):
     rep('static void cpu_step(Atari* a) {\n  const uint8_t op = fetch(a);',
         'static void cpu_step(Atari* a) {\n'
         '  if (g_trace && g_nins > 0) { unsigned short r[2] = {(unsigned short)g_cur_pc, (unsigned short)g_trace_real}; fwrite(r, 2, 2, g_trace); }\n'
-        '  g_trace_real = 0; g_cur_pc = a->PC; g_nins++; g_pc_hist[a->PC]++;\n  const uint8_t op = fetch(a); g_opc[op]++;')
+        '  g_trace_real = 0; g_cur_pc = a->PC; g_nins++; g_pc_hist[a->PC]++;\n  if (g_prev_op == 0x6c) g_ind_tgt[a->PC]++;  /* where a JMP () went */\n  const uint8_t op = fetch(a); g_opc[op]++; g_prev_op = op;')
     src += PATCH_TAIL
     open(os.path.join(out, 'atari_prof.c'), 'w').write(src)
     open(os.path.join(out, 'main.c'), 'w').write(MAIN)

@@ -35,6 +35,9 @@ if __name__ == '__main__':
         cov = os.path.join(prof, name + '.cov')
         if os.path.exists(cov):
             ent['executed'] = ' '.join(sorted({ln.split()[0] for ln in open(cov)} | {'%04x' % p for p in set(pcs.tolist())}))
+            # ... and where its JMP () instructions went (lines marked J): dispatch entries, or the interpreter walks on
+            # from there until it meets one
+            ent['indirect_targets'] = ' '.join(sorted(ln.split()[0] for ln in open(cov) if ln.split()[-1] == 'J'))
         out['%08x' % (zlib.crc32(rom) & 0xffffffff)] = ent
     json.dump(out, open(os.path.join(ROOT, 'parl_amd', 'csrc', 'cart_branch_profile.json'), 'w'), indent=0)
     print({k: (len(v['branches']), len(v.get('executed', '').split())) for k, v in out.items()})
