@@ -89,6 +89,15 @@ PRUNE = bool(int(os.environ.get('PARLHIP_PRUNE', '1')))
 # the static answer for the generic code behind it.  The stale bit is unobservable by construction; the state blob's P
 # differs from the interpreter's in those bits (tests/test_gpu_env.py masks V and C in that one comparison).
 DEAD_FLAGS = bool(int(os.environ.get('PARLHIP_DEAD_FLAGS', '1')))
+# RTS / RTI jumping straight to the return sites the profile run saw (cart_branch_profile.json "returns") instead of
+# leaving for a re-dispatch.  MEASURED AND OFF (PARLHIP_RET_PREDICT=1: on): with every site's usual targets the return
+# edges close cycles through the subroutines and the kernel no longer compiles in 15 minutes; with one target per site
+# (share >= 0.6: PARLHIP_RET_PREDICT_MAX=1 PARLHIP_RET_PREDICT_MIN=0.6) it compiles and is bit-exact, but Pong reads
+# 7.56 M frames/s against 7.62 M without it, Breakout 4.71 = 4.68 M: a re-dispatch costs less than what the extra
+# edges cost the code around them.
+RET_PREDICT = bool(int(os.environ.get('PARLHIP_RET_PREDICT', '0')))
+RET_PREDICT_MAX = int(os.environ.get('PARLHIP_RET_PREDICT_MAX', '4'))
+RET_PREDICT_MIN = float(os.environ.get('PARLHIP_RET_PREDICT_MIN', '0.02'))
 F_READS = {'V': {'BVC', 'BVS', 'PHP', 'BRK'},
            'C': {'ADC', 'SBC', 'ROL', 'ROR', 'ROL_A', 'ROR_A', 'BCC', 'BCS', 'PHP', 'BRK'}}
 F_KILLS = {'V': {'ADC', 'SBC', 'BIT', 'CLV', 'PLP'},
@@ -317,6 +326,7 @@ class Cart(object):
         self.code = {}  # 16-bit address -> (mode, kind, op, b1, b2)
         self.executed = set()
         self.indirect_targets = set()   # where the profile run's JMP () went: dispatch entries (Cart.entries)
+        self.returns = {}               # RTS / RTI address -> [(count, return site)]
         if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'cart_branch_profile.json')):
             import json
             ent = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'cart_branch_profile.json'))).get(
@@ -324,6 +334,10 @@ class Cart(object):
             if ent and ent.get('executed'):
                 self.executed = {int(x, 16) for x in ent['executed'].split()}
             self.indirect_targets = {int(x, 16) for x in ent.get('indirect_targets', '').split()} if ent else set()
+            for item in (ent.get('returns', '').split() if ent else []):
+                ft, cnt = item.split(':')
+                f, t = ft.split('>')
+                self.returns.setdefault(int(f, 16), []).append((int(cnt), int(t, 16)))
         self.discover()
         self.s_hint = self.stack_hints()
         self.cur = None       # block being emitted (goto() needs the source of an edge)
@@ -713,6 +727,17 @@ class Cart(object):
             return 'goto %s;' % self.label(a)
         return '{ e.PC = 0x%04x; /*rare*/ return; }' % a
 
+    def predicted_returns(self, a):
+        if not RET_PREDICT or self.tc is not None:
+            return []
+        sites = sorted(self.returns.get(a, []), reverse=True)
+        tot = float(sum(c for c, t in sites)) or 1.0
+        out = []
+        for c, t in sites[:RET_PREDICT_MAX]:
+            if c / tot >= RET_PREDICT_MIN and t in self.code:
+                out.append('if (e.PC == 0x%04x) { if (__builtin_expect(n > kNativeInstrLimit, 0)) { e.pend = -2; return; } %s }' % (t, self.goto(t)))
+        return out
+
     def fallback(self, a):
         return ['{ e.PC = 0x%04x; return; }' % a]
 
@@ -951,12 +976,12 @@ class Cart(object):
             if op == 'RTS':
                 return ['if (__builtin_expect(e.S < 0x7f || e.S > 0xfd, 0)) { --n; e.PC = 0x%04x; return; }' % a,
                         'e.PC = ((e.ram_rd((e.S + 1) & 0x7f) | (e.ram_rd((e.S + 2) & 0x7f) << 8)) + 1) & 0xffff;',
-                        'e.S = (e.S + 2) & 0xff; e.cyc += 6;', 'e.pend = -2; return;']
+                        'e.S = (e.S + 2) & 0xff; e.cyc += 6;'] + self.predicted_returns(a) + ['e.pend = -2; return;']
             if op == 'RTI':
                 return ['if (__builtin_expect(e.S < 0x7f || e.S > 0xfc, 0)) { --n; e.PC = 0x%04x; return; }' % a,
                         'e.pset((e.ram_rd((e.S + 1) & 0x7f) & ~FB) | FU);',
                         'e.PC = e.ram_rd((e.S + 2) & 0x7f) | (e.ram_rd((e.S + 3) & 0x7f) << 8);',
-                        'e.S = (e.S + 3) & 0xff; e.cyc += 6;', 'e.pend = -2; return;']
+                        'e.S = (e.S + 3) & 0xff; e.cyc += 6;'] + self.predicted_returns(a) + ['e.pend = -2; return;']
             if op == 'BRK':
                 ret, vec = (a + 2) & 0xffff, self.word(0xfffe)
                 return ['if (__builtin_expect(e.S < 0x82, 0)) { --n; e.PC = 0x%04x; return; }' % a,

@@ -19,7 +19,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 PATCH_DECL = '''#include <stdio.h>
-long g_pc_hist[65536], g_ind_tgt[65536]; FILE* g_trace; int g_trace_real; int g_prev_op = -1;
+long g_pc_hist[65536], g_ind_tgt[65536]; int g_prev_pc = 0; long g_ret_n = 0; struct { unsigned short from, to; long n; } g_ret[4096]; FILE* g_trace; int g_trace_real; int g_prev_op = -1;
 long g_nins, g_tiaw, g_real, g_real_reg[64], g_tot_reg[64], g_real_pc[65536], g_opc[256];
 long g_seg_partial, g_seg_full, g_seg_repl, g_spans; static int32_t g_dev_last = -1000000000; int g_cur_pc;
 static int is_nop_write(Atari* a, int reg, int v);
@@ -69,6 +69,7 @@ MAIN = r'''
 #include <stdio.h>
 #include <stdlib.h>
 #include "atari_oracle.h"
+extern long g_ret_n; extern struct { unsigned short from, to; long n; } g_ret[4096];
 extern long g_nins, g_tiaw, g_real, g_real_reg[64], g_tot_reg[64], g_real_pc[65536], g_opc[256], g_pc_hist[65536], g_ind_tgt[65536];
 extern long g_seg_partial, g_seg_full, g_seg_repl, g_spans; extern FILE* g_trace;
 int main(int argc, char** argv) {
@@ -93,6 +94,7 @@ int main(int argc, char** argv) {
   printf("opcodes per frame: JSR %.1f RTS %.1f BRK %.1f RTI %.1f PLA %.1f PLP %.1f PHA %.1f PHP %.1f\n", (double)g_opc[0x20] / F, (double)g_opc[0x60] / F, (double)g_opc[0] / F, (double)g_opc[0x40] / F, (double)g_opc[0x68] / F, (double)g_opc[0x28] / F, (double)g_opc[0x48] / F, (double)g_opc[0x08] / F);
   FILE* o = fopen(argv[3], "w");
   for (int p = 0; p < 65536; p++) if (g_pc_hist[p] || g_real_pc[p]) fprintf(o, "%04x %.3f %.3f%s\n", p, (double)g_pc_hist[p] / F, (double)g_real_pc[p] / F, g_ind_tgt[p] ? " J" : "");
+  for (long k = 0; k < g_ret_n; k++) fprintf(o, "R %04x %04x %ld\n", g_ret[k].from, g_ret[k].to, g_ret[k].n);
   fclose(o);
   return 0;
 }
@@ -114,7 +116,7 @@ def main(out, steps=None):
     rep('static void cpu_step(Atari* a) {\n  const uint8_t op = fetch(a);',
         'static void cpu_step(Atari* a) {\n'
         '  if (g_trace && g_nins > 0) { unsigned short r[2] = {(unsigned short)g_cur_pc, (unsigned short)g_trace_real}; fwrite(r, 2, 2, g_trace); }\n'
-        '  g_trace_real = 0; g_cur_pc = a->PC; g_nins++; g_pc_hist[a->PC]++;\n  if (g_prev_op == 0x6c) g_ind_tgt[a->PC]++;  /* where a JMP () went */\n  const uint8_t op = fetch(a); g_opc[op]++; g_prev_op = op;')
+        '  g_trace_real = 0; g_cur_pc = a->PC; g_nins++; g_pc_hist[a->PC]++;\n  if (g_prev_op == 0x6c) g_ind_tgt[a->PC]++;  /* where a JMP () went */\n  if (g_prev_op == 0x60 || g_prev_op == 0x40) { long k = 0; for (; k < g_ret_n; k++) if (g_ret[k].from == g_prev_pc && g_ret[k].to == a->PC) break; if (k == g_ret_n && g_ret_n < 4096) { g_ret[k].from = (unsigned short)g_prev_pc; g_ret[k].to = a->PC; g_ret[k].n = 0; g_ret_n++; } if (k < 4096) g_ret[k].n++; }  /* RTS / RTI -> return site */\n  g_prev_pc = a->PC;\n  const uint8_t op = fetch(a); g_opc[op]++; g_prev_op = op;')
     src += PATCH_TAIL
     open(os.path.join(out, 'atari_prof.c'), 'w').write(src)
     open(os.path.join(out, 'main.c'), 'w').write(MAIN)

@@ -49,6 +49,8 @@ def main(asm, hist, kernel_index=0, top=30):
     counts, kinds = c2, k2
     dyn = {}
     for ln in open(hist):
+        if ln.startswith('R '):
+            continue
         pc, cnt = ln.split()[:2]
         dyn[int(pc, 16)] = float(cnt)
     tot = sum(counts.get(pc, 0) * c for pc, c in dyn.items())

@@ -34,10 +34,15 @@ if __name__ == '__main__':
         # writes <game>.cov): the roots of the translator's recursive descent (gen_cart_native.Cart.discover)
         cov = os.path.join(prof, name + '.cov')
         if os.path.exists(cov):
-            ent['executed'] = ' '.join(sorted({ln.split()[0] for ln in open(cov)} | {'%04x' % p for p in set(pcs.tolist())}))
+            rows = [ln.split() for ln in open(cov)]
+            rets = [r for r in rows if r[0] == 'R']
+            rows = [r for r in rows if r[0] != 'R']
+            ent['executed'] = ' '.join(sorted({r[0] for r in rows} | {'%04x' % p for p in set(pcs.tolist())}))
+            # RTS / RTI -> where it returned to, with counts (the translator jumps straight to the usual return sites)
+            ent['returns'] = ' '.join('%s>%s:%s' % (r[1], r[2], r[3]) for r in sorted(rets))
             # ... and where its JMP () instructions went (lines marked J): dispatch entries, or the interpreter walks on
             # from there until it meets one
-            ent['indirect_targets'] = ' '.join(sorted(ln.split()[0] for ln in open(cov) if ln.split()[-1] == 'J'))
+            ent['indirect_targets'] = ' '.join(sorted(r[0] for r in rows if r[-1] == 'J'))
         out['%08x' % (zlib.crc32(rom) & 0xffffffff)] = ent
     json.dump(out, open(os.path.join(ROOT, 'parl_amd', 'csrc', 'cart_branch_profile.json'), 'w'), indent=0)
     print({k: (len(v['branches']), len(v.get('executed', '').split())) for k, v in out.items()})
