@@ -95,6 +95,9 @@ DEAD_FLAGS = bool(int(os.environ.get('PARLHIP_DEAD_FLAGS', '1')))
 # (share >= 0.6: PARLHIP_RET_PREDICT_MAX=1 PARLHIP_RET_PREDICT_MIN=0.6) it compiles and is bit-exact, but Pong reads
 # 7.56 M frames/s against 7.62 M without it, Breakout 4.71 = 4.68 M: a re-dispatch costs less than what the extra
 # edges cost the code around them.
+# records are published to wave B at a trace's back edge once this many are waiting (0: only when the translated code
+# returns to the frame loop, i.e. for Pong's display kernel when the 64-entry local log is full)
+TRACE_FLUSH = int(os.environ.get('PARLHIP_TRACE_FLUSH', '0'))
 RET_PREDICT = bool(int(os.environ.get('PARLHIP_RET_PREDICT', '0')))
 RET_PREDICT_MAX = int(os.environ.get('PARLHIP_RET_PREDICT_MAX', '4'))
 RET_PREDICT_MIN = float(os.environ.get('PARLHIP_RET_PREDICT_MIN', '0.02'))
@@ -953,6 +956,9 @@ class Cart(object):
                 # blocks inside 6507 loops that are also dispatch entries — is slower: Pong 1.20 -> 1.43 ms)
                 if tgt <= a:  # backward edge: the only place a frame can loop without bound
                     body += 'if (__builtin_expect(n > kNativeInstrLimit, 0)) { e.PC = 0x%04x; return; } ' % tgt
+                    if self.tc is not None and TRACE_FLUSH and tgt == self.tc.head:
+                        # the trace runs a whole display kernel without leaving: hand wave B what has been recorded so far
+                        body += 'if (__builtin_expect(e.wqn >= %d, 0)) e.rq_flush(); ' % TRACE_FLUSH
                 body += self.goto(tgt)
                 pt = self.branch_prob.get(a)
                 if pt is not None:
