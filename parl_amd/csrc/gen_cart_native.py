@@ -97,7 +97,7 @@ DEAD_FLAGS = bool(int(os.environ.get('PARLHIP_DEAD_FLAGS', '1')))
 # edges cost the code around them.
 # records are published to wave B at a trace's back edge once this many are waiting (0: only when the translated code
 # returns to the frame loop, i.e. for Pong's display kernel when the 64-entry local log is full)
-TRACE_FLUSH = int(os.environ.get('PARLHIP_TRACE_FLUSH', '0'))
+TRACE_FLUSH = int(os.environ.get('PARLHIP_TRACE_FLUSH', '8'))
 RET_PREDICT = bool(int(os.environ.get('PARLHIP_RET_PREDICT', '0')))
 RET_PREDICT_MAX = int(os.environ.get('PARLHIP_RET_PREDICT_MAX', '4'))
 RET_PREDICT_MIN = float(os.environ.get('PARLHIP_RET_PREDICT_MIN', '0.02'))

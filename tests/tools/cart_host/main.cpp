@@ -178,6 +178,10 @@ struct Emu {
   // request is declined so that the hand-over arm of the generated blocks stays exercised.
   int log_calls = 0;
   void write_at(int reg, int v, int cw) { const int c0 = cyc; cyc = cw; host_wr(a, (uint16_t)reg, (uint8_t)v); cyc = c0; }
+  // the device publishes its local records to the picture wave at a trace's back edge (Emu::rq_flush); on the host a
+  // record IS the oracle's register write, so nothing ever waits
+  int wqn = 0;
+  void rq_flush() {}
   bool tia_log(int reg, int v, int cw, bool quiet = false) {
     (void)quiet;  // D1 unchanged: the oracle's own write renders first and then changes no pixel
     if ((log_calls++ % 5) == 4) return false;
