@@ -8,6 +8,20 @@ namespace atari {
 
 constexpr int kW = 160, kH = 210, kYStart = 34, kFrameBytes = kW * kH;
 constexpr int kHBlank = 68, kClocksPerLine = 228, kCyclesPerLine = 76;
+// the observation tail (frame_tail.hpp): the picture's 210 rows are 42 bands of 5; the env's two waves claim them in
+// two chunks from one counter (RenderQueue::obs_next, atari_core.hpp) and convert a chunk in calls of a
+// multiple of kObsStep bands, as far as the picture wave has declared them final (a call's first band waits a whole
+// memory round trip, ~3 k clocks, for its pixels — the frame pair of 1024 envs is 69 MB — so calls are long)
+// Two chunks: the first claim takes bands 0 .. kObsFirst - 1, the second the rest.  The first claimer is wave A at its
+// last instruction unless the picture wave ran out of records during the frame's overscan (it rarely does: through
+// the two rendered frames of a step it is the slower wave, ~20 k clocks behind at wave A's exit).  Measured at 1024
+// Pong envs (round 6, emu_bench): first chunk 12 / 15 / 18 bands 9.43 M frames/s, 21: 9.39, 27: 9.31, 30: 9.28 — a
+// launch lasts as long as its slowest env, not the mean one.
+#ifndef PARLHIP_OBS_FIRST
+#define PARLHIP_OBS_FIRST 18
+#endif
+constexpr int kObsBandRows = 5, kObsBands = kH / kObsBandRows, kObsFirst = PARLHIP_OBS_FIRST, kObsStep = 3;
+static_assert(kObsBands % kObsStep == 0 && kObsFirst % kObsStep == 0 && kObsFirst > 0 && kObsFirst < kObsBands, "whole steps");
 constexpr int kMaxInstrPerFrame = 25000;  // Stella: m6502().execute(25000)
 
 // ---- addressing modes / access kinds / operations of the pre-decoded instruction word ----

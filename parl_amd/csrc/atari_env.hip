@@ -183,7 +183,7 @@ DEVI void store_env(const Emu& e, const Wrap& v, uint8_t* blob, int lane) {
 __device__ unsigned long long g_env_t0[8192], g_env_t1[8192];
 #endif
 #ifdef PARLHIP_ENV_REGIONS  // diagnostic build only (tools/env_regions.py): where a wave's launch goes
-__device__ unsigned long long g_env_regions[8192][16];
+__device__ unsigned long long g_env_regions[8192][24];
 #endif
 #ifdef PARLHIP_ENV_TRACEITER
 __device__ unsigned long long g_env_traceiter[8192][16];
@@ -194,7 +194,9 @@ __device__ unsigned long long g_env_traceiter[8192][16];
 // allocation with the translated cartridges (the biggest function of the library, 500-1500 SGPR spills), and the
 // sixteen scalar registers of its register file went to spill lanes.  One call per launch; the arguments arrive in
 // vector registers (the calling convention) and are made wave-uniform again.
-__device__ __attribute__((noinline)) int picture_wave_main(uint8_t* blob_v, const uint8_t* snap_v, RenderQueue* rq_v, int e_v) {
+__device__ __attribute__((noinline)) int picture_wave_main(uint8_t* blob_v, const uint8_t* snap_v, RenderQueue* rq_v, int e_v,
+                                                           const uint8_t* frames_v, uint32_t* lds_hi_v, int wave_v,
+                                                           const StepFuse* fz_v) {
   auto uni = [](const void* p) -> unsigned long long {
     const unsigned long long x = (unsigned long long)(uintptr_t)p;
     return ((unsigned long long)(uint32_t)rfl((int)(x >> 32)) << 32) | (uint32_t)rfl((int)(uint32_t)x);
@@ -207,14 +209,36 @@ __device__ __attribute__((noinline)) int picture_wave_main(uint8_t* blob_v, cons
 #ifdef PARLHIP_ENV_REGIONS
   for (int i = 0; i < 5; ++i) { r.rt[i] = 0; r.rn[i] = 0; }
 #endif
-  const uint32_t exit_w0 = r.render_main(blob, snap, kSnapBytes);
-  // the launch's last frame is drawn and stored: the env's CPU wave may read the frame pair (observation tail)
+  // bands [b0, b1) of the observation of the frame being drawn (Emu::fb_flags): only launches that deliver observations
+  // ever flag a frame
+  auto convert = [&](int b0, int b1) {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // this wave's own frame stores, before it reads them back
+    const StepFuse* fz = (const StepFuse*)(uintptr_t)uni(fz_v);   // (the kernarg segment pointer is the KERNEL's: an argument here)
+    const int dim = fz->dim, env = rfl(e_v);
+    obs_tail_dispatch((const uint8_t*)(uintptr_t)uni(frames_v), fz->obs_out + (size_t)env * dim * dim, fz->tables,
+                      (uint32_t*)(uintptr_t)uni(lds_hi_v), dim, b0, b1, 0, rfl(wave_v));
+  };
+  const uint32_t exit_w0 = r.render_main(blob, snap, kSnapBytes, convert);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((exit_w0 & 0x300u) == 0x300u) {
+    // wave A's last frame was the flagged one and it is drawn as far as it will ever be: every band is final; both
+    // waves claim chunks until none is left
+    __atomic_store_n(&r.rq->obs_ready, (uint32_t)kObsBands, __ATOMIC_RELAXED);
+    for (;;) {
+      if (r.obs_cur >= r.obs_end) r.obs_take();
+      if (r.obs_cur >= kObsBands) break;
+      convert(r.obs_cur, r.obs_end);
+      r.obs_cur = r.obs_end;
+    }
+  }
+  // the launch's last frame is drawn and stored: the env's CPU wave may read the frame pair (the observation's halves
+  // when the flagged frame was not the last one)
   __atomic_store_n(&r.rq->fin, 1u, __ATOMIC_RELAXED);
 #ifdef PARLHIP_ENV_REGIONS
   const int e = rfl(e_v);
   if (r.lane == 0 && e < 8192) { g_env_regions[e][9] = r.rt[3]; g_env_regions[e][10] = r.rt[4]; g_env_regions[e][11] = r.rt[0];
-    g_env_regions[e][12] = r.rt[1]; g_env_regions[e][13] = (unsigned long long)r.rn[0]; g_env_regions[e][14] = (unsigned long long)r.rn[1]; }
+    g_env_regions[e][12] = r.rt[1]; g_env_regions[e][13] = (unsigned long long)r.rn[0]; g_env_regions[e][14] = (unsigned long long)r.rn[1];
+    g_env_regions[e][17] = r.rt[2]; g_env_regions[e][18] = (unsigned long long)r.rn[2]; g_env_regions[e][19] = __builtin_readcyclecounter(); }
 #else
   (void)e_v;
 #endif
@@ -240,7 +264,8 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
   __shared__ uint32_t rom_lds[kMaxRomWords];
   __shared__ RenderQueue rqs[kEnvsPerBlock];
   for (int i = threadIdx.x; i < prm.rom_size; i += blockDim.x) rom_lds[i] = romw_g[i];
-  if (threadIdx.x < kEnvsPerBlock) { rqs[threadIdx.x].wr = 0; rqs[threadIdx.x].rd = 0; rqs[threadIdx.x].cx = 0; rqs[threadIdx.x].fin = 0; }
+  if (threadIdx.x < kEnvsPerBlock) { rqs[threadIdx.x].wr = 0; rqs[threadIdx.x].rd = 0; rqs[threadIdx.x].cx = 0; rqs[threadIdx.x].fin = 0;
+                                    rqs[threadIdx.x].obs_next = 0; rqs[threadIdx.x].obs_ready = 0; }
   // the observation tail's two colour tables, in the half of rom_lds a 2K cartridge leaves free
   if (fuse_args()->obs_out) obs_tail_stage_tables(rom_lds + kMaxRomWords / 2, fuse_args()->tables, threadIdx.x);
   __syncthreads();
@@ -267,12 +292,13 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
   const int mode = prm.mode, game = prm.game;
   if (picture_wave) {
     uint8_t* rblob = mode == MODE_SNAPSHOT ? snap + (size_t)e * kSnapBytes : states + (size_t)e * kStateBytes;
-    const int exit_w0 = rfl(picture_wave_main(rblob, snap, &rqs[slot], e));
-    if (exit_w0 & 0x100) {   // wave A asks for the observation: this wave takes the lower half of the picture
+    const int exit_w0 = rfl(picture_wave_main(rblob, snap, &rqs[slot], e, frames + (size_t)e * 2 * kFrameBytes,
+                                              rom_lds + kMaxRomWords / 2, wave, fuse_args()));
+    if ((exit_w0 & 0x300) == 0x100) {   // wave A asks for the observation of another frame pair than the flagged one: this wave takes the lower half of the picture
       const StepFuse* fz = fuse_args();
       const int dim = fz->dim;
       obs_tail_dispatch(frames + (size_t)e * 2 * kFrameBytes, fz->obs_out + (size_t)e * dim * dim, fz->tables,
-                        rom_lds + kMaxRomWords / 2, dim, 1, exit_w0 & 1, wave);
+                        rom_lds + kMaxRomWords / 2, dim, kObsBands / 2, kObsBands, exit_w0 & 1, wave);
     }
     return;
   }
@@ -300,6 +326,7 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
   emu.rq_wr = 0;
   emu.cx_spec = 0;
   emu.cx_spec_seq = 0;
+  emu.fb_flags = 0;
   emu.wqn = 0;
   emu.wq = emu.wq2 = 0;
   uint8_t* blob;
@@ -409,6 +436,12 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
       emu.fire1 = swap ? fire : 0;
     }
     // ------------------------------------------------------------------ THE frame
+#ifdef PARLHIP_ENV_REGIONS
+    if (emu.rt[3] == 0) emu.rt[3] = __builtin_readcyclecounter() - k0;   // launch start -> first frame (staging, load, policy head)
+#endif
+    // the 4th frame of the agent step whose observation this launch delivers: unless the episode ends in it, it is the
+    // launch's last (obs_single is 0 after a completed step)
+    emu.fb_flags = (mode == MODE_STEP && phase == PH_SKIP && ctx == CTX_MAIN && skip_i == 3 && fuse_args()->obs_out != nullptr) ? 1 : 0;
     emu.frame<GAME>(fbp, native_ok);
     // ------------------------------------------------------------------ after the frame
     if (phase == PH_ALE) {
@@ -567,9 +600,18 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
   const StepFuse* fz = fuse_args();
   uint8_t* obs_out = mode == MODE_STEP ? fz->obs_out : nullptr;
   const bool do_obs = obs_out != nullptr && phase == PH_END;
-  emu.rq_ctl(Emu::LA_EXIT, (uint32_t)((do_obs ? 0x100 : 0) | (v.obs_single ? 1 : 0)), 0);
+#ifdef PARLHIP_ENV_REGIONS
+  const unsigned long long k_tail = __builtin_readcyclecounter();   // last frame done -> end (store, wait for the picture, observation)
+#endif
+  // the frame flagged for wave B (fb_flags) was indeed the launch's last: its bands are being converted already
+  const bool obs_banded = do_obs && !did_reset && !v.obs_single && emu.fb_flags == 1;
+  emu.rq_ctl(Emu::LA_EXIT, (uint32_t)((do_obs ? 0x100 : 0) | (obs_banded ? 0x200 : 0) | (v.obs_single ? 1 : 0)), 0);
   emu.rq_flush();
   store_env(emu, v, blob, lane);
+#ifdef PARLHIP_ENV_REGIONS
+  const unsigned long long k_tail1 = __builtin_readcyclecounter();
+  unsigned long long k_tail2 = k_tail1;
+#endif
   if (obs_out) {
     if (lane == 0) {
       uint8_t* sn = fz->since_next;   // (null: elastic launches keep the FrameStack counters in elastic_post_kernel)
@@ -586,11 +628,31 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
       }
     }
     if (do_obs) {
-      while (Emu::lds_ld(&emu.rq->fin) == 0u) __builtin_amdgcn_s_sleep(2);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       const int dim = fz->dim;
-      obs_tail_dispatch(buf0, obs_out + (size_t)e * dim * dim, fz->tables, rom_lds + kMaxRomWords / 2, dim, 0,
-                        v.obs_single, wave);
+      if (obs_banded) {
+        for (;;) {
+          emu.obs_take();
+          if (emu.obs_cur >= kObsBands) break;
+          while (emu.obs_cur < emu.obs_end) {
+            // as far as wave B has declared the bands final (all of them when it reaches LA_EXIT at the latest)
+            const int rdy = (int)Emu::lds_ld(&emu.rq->obs_ready);
+            const int n = ((rdy < emu.obs_end ? rdy : emu.obs_end) - emu.obs_cur) / kObsStep * kObsStep;
+            if (n <= 0) { __builtin_amdgcn_s_sleep(2); continue; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            obs_tail_dispatch(buf0, obs_out + (size_t)e * dim * dim, fz->tables, rom_lds + kMaxRomWords / 2, dim,
+                              emu.obs_cur, emu.obs_cur + n, 0, wave);
+            emu.obs_cur += n;
+          }
+        }
+      } else {
+        while (Emu::lds_ld(&emu.rq->fin) == 0u) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef PARLHIP_ENV_REGIONS
+        k_tail2 = __builtin_readcyclecounter();
+#endif
+        obs_tail_dispatch(buf0, obs_out + (size_t)e * dim * dim, fz->tables, rom_lds + kMaxRomWords / 2, dim, 0,
+                          kObsBands / 2, v.obs_single, wave);
+      }
     }
   }
 #ifdef PARLHIP_ENV_TIMING
@@ -600,6 +662,11 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
   if (lane == 0 && e < 8192) {
     for (int i = 0; i < 4; ++i) { g_env_regions[e][i] = emu.rt[i]; g_env_regions[e][4 + i] = (unsigned long long)emu.rn[i]; }
     g_env_regions[e][8] = __builtin_readcyclecounter() - k0;
+    // (packed: store | wait for the picture | observation, 21 bits each)
+    { const unsigned long long k3 = __builtin_readcyclecounter();
+      auto c21 = [](unsigned long long x) { return x > 0x1fffffull ? 0x1fffffull : x; };
+      g_env_regions[e][16] = k_tail;
+      g_env_regions[e][15] = c21(k_tail1 - k_tail) | (c21(k_tail2 - k_tail1) << 21) | (c21(k3 - k_tail2) << 42); }
   }
 #endif
 #ifdef PARLHIP_ENV_TRACEITER
@@ -911,7 +978,7 @@ PARLHIP_EXPORT int parlhip_debug_env_regions(unsigned long long* host, int n) {
 #ifdef PARLHIP_ENV_TRACEITER
   if (n < 0) return hipMemcpyFromSymbol(host, HIP_SYMBOL(parlhip::atari::g_env_traceiter), (size_t)(-n) * 128) == hipSuccess ? PARLHIP_OK : PARLHIP_EINVAL;
 #endif
-  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(parlhip::atari::g_env_regions), (size_t)n * 128) != hipSuccess) return PARLHIP_EINVAL;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(parlhip::atari::g_env_regions), (size_t)n * 192) != hipSuccess) return PARLHIP_EINVAL;
   return PARLHIP_OK;
 }
 #endif

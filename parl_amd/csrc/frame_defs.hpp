@@ -13,6 +13,16 @@ namespace atari {
 #endif
 
 struct Tap { int si; float alpha; };   // one INTER_AREA tap: source index, weight (parlhip_frame_post_tables_init)
+// The observation tail's view of the same taps (frame_tail.hpp), right after the blob's 32-byte header for the two
+// sizes it supports (0 bytes otherwise): x taps lane by lane — Tap[NC][NX][64], column dx = lane + 64 c, tap k; a tap
+// past the column's count repeats its first source pixel with weight 0, a column >= dim is (0, 0) — then the M * NY
+// y taps of band 0.  One round of independent loads at a fixed address instead of header -> xstart -> taps.
+constexpr int kTailHdrBytes = 32;
+constexpr int tail_lane_taps_nx(int dim) { return dim == 42 ? 5 : 3; }
+constexpr int tail_lane_taps_nc(int dim) { return dim > 64 ? 2 : 1; }
+constexpr int tail_lane_taps_bytes(int dim) {
+  return (dim == 42 || dim == 84) ? (tail_lane_taps_nc(dim) * tail_lane_taps_nx(dim) * 64 + 8) * 8 : 0;   // (8 Taps of room for the <= 6 y taps)
+}
 
 DEVI uint32_t gray_of_colors(uint32_t c0, uint32_t c1, const uint32_t* pal) {
   const uint32_t a = pal[c0 >> 1], b = pal[c1 >> 1];

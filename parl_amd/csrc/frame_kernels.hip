@@ -303,13 +303,14 @@ PARLHIP_EXPORT size_t parlhip_frame_post_tables_bytes(int dim) {
   std::vector<int> tmp(dim + 1);
   const int nx = area_tab(kW, dim, tmp.data(), nullptr);
   const int ny = area_tab(kH, dim, tmp.data(), nullptr);
-  return 8 * 4 + 2 * (size_t)(dim + 1) * 4 + (size_t)(nx + ny) * sizeof(Tap) + 128 * 4;
+  return 8 * 4 + (size_t)tail_lane_taps_bytes(dim) + 2 * (size_t)(dim + 1) * 4 + (size_t)(nx + ny) * sizeof(Tap) + 128 * 4;
 }
 
 PARLHIP_EXPORT int parlhip_frame_post_tables_init(void* host_blob, int dim) {
   if (!host_blob || dim < 1 || dim > 210) return PARLHIP_EINVAL;
   int* hdr = (int*)host_blob;
-  int* xstart = hdr + 8;
+  Tap* lane_taps = (Tap*)(hdr + 8);
+  int* xstart = (int*)((char*)(hdr + 8) + tail_lane_taps_bytes(dim));
   int* ystart = xstart + dim + 1;
   Tap* xt = (Tap*)(ystart + dim + 1);
   const int nx = area_tab(kW, dim, xstart, xt);
@@ -323,6 +324,24 @@ PARLHIP_EXPORT int parlhip_frame_post_tables_init(void* host_blob, int dim) {
   hdr[5] = (int)((char*)xt - (char*)host_blob);
   hdr[6] = (int)((char*)yt - (char*)host_blob);
   hdr[7] = (int)((char*)(pal + 128) - (char*)host_blob);
+  if (tail_lane_taps_bytes(dim)) {   // the observation tail's lane-ordered copy (frame_defs.hpp)
+    const int NX = tail_lane_taps_nx(dim), NC = tail_lane_taps_nc(dim), M = dim / 42, NY = dim == 42 ? 5 : 3;
+    for (int c = 0; c < NC; ++c)
+      for (int k = 0; k < NX; ++k)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int dx = lane + 64 * c;
+          Tap t = {0, 0.f};
+          if (dx < dim) {
+            const int x0 = xstart[dx], n = xstart[dx + 1] - x0;
+            if (n > NX) return PARLHIP_EINVAL;
+            t.si = xt[x0 + (k < n ? k : 0)].si;
+            t.alpha = k < n ? xt[x0 + k].alpha : 0.f;
+          }
+          lane_taps[(c * NX + k) * 64 + lane] = t;
+        }
+    Tap* ylane = lane_taps + NC * NX * 64;
+    for (int j = 0; j < 8; ++j) ylane[j] = j < M * NY ? yt[j] : Tap{0, 0.f};
+  }
   return PARLHIP_OK;
 }
 

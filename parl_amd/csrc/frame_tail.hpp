@@ -35,7 +35,7 @@ typedef __attribute__((address_space(3))) tail_u4 tail_lds_u4;
 typedef __attribute__((address_space(1))) uint8_t tail_glb_u8;
 typedef __attribute__((address_space(1))) const tail_u4 tail_glb_cu4;
 
-constexpr int kTailBandRows = 5;                       // source rows per band
+constexpr int kTailBandRows = kObsBandRows;            // source rows per band (5)
 constexpr int kTailBands = kH / kTailBandRows;         // 42
 constexpr int kTailBandBytes = kTailBandRows * kW;     // 800
 constexpr int kTailBandLanes = kTailBandBytes / 16;    // 50 lanes load a band
@@ -68,7 +68,7 @@ DEVI void obs_tail_stage_tables(uint32_t* lds_hi, const uint8_t* blob, int tid) 
 // round trip per tap: 50 us per env).
 template <int DIM>
 static __device__ __attribute__((noinline)) void obs_tail_main(const uint8_t* frames_v, uint8_t* out_v, const uint8_t* blob_v,
-                                                               uint32_t* lds_hi_v, int half_v, int single_v, int wave_v) {
+                                                               uint32_t* lds_hi_v, int b_begin_v, int b_end_v, int single_v, int wave_v) {
   constexpr int M = DIM / kTailBands;             // output rows per band
   constexpr int NY = DIM == 42 ? 5 : 3;           // y taps per output row
   constexpr int NX = DIM == 42 ? 5 : 3;           // x taps per output column (fewer: padded with weight 0)
@@ -80,7 +80,7 @@ static __device__ __attribute__((noinline)) void obs_tail_main(const uint8_t* fr
            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
   };
   const int lane = (int)(threadIdx.x & 63);
-  const int half = __builtin_amdgcn_readfirstlane(half_v);
+  const int b_begin = __builtin_amdgcn_readfirstlane(b_begin_v), b_end = __builtin_amdgcn_readfirstlane(b_end_v);
   const int single = __builtin_amdgcn_readfirstlane(single_v), wave = __builtin_amdgcn_readfirstlane(wave_v);
   const uint8_t* blob = (const uint8_t*)(uintptr_t)uni(blob_v);
   tail_glb_cu4* f0 = (tail_glb_cu4*)(uintptr_t)uni(frames_v);
@@ -91,57 +91,61 @@ static __device__ __attribute__((noinline)) void obs_tail_main(const uint8_t* fr
   const tail_lds_u8* g1 = hi + kTailLdsG1;
   tail_lds_u8* band = hi + kTailLdsBands + wave * kTailBandBytes;
 
-  const int* hdr = (const int*)blob;
-  const int* xstart = (const int*)(blob + hdr[3]);
-  const Tap* xt = (const Tap*)(blob + hdr[5]);
-  typedef int tail_i2 __attribute__((ext_vector_type(2)));
-  typedef __attribute__((address_space(1))) const tail_i2 glb_tap;   // (si, alpha bits)
-  glb_tap* yt = (glb_tap*)(uintptr_t)(blob + hdr[6]);
-
-  // the lane's output columns dx = lane (+ 64 at dim 84) and their x taps; a tap past the column's count carries
-  // weight 0 on the column's first source pixel (buf + S * 0 == buf exactly: buf >= 0)
+  // the lane's output columns dx = lane (+ 64 at dim 84) and their x taps, the band's y taps: the lane-ordered copy at
+  // the head of the tables (frame_defs.hpp tail_lane_taps_bytes) — independent loads, in flight together with the
+  // first bands' pixels (a chunk of three bands is one call of this function: header -> xstart -> taps were three
+  // memory round trips before its first pixel)
+  // (one 64-bit load per tap, split by shifts: as an int2 vector hipcc 7.2 copied .x over .y after the loads)
+  typedef __attribute__((address_space(1))) const unsigned long long glb_tap;   // (si, alpha bits)
+  glb_tap* lt = (glb_tap*)(uintptr_t)(blob + kTailHdrBytes);
+  static_assert(tail_lane_taps_nx(DIM) == NX && tail_lane_taps_nc(DIM) == NC, "the host's lane-ordered taps");
+  unsigned long long xtap[NC][NX];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int k = 0; k < NX; ++k) xtap[c][k] = lt[(c * NX + k) * 64 + lane];
+  const unsigned long long ytap = lt[NC * NX * 64 + (lane < M * NY ? lane : 0)];
+  // bands b_begin .. b_end - 1: a multiple of kTailDepth of them (the halves 0 .. 20 / 21 .. 41, or kObsStep * n bands
+  // of a chunk claimed from the env's band counter, atari_core.hpp RenderQueue::obs_next)
+  const bool loader = lane < kTailBandLanes;
+  // the colour pixels of kTailDepth bands are in flight at any time: the frame pair was stored by the picture wave long
+  // ago and comes from HBM / the far L2 (1024 envs x 67 KB), one band ahead left a memory round trip per band exposed
+  constexpr int kTailDepth = 3;
+  static_assert((kTailBands / 2) % kTailDepth == 0 && kObsStep % kTailDepth == 0, "the band loop is unrolled by the prefetch depth");
+  tail_u4 pa[kTailDepth], pb[kTailDepth];
+#pragma unroll
+  for (int s = 0; s < kTailDepth; ++s) { pa[s] = tail_u4{0u, 0u, 0u, 0u}; pb[s] = pa[s]; }
+#pragma unroll
+  for (int s = 0; s < kTailDepth; ++s)
+    if (loader) {
+      pa[s] = f0[(b_begin + s) * kTailBandLanes + lane];
+      pb[s] = f1[(b_begin + s) * kTailBandLanes + lane];
+    }
+  // (a tap past the column's count carries weight 0 on the column's first source pixel: buf + S * 0 == buf exactly,
+  // buf >= 0; the y taps of a band, row by row, are the same (row inside the band, weight) in every band — 210 / dim and
+  // dim / 42 are exact in binary — checked on the host-built tables by tests/test_capi_symbols.py)
   int xsi[NC][NX];
   float xal[NC][NX];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const int dx = lane + 64 * c;
-    const bool on = dx < DIM;
-    const int x0 = on ? xstart[dx] : 0;
-    const int nx = on ? xstart[dx + 1] - x0 : 0;
+  for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int k = 0; k < NX; ++k) {
-      const Tap t = xt[x0 + (k < nx ? k : 0)];
-      xsi[c][k] = t.si;
-      xal[c][k] = k < nx ? t.alpha : 0.f;
-    }
-  }
-
-  const int b_begin = half ? kTailBands / 2 : 0, b_end = half ? kTailBands : kTailBands / 2;
-  const bool loader = lane < kTailBandLanes;
-  // the y taps of a band, row by row: the same (row inside the band, weight) in every band — 210 / dim and dim / 42
-  // are exact in binary, so the table repeats with the band (checked on the host-built tables by the tests) —
-  // fetched once, from band 0; a per-band fetch sat in the loop as a load whose wait also drained the pixel prefetch
+    for (int k = 0; k < NX; ++k) { xsi[c][k] = (int)(uint32_t)xtap[c][k]; xal[c][k] = __builtin_bit_cast(float, (uint32_t)(xtap[c][k] >> 32)); }
   int rowoff[M * NY];
   float beta[M * NY];
-  {
-    const tail_i2 t = yt[lane < M * NY ? lane : 0];
 #pragma unroll
-    for (int j = 0; j < M * NY; ++j) {
-      rowoff[j] = __builtin_amdgcn_readlane(t.x, j) * kW;
-      beta[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(t.y, j));
-    }
+  for (int j = 0; j < M * NY; ++j) {
+    rowoff[j] = __builtin_amdgcn_readlane((int)(uint32_t)ytap, j) * kW;
+    beta[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)(uint32_t)(ytap >> 32), j));
   }
-  tail_u4 na = {0u, 0u, 0u, 0u}, nb = na;
-  auto prefetch = [&](int bi) {
-    if (loader) {
-      na = f0[bi * kTailBandLanes + lane];
-      nb = f1[bi * kTailBandLanes + lane];
+  for (int bi0 = b_begin; bi0 < b_end; bi0 += kTailDepth)
+#pragma unroll
+  for (int s = 0; s < kTailDepth; ++s) {
+    const int bi = bi0 + s;
+    const tail_u4 a = pa[s], b = pb[s];
+    if (loader && bi + kTailDepth < b_end) {
+      pa[s] = f0[(bi + kTailDepth) * kTailBandLanes + lane];
+      pb[s] = f1[(bi + kTailDepth) * kTailBandLanes + lane];
     }
-  };
-  prefetch(b_begin);
-  for (int bi = b_begin; bi < b_end; ++bi) {
-    const tail_u4 a = na, b = nb;
-    if (bi + 1 < b_end) prefetch(bi + 1);
     // ---- max over the two frames + gray: 16 pixels per lane (frame_post_kernel's fmt == 1 arm)
     {
       const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
@@ -213,10 +217,10 @@ static __device__ __attribute__((noinline)) void obs_tail_main(const uint8_t* fr
 }
 
 // (dim is wave-uniform at the call sites: one branch, two instantiations)
-DEVI void obs_tail_dispatch(const uint8_t* frames, uint8_t* out, const uint8_t* blob, uint32_t* lds_hi, int dim, int half,
-                            int single, int wave) {
-  if (dim == 42) obs_tail_main<42>(frames, out, blob, lds_hi, half, single, wave);
-  else obs_tail_main<84>(frames, out, blob, lds_hi, half, single, wave);
+DEVI void obs_tail_dispatch(const uint8_t* frames, uint8_t* out, const uint8_t* blob, uint32_t* lds_hi, int dim, int b_begin,
+                            int b_end, int single, int wave) {
+  if (dim == 42) obs_tail_main<42>(frames, out, blob, lds_hi, b_begin, b_end, single, wave);
+  else obs_tail_main<84>(frames, out, blob, lds_hi, b_begin, b_end, single, wave);
 }
 
 }  // namespace atari

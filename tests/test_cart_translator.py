@@ -61,7 +61,7 @@ def test_hot_loops_are_emitted_as_traces():
     assert {0x1b, 0x1c, 0x1d, 0x1e, 0x1f} <= tr.shadows
     src = c.source('GAME_PONG')
     assert 'trace of the loop f5e0 .. f63c' in src and 'TL_F5E0:' in src and 'goto TL_F5E0;' in src
-    assert 'e.sbc_bin(m);' in src and 'const int m = h_33;' in src
+    assert 'e.sbc_bin_f<false, false>(m);' in src and 'const int m = h_33;' in src   # (V and C dead after it: round 6's flag liveness)
     assert '{ e.PC = 0xf5e0; e.pend = -2; return; }' in src          # the generic copy's back edge
     assert 'if (e.PC == 0xf5e0) goto L_F5E0;' in src                  # the hottest head ahead of the switch's compare tree
     i0 = src.index('TL_F5E0:')
@@ -213,7 +213,8 @@ def test_host_harness_alu_is_the_device_text_and_matches_oracle(tmp_path):
     dev = open(os.path.join(ROOT, 'parl_amd', 'csrc', 'atari_core.hpp')).read()
     host = open(os.path.join(ROOT, 'tests', 'tools', 'cart_host', 'main.cpp')).read()
     for sig in ('void adc(int m)', 'void sbc(int m)', 'void cmp(int r, int m)', 'void bit(int m)', 'void set_nz(int v)',
-                'int pfull() const', 'void pset(int v)'):
+                'int pfull() const', 'void pset(int v)', 'void adc_bin_f(int m)', 'void sbc_bin_f(int m)', 'void adc_f(int m)',
+                'void sbc_f(int m)', 'void cmp_f(int r, int m)', 'void bit_f(int m)', 'void adc_bin(int m)', 'void sbc_bin(int m)'):
         assert _fn_body(dev, sig) == _fn_body(host, sig), sig
     d = str(tmp_path)
     src = os.path.join(ROOT, 'tests', 'tools', 'cart_host')

@@ -87,30 +87,45 @@ struct Emu {
     P = (P & ~FV) | ((((old ^ m) & (old ^ A)) >> 1) & FV);
     set_nz(A);
   }
-  void adc_bin(int m) {
+  // the translated code's forms with a statically dead V / C left alone: the device's text (Emu::adc_bin_f ... in
+  // atari_core.hpp, compared by tests/test_cart_translator.py)
+  template <bool KV, bool KC> void adc_bin_f(int m) {
     const int old = A;
-    const int sum = A + m + cf;
-    cf = (sum >> 8) & 1;
+    const int sum = A + m + cf;              // 0 .. 511
+    if (KC) cf = (sum >> 8) & 1;
     A = sum & 0xff;
-    P = (P & ~FV) | (((~(old ^ m) & (old ^ A)) >> 1) & FV);
+    if (KV) P = (P & ~FV) | (((~(old ^ m) & (old ^ A)) >> 1) & FV);
     set_nz(A);
   }
-  void sbc_bin(int m) {
+  template <bool KV, bool KC> void sbc_bin_f(int m) {
     const int old = A;
-    const int bin = old - m - (cf ^ 1);
+    const int bin = old - m - (cf ^ 1);      // -256 .. 255
     A = bin & 0xff;
-    cf = ((bin >> 8) & 1) ^ 1;
-    P = (P & ~FV) | ((((old ^ m) & (old ^ A)) >> 1) & FV);
+    if (KC) cf = ((bin >> 8) & 1) ^ 1;
+    if (KV) P = (P & ~FV) | ((((old ^ m) & (old ^ A)) >> 1) & FV);
     set_nz(A);
   }
-  void cmp(int r, int m) { const int d = r - m; cf = ((d >> 8) & 1) ^ 1; set_nz(d & 0xff); }
-  // the translated code's forms with a statically dead V / C left alone (Emu::adc_f ... in atari_core.hpp)
-  template <bool KV, bool KC> void adc_f(int m) { const int sp = P, sc = cf; adc(m); if (!KV) P = (P & ~FV) | (sp & FV); if (!KC) cf = sc; }
-  template <bool KV, bool KC> void sbc_f(int m) { const int sp = P, sc = cf; sbc(m); if (!KV) P = (P & ~FV) | (sp & FV); if (!KC) cf = sc; }
-  template <bool KV, bool KC> void adc_bin_f(int m) { const int sp = P, sc = cf; adc_bin(m); if (!KV) P = (P & ~FV) | (sp & FV); if (!KC) cf = sc; }
-  template <bool KV, bool KC> void sbc_bin_f(int m) { const int sp = P, sc = cf; sbc_bin(m); if (!KV) P = (P & ~FV) | (sp & FV); if (!KC) cf = sc; }
-  template <bool KC> void cmp_f(int r, int m) { const int sc = cf; cmp(r, m); if (!KC) cf = sc; }
-  template <bool KV> void bit_f(int m) { const int sp = P; bit(m); if (!KV) P = (P & ~FV) | (sp & FV); }
+  template <bool KV, bool KC> void adc_f(int m) {
+    const int sp = P, sc = cf;
+    adc(m);
+    if (!KV) P = (P & ~FV) | (sp & FV);
+    if (!KC) cf = sc;
+  }
+  template <bool KV, bool KC> void sbc_f(int m) {
+    const int sp = P, sc = cf;
+    sbc(m);
+    if (!KV) P = (P & ~FV) | (sp & FV);
+    if (!KC) cf = sc;
+  }
+  void adc_bin(int m) { adc_bin_f<true, true>(m); }
+  void sbc_bin(int m) { sbc_bin_f<true, true>(m); }
+  template <bool KC> void cmp_f(int r, int m) {
+    const int d = r - m;                     // -255 .. 255
+    if (KC) cf = ((d >> 8) & 1) ^ 1;         // r >= m
+    set_nz(d & 0xff);
+  }
+  void cmp(int r, int m) { cmp_f<true>(r, m); }
+  template <bool KV> void bit_f(int m) { if (KV) P = (P & ~FV) | (m & FV); nv = m; zv = A & m; }
 
   // the lanes of the device's TIA register file a translated loop keeps scalar shadows of (Emu::t / tset):
   // the write registers its stores are compared with, and the delayed-graphics latches (atari_defs.hpp TiaLane)
