@@ -83,9 +83,9 @@ class KernelTimer(object):
 # SQ counters of atari_env_kernel<Pong> at E = 1024 (profiles/r05_env_pmc.log: the kernel with the policy head at its head
 # and the observation at its tail): active instructions per wave-clock of the two waves an env occupies
 ENV_PMC = {'game': 'PongNoFrameskip-v4', 'envs': 1024, 'dim': 42,
-           'issue_slot_utilisation': 80224.0 / 209577.0, 'instructions_per_frame': 80224,
-           'source': 'profiles/r05_env_pmc.log (rocprofv3 --pmc, tools/pmc_env.sh): SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES per '
-                     'wave and emulated frame, both in 4-clock issue slots — a wave of this kernel issues in 38 % of its '
+           'issue_slot_utilisation': 70759.0 / 161931.0, 'instructions_per_frame': 70759,
+           'source': 'profiles/r06_env_pmc.log (rocprofv3 --pmc, tools/pmc_env.sh): SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES per '
+                     'wave and emulated frame, both in 4-clock issue slots — a wave of this kernel issues in 44 % of its '
                      'slots, two such waves share a SIMD'}
 
 
@@ -94,7 +94,7 @@ def pmc_traffic(key):
     shape (profiles/r01_scan_hbm_traffic.json, produced by tools/prof_traffic.sh: separate
     FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction).  bench.py cannot run under two
     rocprofv3 passes itself; the source file is named next to the number."""
-    for name in ('r05_hbm_traffic.json', 'r04_hbm_traffic.json', 'r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01e_scan_hbm_traffic.json', 'r01_scan_hbm_traffic.json'):
+    for name in ('r06_hbm_traffic.json', 'r05_hbm_traffic.json', 'r04_hbm_traffic.json', 'r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01e_scan_hbm_traffic.json', 'r01_scan_hbm_traffic.json'):
         try:
             t = json.load(open(os.path.join(ROOT, 'profiles', name)))[key]
             return {'traffic': t['hbm_traffic_bytes'], 'traffic_source': 'profiles/%s:%s' % (name, key)}
@@ -105,7 +105,7 @@ def pmc_traffic(key):
 
 def kernel_only_profile(by):
     try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r05_heads_loss_kernel_only.json')))
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r06_heads_loss_kernel_only.json')))
         return {'us': d['avg_us'], 'frac': by / (d['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 'source': d['source'],
                 'measured_in_this_run': False}
     except (OSError, KeyError, ValueError):
