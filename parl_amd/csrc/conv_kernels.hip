@@ -1093,7 +1093,19 @@ constexpr int kZ3P = 13, kZ3Plane = kZ3P * kZ3P;                      // dz3 pad
 constexpr int kLds3bFloats = 64 * kM2b + 64 * kZ3Plane + 128;          // 7,744 + 10,816 + 128 = 18,688 floats = 74,752 B
 constexpr int kPart3 = 64 * 576 + 64;                                  // dW3 [o][k'] + db3
 
-__global__ __launch_bounds__(256) void conv3_84_bwd_kernel(
+// PARLHIP_C84_COEX (experiment): <= 256 registers per lane so that two env waves (2 x 128) fit beside this wave on a SIMD;
+// >= 2: the 84x84 kernels that run two workgroups per CU run one (kC84PerCU)
+#if defined(PARLHIP_C84_COEX) && PARLHIP_C84_COEX >= 2
+constexpr int kC84PerCU = 1;
+#else
+constexpr int kC84PerCU = 2;
+#endif
+#ifdef PARLHIP_C84_COEX
+#define PARLHIP_C84_BWD_BOUNDS __launch_bounds__(256, 2)
+#else
+#define PARLHIP_C84_BWD_BOUNDS __launch_bounds__(256)
+#endif
+__global__ PARLHIP_C84_BWD_BOUNDS void conv3_84_bwd_kernel(
     const float* __restrict__ a2, const float* __restrict__ a3, const float* __restrict__ dy3,
     const float* __restrict__ wt3b, float* __restrict__ dz2, float* __restrict__ partial, int n_obs) {
   extern __shared__ float lds[];
@@ -1247,7 +1259,7 @@ __global__ __launch_bounds__(256) void conv3_84_bwd_kernel(
 constexpr int kLds2bFloats = 32 * kA1Plane + 64 * kM2b + 128;            // 18,432 + 7,744 + 128 = 26,304 floats = 105,216 B
 constexpr int kPart2 = 64 * 512 + 64;
 
-__global__ __launch_bounds__(256) void conv2_84_bwd_kernel(
+__global__ PARLHIP_C84_BWD_BOUNDS void conv2_84_bwd_kernel(
     const float* __restrict__ a1, const float* __restrict__ dz2, const float* __restrict__ wt2b,
     float* __restrict__ dz1, float* __restrict__ partial, int n_obs) {
   extern __shared__ float lds[];
@@ -1619,7 +1631,7 @@ static int launch_conv1_84(const uint8_t* obs, const RingObs& ro, const float* w
     }
     attr_set = true;
   }
-  const int grid = n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU;  // 28 KB of LDS, <= 256 VGPRs: two workgroups per CU
+  const int grid = n_obs < kC84PerCU * kNumCU ? n_obs : kC84PerCU * kNumCU;  // 28 KB of LDS, <= 256 VGPRs: two workgroups per CU
 #define PARLHIP_C184(R, P, O, RO) conv1_84_u8_mfma_kernel<R, P><<<grid, 256, lds_bytes, stream>>>(O, RO, w, b1, out, n_obs)
   if (ro.ring) {
     if (packed) PARLHIP_C184(true, true, nullptr, ro);
@@ -1759,7 +1771,7 @@ PARLHIP_EXPORT int parlhip_atari84_conv23_f32(const float* a1, const float* wt2,
   }
   // 49 KB of LDS: up to three workgroups per CU (two are launched: more only shortens the streamed-weight reuse),
   // one beside a learner workgroup
-  const int grid = n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU;
+  const int grid = n_obs < kC84PerCU * kNumCU ? n_obs : kC84PerCU * kNumCU;
   conv23_84_mfma_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(a1, wt2, b2, wt3, b3, a2_out, a3_out, n_obs);
   return check_launch();
 }
@@ -1821,7 +1833,7 @@ PARLHIP_EXPORT int parlhip_atari84_conv2_bwd_f32(const float* a1, const float* d
 
 // conv1_84_bwd_kernel: 80.7 KB of LDS and <= 256 VGPRs — two workgroups per CU, each one's fill and store phases under
 // the other's MFMAs (conv3 / conv2: 276+ VGPRs of accumulators, one wave per SIMD whatever the grid)
-static int bwd84_conv1_grid(int n_obs) { return n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU; }
+static int bwd84_conv1_grid(int n_obs) { return n_obs < kC84PerCU * kNumCU ? n_obs : kC84PerCU * kNumCU; }
 
 PARLHIP_EXPORT size_t parlhip_atari84_conv1_bwd_workspace_bytes(int n_obs) {
   return n_obs <= 0 ? 0 : (size_t)bwd84_conv1_grid(n_obs) * kPart1 * sizeof(float);
