@@ -145,6 +145,45 @@ def test_frame_post_tables_have_the_structure_the_observation_tail_assumes(built
     assert per_band[0, :, 0].min() == 0 and per_band[0, :, 0].max() == 4
 
 
+@pytest.mark.parametrize('dim,ny,nx', [(42, 5, 5), (84, 3, 3)])
+def test_frame_post_tables_lane_ordered_copy_equals_the_generic_tables(built_lib, dim, ny, nx):
+    """The observation tail reads its x / y taps from a lane-ordered copy right behind the blob's 32-byte header
+    (csrc/frame_defs.hpp tail_lane_taps_bytes: Tap[NC][NX][64] then the first band's y taps): it must be the generic
+    tables re-ordered — column dx = lane + 64 c, tap k; a tap past the column's count = the column's first source pixel
+    with weight 0; a column >= dim = (0, 0).  Host function of the product library, no GPU."""
+    import numpy as np
+    from parl_amd import _native
+    lib = _native.lib()
+    nb = lib.parlhip_frame_post_tables_bytes(dim)
+    blob = np.zeros(nb, np.uint8)
+    assert lib.parlhip_frame_post_tables_init(blob.ctypes.data, dim) == 0
+    hdr = blob[:32].view(np.int32)
+    xstart = blob[hdr[3]:hdr[3] + 4 * (dim + 1)].view(np.int32)
+    ystart = blob[hdr[4]:hdr[4] + 4 * (dim + 1)].view(np.int32)
+    xt = blob[hdr[5]:hdr[5] + 8 * int(xstart[dim])].view(np.int32).reshape(-1, 2)   # (si, alpha bits)
+    yt = blob[hdr[6]:hdr[6] + 8 * int(ystart[dim])].view(np.int32).reshape(-1, 2)
+    nc = 2 if dim > 64 else 1
+    assert hdr[3] == 32 + (nc * nx * 64 + 8) * 8                                   # the copy sits between header and xstart
+    lane = blob[32:32 + nc * nx * 64 * 8].view(np.int32).reshape(nc, nx, 64, 2)
+    for c in range(nc):
+        for ln in range(64):
+            dx = ln + 64 * c
+            for k in range(nx):
+                si, al = lane[c, k, ln]
+                if dx >= dim:
+                    assert (si, al) == (0, 0)
+                    continue
+                x0, n = int(xstart[dx]), int(xstart[dx + 1] - xstart[dx])
+                assert n <= nx
+                if k < n:
+                    assert (si, al) == tuple(xt[x0 + k])
+                else:
+                    assert si == xt[x0, 0] and al == 0                              # weight +0.0f
+    m = dim // 42
+    ylane = blob[32 + nc * nx * 64 * 8:32 + (nc * nx * 64 + 8) * 8].view(np.int32).reshape(8, 2)
+    assert (ylane[:m * ny] == yt[:m * ny]).all() and (ylane[m * ny:] == 0).all()
+
+
 def test_state_blob_constants_python_side_match_the_header():
     """DeviceVectorEnv.running_episode_steps reads MonitorEnv's step counter out of an env's state blob: the byte
     offset of the scalar slots and the slot index are csrc/atari_defs.hpp's"""
