@@ -247,6 +247,8 @@ class GraphedLearn(object):
         torch.cuda.synchronize(dev)
         self.graphs = []
         kw = {'pool': self.pool} if self.pool is not None else {}
+        from ... import dist as pdist
+        tl = pdist.graph_capture_kwargs()   # (a process group's watchdog thread queries events while we capture)
         self.allreduce_in_graph = False
         if split and self._collective_capturable():
             # Data-parallel update as ONE hipGraph: forward + backward | RCCL all-reduce of the flat bucket | clip +
@@ -257,7 +259,7 @@ class GraphedLearn(object):
             # (a backend that cannot be captured), the two-graph form below takes over.
             g1 = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g1, capture_error_mode='thread_local', **kw):
+                with torch.cuda.graph(g1, **{**kw, 'capture_error_mode': 'thread_local'}):
                     self._forward_backward()
                     alg.grad_hook(alg.model)
                     self._clip_and_step()
@@ -271,15 +273,15 @@ class GraphedLearn(object):
             pass
         elif split:
             g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, **kw):
+            with torch.cuda.graph(g1, **kw, **tl):
                 self._forward_backward()
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g1.pool()):
+            with torch.cuda.graph(g2, pool=g1.pool(), **tl):
                 self._clip_and_step()
             self.graphs = [g1, g2]
         else:
             g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, **kw):
+            with torch.cuda.graph(g1, **kw, **tl):
                 self._forward_backward()
                 self._clip_and_step()
             self.graphs = [g1]

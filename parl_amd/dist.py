@@ -92,6 +92,18 @@ def init(backend=None, force=False, timeout_s=None, collective_timeout_s=None):
     return rank, local, world
 
 
+def graph_capture_kwargs():
+    """Keyword arguments for torch.cuda.graph(...) of EVERY capture in this package.  With a process group alive,
+    ProcessGroupNCCL's watchdog thread polls its outstanding collectives with hipEventQuery; under the default
+    capture mode ('global') any such call from any thread while a capture is open fails with
+    hipErrorStreamCaptureUnsupported, the watchdog throws and the process aborts (seen once in 265 runs of the GPU
+    suite: an eager all-reduce still outstanding when a rollout segment was being captured).  'thread_local' confines
+    the check to the capturing thread, which is the only one of ours that issues HIP work."""
+    if dist.is_available() and dist.is_initialized():
+        return {'capture_error_mode': 'thread_local'}
+    return {}
+
+
 def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 

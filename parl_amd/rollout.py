@@ -13,6 +13,7 @@ import os
 
 import torch
 
+from . import dist as pdist
 from . import ops
 
 
@@ -213,6 +214,7 @@ class DeviceRollout(object):
             st = torch.cuda.current_stream(env.device)
             g = torch.cuda.CUDAGraph()
             kw = {'pool': self._graph_pool} if self._graph_pool is not None else {}
+            kw.update(pdist.graph_capture_kwargs())
             with torch.cuda.graph(g, stream=st, **kw):
                 for t in range(t0, t1):
                     self.collect_step(model, t)
@@ -543,7 +545,7 @@ class DeviceA2CRollout(object):
             t0 = env.t
             g = torch.cuda.CUDAGraph()
             side.wait_stream(cur)
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side, **pdist.graph_capture_kwargs()):
                 model.refresh_actor_layout()     # inside the graph: every replay starts from the current weights
                 model._lay_pinned = True
                 try:
