@@ -146,6 +146,25 @@ static __device__ __attribute__((noinline)) void obs_tail_main(const uint8_t* fr
       pa[s] = f0[(bi + kTailDepth) * kTailBandLanes + lane];
       pb[s] = f1[(bi + kTailDepth) * kTailBandLanes + lane];
     }
+    // ---- a band of ONE colour in both frames (most of Pong's picture): every output pixel of the band is that colour's
+    // gray — the area taps of a constant sum to it within 1e-4 and the result is rounded to the nearest integer
+    // (tests/test_frame_oracle_pin.py checks every colour at both sizes on the oracle) — no LDS band, no taps: the
+    // env's two waves share one SIMD, and through the observation both are bound by its vector ALU
+    {
+      const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.x);
+      const bool flat = (((a.x ^ c0) | (a.y ^ c0) | (a.z ^ c0) | (a.w ^ c0) | (b.x ^ c0) | (b.y ^ c0) | (b.z ^ c0) | (b.w ^ c0)) & 0xfefefefeu) == 0u;
+      if ((((c0 ^ (c0 >> 8)) & 0x00fefefeu) == 0u) && __ballot(loader && !flat) == 0ull) {
+        const uint8_t g = g1[(c0 >> 1) & 127];
+#pragma unroll
+        for (int r = 0; r < M; ++r)
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int dx = lane + 64 * c;
+            if (dx < DIM) out[(bi * M + r) * DIM + dx] = g;
+          }
+        continue;
+      }
+    }
     // ---- max over the two frames + gray: 16 pixels per lane (frame_post_kernel's fmt == 1 arm)
     {
       const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};

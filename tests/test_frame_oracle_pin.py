@@ -146,3 +146,24 @@ def test_opencv_gray_variants_enumerated():
     assert pairs == [(5, 95), (23, 110), (52, 118), (59, 83), (66, 74), (69, 119)]
     # the oracle itself is the 14-bit variant
     assert np.array_equal(gray_ref(mx.astype(np.uint8)), a.astype(np.uint8))
+
+
+@pytest.mark.parametrize('dim', [42, 84])
+def test_a_picture_of_one_colour_becomes_that_colours_gray(dim):
+    """The observation tail (csrc/frame_tail.hpp) stores a band of one colour as that colour's gray without running the
+    area taps: on the oracle every colour byte, as a whole constant picture, must come out as exactly that — the
+    taps of a constant sum to it within float rounding and cv::saturate_cast rounds to the nearest integer."""
+    import numpy as np
+    from oracle import c_oracle
+    from parl_amd import _native
+    lib = _native.lib()
+    nb = lib.parlhip_frame_post_tables_bytes(dim)
+    blob = np.zeros(nb, np.uint8)
+    assert lib.parlhip_frame_post_tables_init(blob.ctypes.data, dim) == 0
+    hdr = blob[:32].view(np.int32)
+    pal = blob[hdr[7] - 512:hdr[7]].view(np.uint32).astype(np.int64)     # colour >> 1 -> 0xRRGGBB (the product's table)
+    gray = (((pal >> 16) & 255) * 4899 + ((pal >> 8) & 255) * 9617 + (pal & 255) * 1868 + 8192) >> 14
+    for c in range(256):
+        f = np.full((1, 210, 160), c, np.uint8)
+        out = c_oracle.frame_post(f, f, dim, 1)
+        assert (out == gray[c >> 1]).all(), (dim, c, np.unique(out), gray[c >> 1])
