@@ -17,10 +17,13 @@ constexpr int kHBlank = 68, kClocksPerLine = 228, kCyclesPerLine = 76;
 // the two rendered frames of a step it is the slower wave, ~20 k clocks behind at wave A's exit).  Measured at 1024
 // Pong envs (round 6, emu_bench): first chunk 12 / 15 / 18 bands 9.43 M frames/s, 21: 9.39, 27: 9.31, 30: 9.28 — a
 // launch lasts as long as its slowest env, not the mean one.
+#ifndef PARLHIP_OBS_STEP
+#define PARLHIP_OBS_STEP 3
+#endif
 #ifndef PARLHIP_OBS_FIRST
 #define PARLHIP_OBS_FIRST 18
 #endif
-constexpr int kObsBandRows = 5, kObsBands = kH / kObsBandRows, kObsFirst = PARLHIP_OBS_FIRST, kObsStep = 3;
+constexpr int kObsBandRows = 5, kObsBands = kH / kObsBandRows, kObsFirst = PARLHIP_OBS_FIRST, kObsStep = PARLHIP_OBS_STEP;
 static_assert(kObsBands % kObsStep == 0 && kObsFirst % kObsStep == 0 && kObsFirst > 0 && kObsFirst < kObsBands, "whole steps");
 constexpr int kMaxInstrPerFrame = 25000;  // Stella: m6502().execute(25000)
 

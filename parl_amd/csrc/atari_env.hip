@@ -298,7 +298,7 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
       const StepFuse* fz = fuse_args();
       const int dim = fz->dim;
       obs_tail_dispatch(frames + (size_t)e * 2 * kFrameBytes, fz->obs_out + (size_t)e * dim * dim, fz->tables,
-                        rom_lds + kMaxRomWords / 2, dim, kObsBands / 2, kObsBands, exit_w0 & 1, wave);
+                        rom_lds + kMaxRomWords / 2, dim, kObsFirst, kObsBands, exit_w0 & 1, wave);
     }
     return;
   }
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
         k_tail2 = __builtin_readcyclecounter();
 #endif
         obs_tail_dispatch(buf0, obs_out + (size_t)e * dim * dim, fz->tables, rom_lds + kMaxRomWords / 2, dim, 0,
-                          kObsBands / 2, v.obs_single, wave);
+                          kObsFirst, v.obs_single, wave);
       }
     }
   }

@@ -35,6 +35,9 @@ typedef __attribute__((address_space(3))) tail_u4 tail_lds_u4;
 typedef __attribute__((address_space(1))) uint8_t tail_glb_u8;
 typedef __attribute__((address_space(1))) const tail_u4 tail_glb_cu4;
 
+#ifndef PARLHIP_TAIL_DEPTH
+#define PARLHIP_TAIL_DEPTH 3
+#endif
 constexpr int kTailBandRows = kObsBandRows;            // source rows per band (5)
 constexpr int kTailBands = kH / kTailBandRows;         // 42
 constexpr int kTailBandBytes = kTailBandRows * kW;     // 800
@@ -110,8 +113,8 @@ static __device__ __attribute__((noinline)) void obs_tail_main(const uint8_t* fr
   const bool loader = lane < kTailBandLanes;
   // the colour pixels of kTailDepth bands are in flight at any time: the frame pair was stored by the picture wave long
   // ago and comes from HBM / the far L2 (1024 envs x 67 KB), one band ahead left a memory round trip per band exposed
-  constexpr int kTailDepth = 3;
-  static_assert((kTailBands / 2) % kTailDepth == 0 && kObsStep % kTailDepth == 0, "the band loop is unrolled by the prefetch depth");
+  constexpr int kTailDepth = PARLHIP_TAIL_DEPTH;
+  static_assert(kObsFirst % kTailDepth == 0 && (kObsBands - kObsFirst) % kTailDepth == 0 && kObsStep % kTailDepth == 0, "the band loop is unrolled by the prefetch depth");
   tail_u4 pa[kTailDepth], pb[kTailDepth];
 #pragma unroll
   for (int s = 0; s < kTailDepth; ++s) { pa[s] = tail_u4{0u, 0u, 0u, 0u}; pb[s] = pa[s]; }
