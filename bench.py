@@ -83,9 +83,9 @@ class KernelTimer(object):
 # SQ counters of atari_env_kernel<Pong> at E = 1024 (profiles/r05_env_pmc.log: the kernel with the policy head at its head
 # and the observation at its tail): active instructions per wave-clock of the two waves an env occupies
 ENV_PMC = {'game': 'PongNoFrameskip-v4', 'envs': 1024, 'dim': 42,
-           'issue_slot_utilisation': 70759.0 / 161931.0, 'instructions_per_frame': 70759,
+           'issue_slot_utilisation': 69620.0 / 160725.0, 'instructions_per_frame': 69620,
            'source': 'profiles/r06_env_pmc.log (rocprofv3 --pmc, tools/pmc_env.sh): SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES per '
-                     'wave and emulated frame, both in 4-clock issue slots — a wave of this kernel issues in 44 % of its '
+                     'wave and emulated frame, both in 4-clock issue slots — a wave of this kernel issues in 43 % of its '
                      'slots, two such waves share a SIMD'}
 
 
