@@ -252,6 +252,32 @@ def test_missing_rank_makes_init_raise_within_the_timeout():
     assert time.time() - t0 < 60
 
 
+def test_captures_are_thread_local_once_a_process_group_exists():
+    """parl_amd.dist.graph_capture_kwargs(): every hipGraph capture of the package (rollout segments, the A2C rollout,
+    all forms of the update graph) takes it.  Without a group: torch's default; with one: capture_error_mode
+    'thread_local' — ProcessGroupNCCL's watchdog thread polls its collectives with hipEventQuery and, in the default
+    mode, aborts the process if it does so while a capture is open."""
+    import subprocess
+    code = ('import sys; sys.path.insert(0, %r)\n'
+            'from parl_amd import dist as pdist\n'
+            'assert pdist.graph_capture_kwargs() == {}, pdist.graph_capture_kwargs()\n'
+            'pdist.init(backend="gloo", force=True, timeout_s=30)\n'
+            'assert pdist.graph_capture_kwargs() == {"capture_error_mode": "thread_local"}\n'
+            'print("OK")\n') % ROOT
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=120, text=True)
+    assert p.returncode == 0 and 'OK' in p.stdout, p.stdout[-2000:]
+    src = open(os.path.join(ROOT, 'parl_amd', 'rollout.py')).read() + \
+        open(os.path.join(ROOT, 'parl_amd', 'algorithms', 'impala', 'graphed.py')).read()
+    import re
+    caps = re.findall(r'torch\.cuda\.graph\(([^\n]*)', src)
+    # (every capture call passes the kwargs on: directly, as `tl`, or through a `kw` that was updated with them)
+    assert len(caps) >= 6 and all(('graph_capture_kwargs' in c) or ('**tl' in c) or ('**kw' in c) or ('thread_local' in c)
+                                  for c in caps), caps
+    assert 'kw.update(pdist.graph_capture_kwargs())' in src
+
+
 def _cartpole_dp_worker(rank, world, port, q, updates):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
