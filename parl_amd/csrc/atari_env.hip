@@ -238,7 +238,7 @@ __device__ __attribute__((noinline)) int picture_wave_main(uint8_t* blob_v, cons
   const int e = rfl(e_v);
   if (r.lane == 0 && e < 8192) { g_env_regions[e][9] = r.rt[3]; g_env_regions[e][10] = r.rt[4]; g_env_regions[e][11] = r.rt[0];
     g_env_regions[e][12] = r.rt[1]; g_env_regions[e][13] = (unsigned long long)r.rn[0]; g_env_regions[e][14] = (unsigned long long)r.rn[1];
-    g_env_regions[e][17] = r.rt[2]; g_env_regions[e][18] = (unsigned long long)r.rn[2]; g_env_regions[e][19] = __builtin_readcyclecounter(); }
+    g_env_regions[e][20] = (unsigned long long)r.rn[4]; g_env_regions[e][17] = r.rt[2]; g_env_regions[e][18] = (unsigned long long)r.rn[2]; g_env_regions[e][19] = __builtin_readcyclecounter(); }
 #else
   (void)e_v;
 #endif

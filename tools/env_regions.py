@@ -53,5 +53,6 @@ if __name__ == '__main__':
     print('  %-28s %9.0f clocks before the first frame (staging, load, policy head), %.0f after the last (store %.0f, wait for the picture %.0f, observation %.0f)' % ('A: of the rest', m[3], m[15], m[24], m[25], m[26]))
     print('  %-28s wave A pushes LA_EXIT -> %.0f clocks -> wave B takes the batch that holds it (%.1f records) -> %.0f clocks -> fin' % ('the exit hand-shake:', m[27], m[29], m[28]))
     print('  %-28s %9.0f clocks = %4.1f %% of wave B\'s lifetime (the rest: polling an empty ring)' % ('B: replaying records', m[9], 100 * m[9] / max(m[10], 1)))
+    print('  %-28s %9.0f records per frame, %.0f clocks per record outside tia_update' % ('B:', m[20] / frames, (m[9] - m[11]) / max(m[20], 1)))
     print('  %-28s %9.0f clocks in tia_update (%.1f calls per frame, %.0f clocks each), of it render_seg %.0f clocks (%.1f calls per frame, %.0f each)' %
           ('B:', m[11], m[13] / frames, m[11] / max(m[13], 1), m[12], m[14] / frames, m[12] / max(m[14], 1)))
