@@ -1536,7 +1536,16 @@ static int launch_conv12(const uint8_t* obs, const RingObs& ro, const float* w1,
     }
     attr_set = true;
   }
-  const int grid = n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU;  // 71 KB of LDS: two workgroups per CU
+  // The learner's launches (SAVE forward, backward) run ONE workgroup per CU, the actors' two.  Alone that costs the
+  // learner 7 % (one 1000-row update 0.250 -> 0.269 ms: a single workgroup has nobody to hide its fills behind), but
+  // its conv kernels are what stretches the emulator's waves beside them and one learner wave per SIMD
+  // instead of two stretches them less: pipeline 6.26-6.30 -> 6.42-6.46 M frames/s (128 / 192 / 384 workgroups:
+  // 6.12-6.15 / 6.36 / 6.12-6.14 M; round 6, same box, two runs each).
+#ifndef PARLHIP_C12_LEARNER_GRID
+#define PARLHIP_C12_LEARNER_GRID kNumCU
+#endif
+  const int max_grid = a1_out ? PARLHIP_C12_LEARNER_GRID : 2 * kNumCU;
+  const int grid = n_obs < max_grid ? n_obs : max_grid;  // 71 KB of LDS: two workgroups per CU
 #define PARLHIP_C12(R, P, S, O, RO) \
   conv12_u8_mfma_kernel<R, P, S><<<grid, 256, lds_bytes, stream>>>(O, RO, w1, b1, w2, b2, out, n_obs, packed, a1_out)
   if (a1_out) {
@@ -1688,7 +1697,10 @@ PARLHIP_EXPORT int parlhip_atari84_conv1_ring_packed_u8_f32(const uint8_t* ring,
   return launch_conv1_84(nullptr, RingObs{ring, since, num_slots, E, slot}, wt1, b1, out, E, true, (hipStream_t)stream);
 }
 
-static int conv12_bwd_grid(int n_obs) { return n_obs < 2 * kNumCU ? n_obs : 2 * kNumCU; }  // 69 KB of LDS: two per CU
+#ifndef PARLHIP_C12_LEARNER_GRID
+#define PARLHIP_C12_LEARNER_GRID kNumCU
+#endif
+static int conv12_bwd_grid(int n_obs) { return n_obs < PARLHIP_C12_LEARNER_GRID ? n_obs : PARLHIP_C12_LEARNER_GRID; }  // (69 KB of LDS: two would fit)
 
 PARLHIP_EXPORT size_t parlhip_atari42_conv12_bwd_workspace_bytes(int n_obs) {
   return n_obs <= 0 ? 0 : (size_t)conv12_bwd_grid(n_obs) * kBwdPartial * sizeof(float);
