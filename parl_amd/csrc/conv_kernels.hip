@@ -1100,6 +1100,15 @@ constexpr int kC84PerCU = 1;
 #else
 constexpr int kC84PerCU = 2;
 #endif
+// PARLHIP_C84_LEARNER_PER_CU (experiment): the big launches (>= 4096 observations: the learner's) of the 84x84 kernels
+// that run two workgroups per CU
+#ifndef PARLHIP_C84_LEARNER_PER_CU
+#define PARLHIP_C84_LEARNER_PER_CU kC84PerCU
+#endif
+#ifndef PARLHIP_C84_LEARNER_MIN_OBS
+#define PARLHIP_C84_LEARNER_MIN_OBS 4096
+#endif
+static inline int c84_per_cu(int n_obs) { return n_obs >= PARLHIP_C84_LEARNER_MIN_OBS ? PARLHIP_C84_LEARNER_PER_CU : kC84PerCU; }
 #ifdef PARLHIP_C84_COEX
 #define PARLHIP_C84_BWD_BOUNDS __launch_bounds__(256, 2)
 #else
@@ -1640,7 +1649,7 @@ static int launch_conv1_84(const uint8_t* obs, const RingObs& ro, const float* w
     }
     attr_set = true;
   }
-  const int grid = n_obs < kC84PerCU * kNumCU ? n_obs : kC84PerCU * kNumCU;  // 28 KB of LDS, <= 256 VGPRs: two workgroups per CU
+  const int grid = n_obs < c84_per_cu(n_obs) * kNumCU ? n_obs : c84_per_cu(n_obs) * kNumCU;  // 28 KB of LDS, <= 256 VGPRs: two workgroups per CU
 #define PARLHIP_C184(R, P, O, RO) conv1_84_u8_mfma_kernel<R, P><<<grid, 256, lds_bytes, stream>>>(O, RO, w, b1, out, n_obs)
   if (ro.ring) {
     if (packed) PARLHIP_C184(true, true, nullptr, ro);
@@ -1700,7 +1709,10 @@ PARLHIP_EXPORT int parlhip_atari84_conv1_ring_packed_u8_f32(const uint8_t* ring,
 #ifndef PARLHIP_C12_LEARNER_GRID
 #define PARLHIP_C12_LEARNER_GRID kNumCU
 #endif
-static int conv12_bwd_grid(int n_obs) { return n_obs < PARLHIP_C12_LEARNER_GRID ? n_obs : PARLHIP_C12_LEARNER_GRID; }  // (69 KB of LDS: two would fit)
+#ifndef PARLHIP_C12_LEARNER_BWD_GRID
+#define PARLHIP_C12_LEARNER_BWD_GRID PARLHIP_C12_LEARNER_GRID
+#endif
+static int conv12_bwd_grid(int n_obs) { return n_obs < PARLHIP_C12_LEARNER_BWD_GRID ? n_obs : PARLHIP_C12_LEARNER_BWD_GRID; }  // (69 KB of LDS: two would fit)
 
 PARLHIP_EXPORT size_t parlhip_atari42_conv12_bwd_workspace_bytes(int n_obs) {
   return n_obs <= 0 ? 0 : (size_t)conv12_bwd_grid(n_obs) * kBwdPartial * sizeof(float);
@@ -1783,7 +1795,7 @@ PARLHIP_EXPORT int parlhip_atari84_conv23_f32(const float* a1, const float* wt2,
   }
   // 49 KB of LDS: up to three workgroups per CU (two are launched: more only shortens the streamed-weight reuse),
   // one beside a learner workgroup
-  const int grid = n_obs < kC84PerCU * kNumCU ? n_obs : kC84PerCU * kNumCU;
+  const int grid = n_obs < c84_per_cu(n_obs) * kNumCU ? n_obs : c84_per_cu(n_obs) * kNumCU;
   conv23_84_mfma_kernel<<<grid, 256, lds_bytes, (hipStream_t)stream>>>(a1, wt2, b2, wt3, b3, a2_out, a3_out, n_obs);
   return check_launch();
 }
@@ -1845,7 +1857,7 @@ PARLHIP_EXPORT int parlhip_atari84_conv2_bwd_f32(const float* a1, const float* d
 
 // conv1_84_bwd_kernel: 80.7 KB of LDS and <= 256 VGPRs — two workgroups per CU, each one's fill and store phases under
 // the other's MFMAs (conv3 / conv2: 276+ VGPRs of accumulators, one wave per SIMD whatever the grid)
-static int bwd84_conv1_grid(int n_obs) { return n_obs < kC84PerCU * kNumCU ? n_obs : kC84PerCU * kNumCU; }
+static int bwd84_conv1_grid(int n_obs) { return n_obs < c84_per_cu(n_obs) * kNumCU ? n_obs : c84_per_cu(n_obs) * kNumCU; }
 
 PARLHIP_EXPORT size_t parlhip_atari84_conv1_bwd_workspace_bytes(int n_obs) {
   return n_obs <= 0 ? 0 : (size_t)bwd84_conv1_grid(n_obs) * kPart1 * sizeof(float);
