@@ -231,7 +231,7 @@ __device__ __attribute__((noinline)) int picture_wave_main(uint8_t* blob_v, cons
       r.obs_cur = r.obs_end;
     }
   }
-  // the launch's last frame is drawn and stored: the env's CPU wave may read the frame pair (the observation's halves
+  // the launch's last frame is drawn and stored: the env's CPU wave may read the frame pair (the observation's two chunks
   // when the flagged frame was not the last one)
   __atomic_store_n(&r.rq->fin, 1u, __ATOMIC_RELAXED);
 #ifdef PARLHIP_ENV_REGIONS
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(128 * kEnvsPerBlock, 4) void atari_env_kernel(
     uint8_t* rblob = mode == MODE_SNAPSHOT ? snap + (size_t)e * kSnapBytes : states + (size_t)e * kStateBytes;
     const int exit_w0 = rfl(picture_wave_main(rblob, snap, &rqs[slot], e, frames + (size_t)e * 2 * kFrameBytes,
                                               rom_lds + kMaxRomWords / 2, wave, fuse_args()));
-    if ((exit_w0 & 0x300) == 0x100) {   // wave A asks for the observation of another frame pair than the flagged one: this wave takes the lower half of the picture
+    if ((exit_w0 & 0x300) == 0x100) {   // wave A asks for the observation of another frame pair than the flagged one: this wave takes the second chunk of bands
       const StepFuse* fz = fuse_args();
       const int dim = fz->dim;
       obs_tail_dispatch(frames + (size_t)e * 2 * kFrameBytes, fz->obs_out + (size_t)e * dim * dim, fz->tables,

@@ -9,10 +9,13 @@
 // and it cannot start before the SLOWEST env of the grid has finished; here every env converts its own pair of
 // frames as soon as its picture wave has drawn them, and only the slowest env's conversion is exposed.
 // How: the 210 source rows are 42 bands of 5; an output row's INTER_AREA taps never leave its band for dim in
-// {42, 84} (210 / 5 = 42 divides dim).  The env's CPU wave takes bands 0 .. 20, its picture wave 21 .. 41 — no
-// barrier between them, each has its own 800-byte gray band in LDS.  Per band: 50 lanes load one uint4 of each
-// colour frame (the next band's are already in flight), max + gray through the two LDS tables, band to LDS, then
-// lane = output column: the band's y taps (prefetched by lanes 0 .. 15) times the lane's x taps (registers).
+// {42, 84} (210 / 5 = 42 divides dim).  The env's two waves claim the bands in two chunks from a counter in the env's
+// ring header (the CPU wave bands 0 .. 17 at its last instruction, the picture wave the rest when it has replayed its
+// last records; atari_defs.hpp kObsFirst, atari_core.hpp RenderQueue::obs_next) — no barrier between them, each has
+// its own 800-byte gray band in LDS.  Per band: 50 lanes load one uint4 of each colour frame (three bands' loads in
+// flight), a band of one colour in both frames is stored as that colour's gray at once; otherwise max + gray through
+// the two LDS tables, band to LDS, then lane = output column: the band's y taps times the lane's x taps (registers,
+// from the lane-ordered copy at the head of the tables blob).
 // LDS: the upper half of the cartridge table's 16 KB (an unbanked 2K cartridge — Pong, Breakout — fills the lower
 // half; a 4K cartridge takes the separate launch): no byte added to the env kernel's static LDS, which is what
 // lets it sit beside two 70 KB learner workgroups on a CU.
@@ -61,7 +64,7 @@ DEVI void obs_tail_stage_tables(uint32_t* lds_hi, const uint8_t* blob, int tid) 
   }
 }
 
-// One half (half 0: bands 0 .. 20, half 1: 21 .. 41) of one env's observation.  frames: the env's colour frame
+// Bands [b_begin, b_end) of one env's observation (a claimed chunk or part of it, atari_defs.hpp kObsFirst).  frames: the env's colour frame
 // pair; out: its dim x dim slot of the rollout ring; `wave`: which of the workgroup's eight band buffers is this
 // wave's.  Arguments arrive in vector registers (a call) and are made wave-uniform again.
 // The tap structure of the two supported sizes is fixed (tests/test_frame_oracle_pin.py checks the host-built tables
@@ -108,7 +111,7 @@ static __device__ __attribute__((noinline)) void obs_tail_main(const uint8_t* fr
 #pragma unroll
     for (int k = 0; k < NX; ++k) xtap[c][k] = lt[(c * NX + k) * 64 + lane];
   const unsigned long long ytap = lt[NC * NX * 64 + (lane < M * NY ? lane : 0)];
-  // bands b_begin .. b_end - 1: a multiple of kTailDepth of them (the halves 0 .. 20 / 21 .. 41, or kObsStep * n bands
+  // bands b_begin .. b_end - 1: a multiple of kTailDepth of them (the chunks 0 .. 17 / 18 .. 41, or kObsStep * n bands
   // of a chunk claimed from the env's band counter, atari_core.hpp RenderQueue::obs_next)
   const bool loader = lane < kTailBandLanes;
   // the colour pixels of kTailDepth bands are in flight at any time: the frame pair was stored by the picture wave long
