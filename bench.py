@@ -609,7 +609,7 @@ def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=5)   # (rollout segments are captured as hipGraphs on their second run: fewer warm-up steps put captures into the timed region)
     ap.add_argument('--envs', type=int, default=1024, help='envs (actors) per GPU')
     ap.add_argument('--dim', type=int, default=42, help='obs size: 42 = examples/IMPALA config, 84 = A2C model')
     ap.add_argument('--sample-batch-steps', type=int, default=50)
